@@ -1,0 +1,39 @@
+# Build of libpcc_nn (gfx950 HIP kernels + C-ABI), the CPU oracle and helper tools.
+# hipcc cross-compiles gfx950 without a GPU.  -ffp-contract=off everywhere: the
+# distance arithmetic must round like FLANN's L2_Simple (no FMA).
+HIPCC      ?= /opt/rocm/bin/hipcc
+CC         ?= gcc
+CXX        ?= g++
+ARCH       ?= gfx950
+HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -Iinclude -Ipointcloudcomparator_amd/csrc
+CSRC       := pointcloudcomparator_amd/csrc
+LIBDIR     := pointcloudcomparator_amd/lib
+HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip)
+HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
+
+all: lib oracle
+
+lib: $(LIBDIR)/libpcc_nn.so
+oracle: oracle/_build/libpcc_oracle.so
+ubench: build/ubench_valu
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp include/pcc_nn.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libpcc_nn.so: $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+
+oracle/_build/libpcc_oracle.so: oracle/pcc_oracle.c oracle/pcc_oracle.h
+	@mkdir -p oracle/_build
+	$(CC) -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread -o $@ oracle/pcc_oracle.c -lm
+
+build/ubench_valu: $(CSRC)/ubench_valu.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
+clean:
+	rm -rf build $(LIBDIR)/*.so oracle/_build
+
+.PHONY: all lib oracle ubench clean

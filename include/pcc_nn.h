@@ -1,0 +1,179 @@
+/*
+ * pcc_nn.h -- C-ABI of libpcc_nn: the MI355X (gfx950) nearest-neighbour /
+ * radius-search engine that replaces the pcl::KdTreeFLANN path of
+ * adr-arroyo/PointCloudComparator.
+ *
+ * The reference has no FFI layer: it calls PCL C++ classes one query at a time
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference tree).  Everything is plain C:
+ * opaque handle, pointers, sizes, int status.  No allocation crosses the ABI;
+ * outputs are caller-allocated.
+ *
+ * Memory spaces: every data pointer is tagged by a `mem` argument --
+ * PCC_MEM_HOST (library copies H2D/D2H itself) or PCC_MEM_DEVICE (pointer is
+ * HBM on the index's device; results are written to device memory on the
+ * index's stream and the call returns without synchronising).
+ *
+ * Points are AoS with a byte stride; the first `dim` floats of each element
+ * are the coordinates.  dim must be 3 -- that is what every hot call site of
+ * the reference searches on (pcl::PointXYZRGB 32 B, pcl::PointXYZ 16 B, and
+ * pcl::Histogram<32> 128 B through PCL's 3-float DefaultPointRepresentation,
+ * SURVEY.md 3.2 / 9.1).
+ *
+ * Semantics shared by all searches:
+ *   - reference points with a non-finite coordinate are skipped; returned
+ *     indices are positions in the ORIGINAL cloud (PCL index_mapping_);
+ *   - d2 = ((dx*dx)+dy*dy)+dz*dz in fp32, every op rounded separately
+ *     (FLANN L2_Simple<float>); distances are SQUARED;
+ *   - exact-distance ties resolve to the LOWEST original index;
+ *   - a non-finite query never aborts: idx = -1, d2 = +inf, count = 0.
+ */
+#ifndef PCC_NN_H
+#define PCC_NN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCC_VERSION 100
+
+typedef struct pcc_index pcc_index;
+
+enum pcc_status {
+    PCC_OK = 0,
+    PCC_ERR_INVALID = -1,     /* bad argument */
+    PCC_ERR_EMPTY = -2,       /* no valid reference point ("Cannot create a KDTree with an empty input cloud") */
+    PCC_ERR_DEVICE = -3,      /* HIP runtime failure (no GPU, launch error, ...) */
+    PCC_ERR_NOMEM = -4,
+    PCC_ERR_UNSUPPORTED = -5, /* dim != 3, k too large, ... */
+    PCC_ERR_OVERFLOW = -6     /* caller-provided output capacity too small */
+};
+enum pcc_mem { PCC_MEM_HOST = 0, PCC_MEM_DEVICE = 1 };
+/* search engine behind an index.  Both are exact and return identical bits.
+ *   BRUTE: tiled exhaustive scan (query tile in registers, reference tile in LDS)
+ *   GRID : cell-sorted references, exact ring search with conservative bounds,
+ *          BRUTE fallback for queries the rings do not resolve
+ *   AUTO : GRID when the cloud is large enough to amortise its build. */
+enum pcc_engine { PCC_ENGINE_AUTO = 0, PCC_ENGINE_BRUTE = 1, PCC_ENGINE_GRID = 2 };
+
+#define PCC_KNN_MAX_K 128
+
+int pcc_version(void);
+/* thread-local message for the last non-OK status returned on this thread */
+const char *pcc_last_error(void);
+int pcc_device_count(int *count);
+
+/* ---- index lifetime -------------------------------------------------------
+ * replaces: pcl::KdTreeFLANN<T> ctor + setInputCloud (src/comparator.cpp:564-565),
+ *           pcl::search::KdTree<T>::setInputCloud (src/segmentation.cpp:120-122)
+ *           and the trees ICP / SOR / EC build internally
+ *           (src/comparator.cpp:1096,1527,1541; src/segmentation.cpp:131).
+ * Copies (uploads) the cloud; the caller may free `pts` after the call. */
+int pcc_index_create(const void *pts, size_t n, size_t stride_bytes, int dim,
+                     int mem, int device, int engine, pcc_index **out);
+int pcc_index_destroy(pcc_index *index);
+/* number of valid (finite) reference points == PCL total_nr_points_ */
+int pcc_index_size(const pcc_index *index, size_t *n_valid);
+/* run this index's work on a caller-owned hipStream_t (NULL = library stream) */
+int pcc_index_set_stream(pcc_index *index, void *hip_stream);
+int pcc_index_sync(pcc_index *index);
+/* engine actually in use (PCC_ENGINE_BRUTE or PCC_ENGINE_GRID) */
+int pcc_index_engine(const pcc_index *index, int *engine);
+/* force the engine for subsequent searches on this index */
+int pcc_index_set_engine(pcc_index *index, int engine);
+
+/* ---- k = 1 nearest neighbour ------------------------------------------------
+ * replaces: N calls of KdTreeFLANN::nearestKSearch(pt, 1, idx, d2)
+ *           (src/comparator.cpp:571-577; ICP determineCorrespondences and
+ *           getFitnessScore reached from :1096,:1099).
+ * idx[nq], d2[nq] live in the same memory space as the queries. */
+int pcc_nn1(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes,
+            int mem, int32_t *idx, float *d2);
+
+/* ---- k nearest neighbours ---------------------------------------------------
+ * replaces: nearestKSearch(pt, k, ...) with k = mean_k+1 = 51 inside
+ *           StatisticalOutlierRemoval (src/comparator.cpp:1523-1541).
+ * Row i holds min(k, n_valid) results ascending by (d2, idx), padded with
+ * idx=-1, d2=+inf.  1 <= k <= PCC_KNN_MAX_K. */
+int pcc_knn(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes,
+            int mem, int k, int32_t *idx, float *d2);
+
+/* ---- radius search ------------------------------------------------------------
+ * replaces: KdTreeFLANN::radiusSearch(pt, radius, idx, d2, max_nn = 0) as used
+ *           by pcl::extractEuclideanClusters (src/segmentation.cpp:125-131).
+ * r2 = float(radius*radius) evaluated in double; the test is strict d2 < r2.
+ * Two-pass CSR: count, caller prefix-sums into offsets[nq+1], fill.  With
+ * sorted != 0 each row is ascending by (d2, idx) (PCL's sorted results). */
+int pcc_radius_count(pcc_index *index, const void *queries, size_t nq,
+                     size_t stride_bytes, int mem, double radius, int32_t *counts);
+int pcc_radius_fill(pcc_index *index, const void *queries, size_t nq,
+                    size_t stride_bytes, int mem, double radius, int sorted,
+                    const int64_t *offsets, int32_t *idx, float *d2);
+
+/* ---- Euclidean clustering -----------------------------------------------------
+ * replaces: pcl::EuclideanClusterExtraction::extract with
+ *           setClusterTolerance/MinClusterSize/MaxClusterSize
+ *           (src/segmentation.cpp:125-131): connected components of the graph
+ *           d2(i,j) < float(double(float(tol))^2) over the indexed cloud,
+ *           filtered to [min_size, max_size], ordered by size descending
+ *           (ties: lowest member index first).
+ * labels[n_original] (memory space `mem`): cluster id or -1.  sizes[] (host,
+ * nullable) receives up to max_sizes cluster sizes.  *n_clusters (host). */
+int pcc_euclidean_clusters(pcc_index *index, double tolerance, uint32_t min_size,
+                           uint32_t max_size, int mem, int32_t *labels,
+                           int32_t *n_clusters, int32_t *sizes, int max_sizes);
+
+/* ---- statistical outlier removal ------------------------------------------------
+ * replaces: pcl::StatisticalOutlierRemoval::filter, setMeanK / setStddevMulThresh
+ *           (src/comparator.cpp:1523-1527, 1537-1541).  Self-query of the
+ *           indexed cloud with k = mean_k+1; mean_dist[i] = float(sum_{j=1..k-1}
+ *           sqrt(d2_j) / mean_k) (double sum); threshold = mean + mult*stddev
+ *           (double, n-1); inlier[i] = mean_dist[i] <= threshold.
+ * mean_dist / inlier have n_original entries in memory space `mem` (either may
+ * be NULL); *threshold and *kept are host scalars. */
+int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
+            float *mean_dist, uint8_t *inlier, double *threshold, size_t *kept);
+
+/* ---- ICP building blocks ----------------------------------------------------------
+ * replaces: pcl::IterativeClosestPoint::align / getFitnessScore
+ *           (src/comparator.cpp:1091-1099).
+ * pcc_icp_step: NN of every source point against the target index plus the
+ *   double-precision sums Umeyama needs, fused in one pass.
+ *   sums[0..2]=sum p, [3..5]=sum q, [6..14]=sum q p^T (row-major, q row, p col),
+ *   [15]=sum d2, [16]=count.  idx/d2 may be NULL.  sums is a HOST array.
+ * pcc_transform: dst = T * src with PCL's transformPointCloud rounding
+ *   ((m0*x + m1*y) + m2*z) + m3; T row-major 4x4 (host); dst may alias src.
+ * pcc_icp_align: the whole loop on the device (source stays resident):
+ *   max_iter iterations (early exit on |mse-prev| < 1e-12 unless fixed != 0),
+ *   final transform T (host, row-major), *fitness = mean squared NN distance of
+ *   the finally transformed source, *converged as PCL's hasConverged(). */
+int pcc_icp_step(pcc_index *target, const void *src, size_t n, size_t stride_bytes,
+                 int mem, int32_t *idx, float *d2, double sums[17]);
+int pcc_transform(pcc_index *ctx, const float T[16], const void *src, size_t n,
+                  size_t src_stride, void *dst, size_t dst_stride, int mem);
+int pcc_icp_align(pcc_index *target, const void *src, size_t n, size_t stride_bytes,
+                  int mem, int max_iter, int fixed, float T[16], double *fitness,
+                  int *iterations, int *converged);
+
+/* ---- descriptor correspondence ------------------------------------------------------
+ * replaces: matchRIFTFeaturesKnn (src/comparator.cpp:560-588): index built on
+ *   descriptors1, one k=1 query per element of descriptors2, a match is kept
+ *   when d2 < threshold (0.05f in the reference).  out[0] = 0 is the dummy
+ *   element the reference's vector starts with (:568); *out_size = 1 + matches.
+ *   out is a HOST array of at least n2+1 ints. */
+int pcc_match_knn(pcc_index *index_des1, const void *des2, size_t n2,
+                  size_t stride_bytes, int mem, float threshold, int32_t *out,
+                  int32_t *out_size);
+
+/* ---- instrumentation ------------------------------------------------------------------
+ * counters of the last search on this index (host):
+ *  stats[0] queries resolved by the GRID engine, [1] queries sent to the BRUTE
+ *  fallback, [2] reference points valid, [3] grid cells, [4] pair evaluations
+ *  (GRID engine, when counting is compiled in; else 0). */
+int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,762 @@
+/*
+ * pcc_oracle.c -- CPU restatement of the reference's NN path (see pcc_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY / PARITY UNPINNED (no reference fixtures exist; PCL
+ * and FLANN are absent from /root/reference and from this image).  Each block
+ * cites the SURVEY.md section 9 paragraph (the restated PCL 1.7 / FLANN 1.8.4
+ * behaviour) and the reference call site it serves.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction: FLANN's
+ * L2_Simple was compiled for x86-64 SSE2 with separately rounded mul/add).
+ */
+#include "pcc_oracle.h"
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LEAF_MAX 15 /* KDTreeSingleIndexParams(15), SURVEY 9.1 */
+
+static inline const float *pt_at(const void *base, size_t stride, size_t i) {
+    return (const float *)((const char *)base + stride * i);
+}
+static inline int finite3(const float *p) {
+    return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]);
+}
+/* FLANN L2_Simple<float>::operator(): result=0; result+=diff*diff per dim (9.2) */
+static inline float l2_simple(const float *a, const float *b) {
+    float r = 0.0f, d;
+    d = a[0] - b[0]; r += d * d;
+    d = a[1] - b[1]; r += d * d;
+    d = a[2] - b[2]; r += d * d;
+    return r;
+}
+
+/* ===================== exhaustive definitional oracle ===================== */
+
+void orc_nn1_exhaustive(const void *ref, size_t m, size_t rstride,
+                        const void *qry, size_t n, size_t qstride,
+                        int32_t *idx, float *d2) {
+    for (size_t i = 0; i < n; ++i) {
+        const float *q = pt_at(qry, qstride, i);
+        int32_t bi = -1;
+        float bd = INFINITY;
+        if (finite3(q)) {
+            for (size_t j = 0; j < m; ++j) {
+                const float *r = pt_at(ref, rstride, j);
+                if (!finite3(r)) continue;
+                float d = l2_simple(q, r);
+                if (bi < 0 || d < bd) { bd = d; bi = (int32_t)j; } /* strict <: lowest index wins */
+            }
+        }
+        idx[i] = bi;
+        d2[i] = bd;
+    }
+}
+
+typedef struct { float d; int32_t i; } di_t;
+static int di_cmp(const void *a, const void *b) {
+    const di_t *x = (const di_t *)a, *y = (const di_t *)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+int orc_knn_exhaustive(const void *ref, size_t m, size_t rstride,
+                       const void *qry, size_t n, size_t qstride, int k,
+                       int32_t *idx, float *d2) {
+    di_t *all = (di_t *)malloc(sizeof(di_t) * (m ? m : 1));
+    int found = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float *q = pt_at(qry, qstride, i);
+        size_t c = 0;
+        if (finite3(q)) {
+            for (size_t j = 0; j < m; ++j) {
+                const float *r = pt_at(ref, rstride, j);
+                if (!finite3(r)) continue;
+                all[c].d = l2_simple(q, r);
+                all[c].i = (int32_t)j;
+                ++c;
+            }
+            qsort(all, c, sizeof(di_t), di_cmp);
+        }
+        for (int t = 0; t < k; ++t) {
+            if ((size_t)t < c) { idx[i * k + t] = all[t].i; d2[i * k + t] = all[t].d; }
+            else { idx[i * k + t] = -1; d2[i * k + t] = INFINITY; }
+        }
+        found = (int)(c < (size_t)k ? c : (size_t)k);
+    }
+    free(all);
+    return found;
+}
+
+void orc_radius_count_exhaustive(const void *ref, size_t m, size_t rstride,
+                                 const void *qry, size_t n, size_t qstride,
+                                 float r2, int32_t *counts) {
+    for (size_t i = 0; i < n; ++i) {
+        const float *q = pt_at(qry, qstride, i);
+        int32_t c = 0;
+        if (finite3(q))
+            for (size_t j = 0; j < m; ++j) {
+                const float *r = pt_at(ref, rstride, j);
+                if (finite3(r) && l2_simple(q, r) < r2) ++c; /* strict, 9.3 */
+            }
+        counts[i] = c;
+    }
+}
+
+/* =============== FLANN KDTreeSingleIndex restatement (9.2) ================ */
+
+typedef struct { float low, high; } interval_t;
+typedef struct kdnode {
+    int left, right;       /* leaf: [left,right) into the reordered data */
+    int divfeat;           /* inner */
+    float divlow, divhigh; /* inner */
+    int child1, child2;    /* node indices, -1 for leaf */
+} kdnode;
+
+struct orc_kdtree {
+    size_t n;        /* valid points */
+    float *pts;      /* dense n*3, PCL convertCloudToArray order (9.1) */
+    int32_t *map;    /* index_mapping_: dense -> original */
+    int *vind;       /* FLANN vind_ */
+    float *data;     /* reordered copy (reorder = true) */
+    kdnode *nodes;
+    size_t nnodes, capnodes;
+    int root;
+    interval_t root_bbox[3];
+};
+
+static int new_node(orc_kdtree *t) {
+    if (t->nnodes == t->capnodes) {
+        t->capnodes = t->capnodes ? t->capnodes * 2 : 1024;
+        t->nodes = (kdnode *)realloc(t->nodes, t->capnodes * sizeof(kdnode));
+    }
+    kdnode *nd = &t->nodes[t->nnodes];
+    nd->child1 = nd->child2 = -1;
+    return (int)t->nnodes++;
+}
+
+static void compute_minmax(const orc_kdtree *t, const int *ind, int count, int dim,
+                           float *mn, float *mx) {
+    *mn = *mx = t->pts[(size_t)ind[0] * 3 + dim];
+    for (int i = 1; i < count; ++i) {
+        float v = t->pts[(size_t)ind[i] * 3 + dim];
+        if (v < *mn) *mn = v;
+        if (v > *mx) *mx = v;
+    }
+}
+
+/* KDTreeSingleIndex::planeSplit */
+static void plane_split(const orc_kdtree *t, int *ind, int count, int cutfeat,
+                        float cutval, int *lim1, int *lim2) {
+    int left = 0, right = count - 1;
+    for (;;) {
+        while (left <= right && t->pts[(size_t)ind[left] * 3 + cutfeat] < cutval) ++left;
+        while (left <= right && t->pts[(size_t)ind[right] * 3 + cutfeat] >= cutval) --right;
+        if (left > right) break;
+        int tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim1 = left;
+    right = count - 1;
+    for (;;) {
+        while (left <= right && t->pts[(size_t)ind[left] * 3 + cutfeat] <= cutval) ++left;
+        while (left <= right && t->pts[(size_t)ind[right] * 3 + cutfeat] > cutval) --right;
+        if (left > right) break;
+        int tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim2 = left;
+}
+
+/* KDTreeSingleIndex::middleSplit */
+static void middle_split(const orc_kdtree *t, int *ind, int count, int *index,
+                         int *cutfeat, float *cutval, const interval_t *bbox) {
+    float max_span = bbox[0].high - bbox[0].low;
+    *cutfeat = 0;
+    *cutval = (bbox[0].high + bbox[0].low) / 2;
+    for (int i = 1; i < 3; ++i) {
+        float span = bbox[i].high - bbox[i].low;
+        if (span > max_span) {
+            max_span = span;
+            *cutfeat = i;
+            *cutval = (bbox[i].high + bbox[i].low) / 2;
+        }
+    }
+    float mn, mx;
+    compute_minmax(t, ind, count, *cutfeat, &mn, &mx);
+    *cutval = (mn + mx) / 2;
+    max_span = mx - mn;
+    int k = *cutfeat;
+    for (int i = 0; i < 3; ++i) {
+        if (i == k) continue;
+        float span = bbox[i].high - bbox[i].low;
+        if (span > max_span) {
+            compute_minmax(t, ind, count, i, &mn, &mx);
+            span = mx - mn;
+            if (span > max_span) {
+                max_span = span;
+                *cutfeat = i;
+                *cutval = (mn + mx) / 2;
+            }
+        }
+    }
+    int lim1, lim2;
+    plane_split(t, ind, count, *cutfeat, *cutval, &lim1, &lim2);
+    if (lim1 > count / 2) *index = lim1;
+    else if (lim2 < count / 2) *index = lim2;
+    else *index = count / 2;
+}
+
+/* KDTreeSingleIndex::divideTree */
+static int divide_tree(orc_kdtree *t, int left, int right, interval_t *bbox) {
+    int ni = new_node(t);
+    if (right - left <= LEAF_MAX) {
+        t->nodes[ni].left = left;
+        t->nodes[ni].right = right;
+        for (int d = 0; d < 3; ++d)
+            bbox[d].low = bbox[d].high = t->pts[(size_t)t->vind[left] * 3 + d];
+        for (int k = left + 1; k < right; ++k)
+            for (int d = 0; d < 3; ++d) {
+                float v = t->pts[(size_t)t->vind[k] * 3 + d];
+                if (v < bbox[d].low) bbox[d].low = v;
+                if (v > bbox[d].high) bbox[d].high = v;
+            }
+    } else {
+        int idx, cutfeat;
+        float cutval;
+        middle_split(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, bbox);
+        interval_t lb[3], rb[3];
+        memcpy(lb, bbox, sizeof(lb));
+        memcpy(rb, bbox, sizeof(rb));
+        lb[cutfeat].high = cutval;
+        int c1 = divide_tree(t, left, left + idx, lb);
+        rb[cutfeat].low = cutval;
+        int c2 = divide_tree(t, left + idx, right, rb);
+        kdnode *nd = &t->nodes[ni]; /* re-fetch: realloc may have moved nodes */
+        nd->divfeat = cutfeat;
+        nd->child1 = c1;
+        nd->child2 = c2;
+        nd->divlow = lb[cutfeat].high;
+        nd->divhigh = rb[cutfeat].low;
+        for (int d = 0; d < 3; ++d) {
+            bbox[d].low = lb[d].low < rb[d].low ? lb[d].low : rb[d].low;
+            bbox[d].high = lb[d].high > rb[d].high ? lb[d].high : rb[d].high;
+        }
+    }
+    return ni;
+}
+
+orc_kdtree *orc_kdtree_build(const void *pts, size_t m, size_t stride) {
+    orc_kdtree *t = (orc_kdtree *)calloc(1, sizeof(*t));
+    t->pts = (float *)malloc(sizeof(float) * 3 * (m ? m : 1));
+    t->map = (int32_t *)malloc(sizeof(int32_t) * (m ? m : 1));
+    /* KdTreeFLANN::convertCloudToArray: skip invalid, keep order (9.1) */
+    size_t c = 0;
+    for (size_t i = 0; i < m; ++i) {
+        const float *p = pt_at(pts, stride, i);
+        if (!finite3(p)) continue;
+        t->pts[c * 3 + 0] = p[0];
+        t->pts[c * 3 + 1] = p[1];
+        t->pts[c * 3 + 2] = p[2];
+        t->map[c] = (int32_t)i;
+        ++c;
+    }
+    t->n = c;
+    if (c == 0) { orc_kdtree_free(t); return NULL; }
+    t->vind = (int *)malloc(sizeof(int) * c);
+    for (size_t i = 0; i < c; ++i) t->vind[i] = (int)i;
+    for (int d = 0; d < 3; ++d) {
+        float mn, mx;
+        compute_minmax(t, t->vind, (int)c, d, &mn, &mx);
+        t->root_bbox[d].low = mn;
+        t->root_bbox[d].high = mx;
+    }
+    interval_t bb[3];
+    memcpy(bb, t->root_bbox, sizeof(bb));
+    t->root = divide_tree(t, 0, (int)c, bb);
+    t->data = (float *)malloc(sizeof(float) * 3 * c);
+    for (size_t i = 0; i < c; ++i)
+        memcpy(t->data + i * 3, t->pts + (size_t)t->vind[i] * 3, 3 * sizeof(float));
+    return t;
+}
+
+void orc_kdtree_free(orc_kdtree *t) {
+    if (!t) return;
+    free(t->pts); free(t->map); free(t->vind); free(t->data); free(t->nodes);
+    free(t);
+}
+size_t orc_kdtree_size(const orc_kdtree *t) { return t ? t->n : 0; }
+
+/* result sets ------------------------------------------------------------- */
+typedef struct {
+    int knn_cap, knn_cnt; /* KNNSimpleResultSet */
+    float worst;
+    di_t *items;
+    int radius_mode;      /* RadiusResultSet */
+    float radius;
+    size_t rcnt, rcap;
+} rset_t;
+
+static inline void rset_add(rset_t *rs, float dist, int32_t index) {
+    if (rs->radius_mode) {
+        if (dist < rs->radius) { /* strict (9.3) */
+            if (rs->rcnt == rs->rcap) {
+                rs->rcap = rs->rcap ? rs->rcap * 2 : 64;
+                rs->items = (di_t *)realloc(rs->items, rs->rcap * sizeof(di_t));
+            }
+            rs->items[rs->rcnt].d = dist;
+            rs->items[rs->rcnt].i = index;
+            rs->rcnt++;
+        }
+        return;
+    }
+    /* KNNSimpleResultSet::addPoint: ties keep the earlier-visited point */
+    if (dist >= rs->worst) return;
+    if (rs->knn_cnt < rs->knn_cap) ++rs->knn_cnt;
+    int i;
+    for (i = rs->knn_cnt - 1; i > 0; --i) {
+        if (rs->items[i - 1].d > dist) rs->items[i] = rs->items[i - 1];
+        else break;
+    }
+    rs->items[i].d = dist;
+    rs->items[i].i = index;
+    rs->worst = rs->items[rs->knn_cap - 1].d;
+}
+
+/* KDTreeSingleIndex::searchLevel, epsError = 1 (eps = 0, exact) */
+static void search_level(const orc_kdtree *t, rset_t *rs, const float *q, int ni,
+                         float mindistsq, float dists[3]) {
+    const kdnode *nd = &t->nodes[ni];
+    if (nd->child1 < 0) {
+        float worst = rs->radius_mode ? rs->radius : rs->worst;
+        for (int i = nd->left; i < nd->right; ++i) {
+            float d = l2_simple(q, t->data + (size_t)i * 3);
+            if (d < worst) rset_add(rs, d, t->vind[i]);
+        }
+        return;
+    }
+    int f = nd->divfeat;
+    float val = q[f];
+    float diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+    int best, other;
+    float cut;
+    if ((diff1 + diff2) < 0) {
+        best = nd->child1; other = nd->child2;
+        cut = (val - nd->divhigh) * (val - nd->divhigh);
+    } else {
+        best = nd->child2; other = nd->child1;
+        cut = (val - nd->divlow) * (val - nd->divlow);
+    }
+    search_level(t, rs, q, best, mindistsq, dists);
+    float dst = dists[f];
+    mindistsq = mindistsq + cut - dst;
+    dists[f] = cut;
+    float worst = rs->radius_mode ? rs->radius : rs->worst;
+    if (mindistsq <= worst) search_level(t, rs, q, other, mindistsq, dists);
+    dists[f] = dst;
+}
+
+static void find_neighbors(const orc_kdtree *t, rset_t *rs, const float *q) {
+    float dists[3] = {0, 0, 0};
+    float distsq = 0;
+    for (int d = 0; d < 3; ++d) { /* computeInitialDistances */
+        if (q[d] < t->root_bbox[d].low) {
+            dists[d] = (q[d] - t->root_bbox[d].low) * (q[d] - t->root_bbox[d].low);
+            distsq += dists[d];
+        }
+        if (q[d] > t->root_bbox[d].high) {
+            dists[d] = (q[d] - t->root_bbox[d].high) * (q[d] - t->root_bbox[d].high);
+            distsq += dists[d];
+        }
+    }
+    search_level(t, rs, q, t->root, distsq, dists);
+}
+
+int orc_kdtree_knn(const orc_kdtree *t, const float q[3], int k, int32_t *idx, float *d2) {
+    if (!t || !finite3(q)) return 0; /* PCL asserts on invalid query (9.1) */
+    if ((size_t)k > t->n) k = (int)t->n;
+    if (k <= 0) return 0;
+    di_t stack_items[64];
+    rset_t rs;
+    memset(&rs, 0, sizeof(rs));
+    rs.knn_cap = k;
+    rs.items = k <= 64 ? stack_items : (di_t *)malloc(sizeof(di_t) * k);
+    rs.items[k - 1].d = FLT_MAX; /* KNNSimpleResultSet::clear */
+    rs.worst = FLT_MAX;
+    find_neighbors(t, &rs, q);
+    for (int i = 0; i < rs.knn_cnt; ++i) {
+        idx[i] = t->map[rs.items[i].i]; /* index_mapping_ (9.1) */
+        d2[i] = rs.items[i].d;
+    }
+    int c = rs.knn_cnt;
+    if (rs.items != stack_items) free(rs.items);
+    return c;
+}
+
+int orc_kdtree_radius(const orc_kdtree *t, const float q[3], float r2, int sorted,
+                      int32_t *idx, float *d2, int cap) {
+    if (!t || !finite3(q)) return 0;
+    rset_t rs;
+    memset(&rs, 0, sizeof(rs));
+    rs.radius_mode = 1;
+    rs.radius = r2;
+    find_neighbors(t, &rs, q);
+    for (size_t i = 0; i < rs.rcnt; ++i) rs.items[i].i = t->map[rs.items[i].i];
+    if (sorted) qsort(rs.items, rs.rcnt, sizeof(di_t), di_cmp); /* (dist, index) */
+    for (size_t i = 0; i < rs.rcnt && (int)i < cap; ++i) {
+        idx[i] = rs.items[i].i;
+        d2[i] = rs.items[i].d;
+    }
+    int c = (int)rs.rcnt;
+    free(rs.items);
+    return c;
+}
+
+void orc_kdtree_nn1_batch(const orc_kdtree *t, const void *qry, size_t n,
+                          size_t qstride, int32_t *idx, float *d2) {
+    for (size_t i = 0; i < n; ++i) {
+        int32_t bi = -1;
+        float bd = INFINITY;
+        if (orc_kdtree_knn(t, pt_at(qry, qstride, i), 1, &bi, &bd) != 1) { bi = -1; bd = INFINITY; }
+        idx[i] = bi;
+        d2[i] = bd;
+    }
+}
+
+typedef struct {
+    const orc_kdtree *t; const void *q; size_t n, stride; int32_t *idx; float *d2;
+} mt_arg;
+static void *mt_run(void *p) {
+    mt_arg *a = (mt_arg *)p;
+    orc_kdtree_nn1_batch(a->t, a->q, a->n, a->stride, a->idx, a->d2);
+    return NULL;
+}
+void orc_kdtree_nn1_batch_mt(const orc_kdtree *t, const void *qry, size_t n,
+                             size_t qstride, int32_t *idx, float *d2, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    mt_arg args[256];
+    size_t per = (n + nthreads - 1) / nthreads;
+    int used = 0;
+    for (int i = 0; i < nthreads; ++i) {
+        size_t b = per * i;
+        if (b >= n) break;
+        size_t e = b + per < n ? b + per : n;
+        args[i] = (mt_arg){t, (const char *)qry + qstride * b, e - b, qstride, idx + b, d2 + b};
+        pthread_create(&th[i], NULL, mt_run, &args[i]);
+        ++used;
+    }
+    for (int i = 0; i < used; ++i) pthread_join(th[i], NULL);
+}
+
+/* ============== matchRIFTFeaturesKnn (src/comparator.cpp:560-588) ========== */
+
+int orc_match_rift_knn(const void *des1, size_t n1, const void *des2, size_t n2,
+                       size_t stride, int32_t *out) {
+    orc_kdtree *t = orc_kdtree_build(des1, n1, stride); /* :564-565 */
+    int c = 0;
+    out[c++] = 0; /* std::vector<int> correspondence(1), :568 */
+    for (size_t i = 0; i < n2; ++i) {
+        int32_t nb;
+        float sd;
+        int found = orc_kdtree_knn(t, pt_at(des2, stride, i), 1, &nb, &sd); /* :576 */
+        if (found == 1 && sd < 0.05f) out[c++] = nb;                        /* :579-580 */
+    }
+    orc_kdtree_free(t);
+    return c;
+}
+
+/* ======= EuclideanClusterExtraction (src/segmentation.cpp:125-131, 9.4) ==== */
+
+typedef struct { int32_t first; int32_t size; int32_t id; } clus_t;
+static int clus_cmp(const void *a, const void *b) {
+    const clus_t *x = (const clus_t *)a, *y = (const clus_t *)b;
+    if (x->size != y->size) return y->size - x->size; /* largest first */
+    return (x->first > y->first) - (x->first < y->first); /* PCL leaves ties unspecified */
+}
+
+int orc_euclidean_clusters(const void *pts, size_t m, size_t stride, float tolerance,
+                           uint32_t min_size, uint32_t max_size, int32_t *labels,
+                           int32_t *cluster_sizes, int max_clusters) {
+    for (size_t i = 0; i < m; ++i) labels[i] = -1;
+    orc_kdtree *t = orc_kdtree_build(pts, m, stride);
+    if (!t) return 0;
+    /* radiusSearch(pt, double(tol)): r2 = float(double(tol)*double(tol)) (9.3) */
+    float r2 = (float)((double)tolerance * (double)tolerance);
+    uint8_t *processed = (uint8_t *)calloc(m, 1);
+    int32_t *queue = (int32_t *)malloc(sizeof(int32_t) * m);
+    int32_t *tmp_label = (int32_t *)malloc(sizeof(int32_t) * m);
+    int ncap = 1024, nn;
+    int32_t *nidx = (int32_t *)malloc(sizeof(int32_t) * ncap);
+    float *nd2 = (float *)malloc(sizeof(float) * ncap);
+    clus_t *cl = NULL;
+    size_t ncl = 0, capcl = 0;
+    for (size_t i = 0; i < m; ++i) tmp_label[i] = -1;
+    for (size_t i = 0; i < m; ++i) {
+        if (processed[i]) continue;
+        if (!finite3(pt_at(pts, stride, i))) continue; /* PCL asserts; callers strip NaNs first */
+        size_t qn = 0, sq = 0;
+        queue[qn++] = (int32_t)i;
+        processed[i] = 1;
+        while (sq < qn) {
+            const float *p = pt_at(pts, stride, (size_t)queue[sq]);
+            nn = orc_kdtree_radius(t, p, r2, 1, nidx, nd2, ncap);
+            if (nn > ncap) {
+                ncap = nn * 2;
+                nidx = (int32_t *)realloc(nidx, sizeof(int32_t) * ncap);
+                nd2 = (float *)realloc(nd2, sizeof(float) * ncap);
+                nn = orc_kdtree_radius(t, p, r2, 1, nidx, nd2, ncap);
+            }
+            /* nn_start_idx = 1: the first sorted result is assumed to be the point itself */
+            for (int j = 1; j < nn; ++j) {
+                if (nidx[j] < 0 || processed[nidx[j]]) continue;
+                queue[qn++] = nidx[j];
+                processed[nidx[j]] = 1;
+            }
+            ++sq;
+        }
+        if (qn >= min_size && qn <= max_size) {
+            if (ncl == capcl) {
+                capcl = capcl ? capcl * 2 : 256;
+                cl = (clus_t *)realloc(cl, capcl * sizeof(clus_t));
+            }
+            cl[ncl].first = (int32_t)i; /* lowest member index: i is the seed */
+            cl[ncl].size = (int32_t)qn;
+            cl[ncl].id = (int32_t)ncl;
+            for (size_t k = 0; k < qn; ++k) tmp_label[queue[k]] = (int32_t)ncl;
+            ++ncl;
+        }
+    }
+    /* std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters) */
+    qsort(cl, ncl, sizeof(clus_t), clus_cmp);
+    int32_t *remap = (int32_t *)malloc(sizeof(int32_t) * (ncl ? ncl : 1));
+    for (size_t r = 0; r < ncl; ++r) {
+        remap[cl[r].id] = (int32_t)r;
+        if ((int)r < max_clusters && cluster_sizes) cluster_sizes[r] = cl[r].size;
+    }
+    for (size_t i = 0; i < m; ++i) labels[i] = tmp_label[i] >= 0 ? remap[tmp_label[i]] : -1;
+    free(remap); free(cl); free(nidx); free(nd2); free(tmp_label); free(queue); free(processed);
+    orc_kdtree_free(t);
+    return (int)ncl;
+}
+
+/* ======== StatisticalOutlierRemoval (src/comparator.cpp:1523-1541, 9.6) ==== */
+
+size_t orc_sor(const void *pts, size_t n, size_t stride, int mean_k, double stddev_mult,
+               float *mean_dist, uint8_t *inlier, double *thresh) {
+    orc_kdtree *t = orc_kdtree_build(pts, n, stride);
+    int k = mean_k + 1;
+    int32_t *ni = (int32_t *)malloc(sizeof(int32_t) * k);
+    float *nd = (float *)malloc(sizeof(float) * k);
+    size_t valid = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = pt_at(pts, stride, i);
+        mean_dist[i] = 0.0f;
+        if (!t || !finite3(p)) continue;
+        int found = orc_kdtree_knn(t, p, k, ni, nd);
+        if (found != k) continue; /* "no neighbours found": distance stays 0 */
+        double s = 0.0;
+        for (int j = 1; j < k; ++j) s += sqrt((double)nd[j]); /* k = 0 is the point itself */
+        mean_dist[i] = (float)(s / mean_k);
+        ++valid;
+    }
+    double sum = 0, sq = 0;
+    for (size_t i = 0; i < n; ++i) { sum += mean_dist[i]; sq += (double)mean_dist[i] * mean_dist[i]; }
+    double mean = sum / (double)valid;
+    double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
+    double thr = mean + stddev_mult * sqrt(var);
+    if (thresh) *thresh = thr;
+    size_t kept = 0;
+    for (size_t i = 0; i < n; ++i) {
+        inlier[i] = !(mean_dist[i] > thr);
+        kept += inlier[i];
+    }
+    free(ni); free(nd);
+    orc_kdtree_free(t);
+    return kept;
+}
+
+/* ================= ICP (src/comparator.cpp:1089-1110, 9.5) ================= */
+
+void orc_transform(const float T[16], const void *src, size_t n, size_t sstride, float *dst) {
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = pt_at(src, sstride, i);
+        float x = p[0], y = p[1], z = p[2];
+        /* pcl::transformPointCloud: ((m0*x + m1*y) + m2*z) + m3, unfused floats */
+        dst[i * 3 + 0] = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+        dst[i * 3 + 1] = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+        dst[i * 3 + 2] = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+    }
+}
+
+void orc_icp_step_sums(const orc_kdtree *tree, const void *tgt, size_t tstride,
+                       const void *src, size_t n, size_t sstride, int32_t *idx, float *d2,
+                       double sums[17]) {
+    for (int i = 0; i < 17; ++i) sums[i] = 0;
+    orc_kdtree_nn1_batch(tree, src, n, sstride, idx, d2);
+    for (size_t i = 0; i < n; ++i) {
+        if (idx[i] < 0) continue;
+        const float *p = pt_at(src, sstride, i);
+        const float *q = pt_at(tgt, tstride, (size_t)idx[i]);
+        for (int a = 0; a < 3; ++a) { sums[a] += p[a]; sums[3 + a] += q[a]; }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) sums[6 + r * 3 + c] += (double)q[r] * (double)p[c];
+        sums[15] += d2[i];
+        sums[16] += 1.0;
+    }
+}
+
+/* 3x3 one-sided Jacobi SVD in double: A = U diag(s) V^T */
+static void svd3(const double A[9], double U[9], double s[3], double V[9]) {
+    double B[9];
+    memcpy(B, A, sizeof(B));
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int r = 0; r < 3; ++r) {
+                    a += B[r * 3 + p] * B[r * 3 + p];
+                    b += B[r * 3 + q] * B[r * 3 + q];
+                    c += B[r * 3 + p] * B[r * 3 + q];
+                }
+                off += fabs(c);
+                if (fabs(c) < 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                double zeta = (b - a) / (2.0 * c);
+                double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                for (int r = 0; r < 3; ++r) {
+                    double bp = B[r * 3 + p], bq = B[r * 3 + q];
+                    B[r * 3 + p] = cs * bp - sn * bq;
+                    B[r * 3 + q] = sn * bp + cs * bq;
+                    double vp = V[r * 3 + p], vq = V[r * 3 + q];
+                    V[r * 3 + p] = cs * vp - sn * vq;
+                    V[r * 3 + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-300) break;
+    }
+    for (int c = 0; c < 3; ++c) {
+        double nrm = 0;
+        for (int r = 0; r < 3; ++r) nrm += B[r * 3 + c] * B[r * 3 + c];
+        s[c] = sqrt(nrm);
+    }
+    /* sort descending */
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (s[order[j]] > s[order[i]]) { int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
+    double Us[9], Vs[9], ss[3];
+    for (int c = 0; c < 3; ++c) {
+        int o = order[c];
+        ss[c] = s[o];
+        for (int r = 0; r < 3; ++r) {
+            Us[r * 3 + c] = s[o] > 1e-300 ? B[r * 3 + o] / s[o] : 0.0;
+            Vs[r * 3 + c] = V[r * 3 + o];
+        }
+    }
+    /* complete U for rank-deficient cases: third column = cross of first two */
+    if (ss[2] <= 1e-300 * (ss[0] > 0 ? ss[0] : 1)) {
+        Us[2] = Us[3] * Us[7] - Us[6] * Us[4];
+        Us[5] = Us[6] * Us[1] - Us[0] * Us[7];
+        Us[8] = Us[0] * Us[4] - Us[3] * Us[1];
+    }
+    memcpy(U, Us, sizeof(Us)); memcpy(V, Vs, sizeof(Vs)); memcpy(s, ss, sizeof(ss));
+}
+static double det3(const double M[9]) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+int orc_umeyama_from_sums(const double sums[17], float T[16]) {
+    double n = sums[16];
+    if (n < 3) return -1; /* min_number_correspondences_ = 3 (9.5) */
+    double pm[3], qm[3], S[9];
+    for (int a = 0; a < 3; ++a) { pm[a] = sums[a] / n; qm[a] = sums[3 + a] / n; }
+    /* sigma = (1/n) sum (q - qm)(p - pm)^T = (1/n) sum q p^T - qm pm^T */
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) S[r * 3 + c] = sums[6 + r * 3 + c] / n - qm[r] * pm[c];
+    double U[9], V[9], sv[3];
+    svd3(S, U, sv, V);
+    double d[3] = {1, 1, 1};
+    if (det3(U) * det3(V) < 0) d[2] = -1; /* reflection fix (Umeyama eq. 39-43) */
+    double R[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += U[r * 3 + k] * d[k] * V[c * 3 + k];
+            R[r * 3 + c] = acc;
+        }
+    for (int r = 0; r < 3; ++r) {
+        double tr = qm[r];
+        for (int c = 0; c < 3; ++c) {
+            T[r * 4 + c] = (float)R[r * 3 + c];
+            tr -= R[r * 3 + c] * pm[c];
+        }
+        T[r * 4 + 3] = (float)tr;
+    }
+    T[12] = T[13] = T[14] = 0.0f;
+    T[15] = 1.0f;
+    return 0;
+}
+
+static void mat4_mul(const float A[16], const float B[16], float C[16]) {
+    float R[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0;
+            for (int k = 0; k < 4; ++k) acc += A[r * 4 + k] * B[k * 4 + c];
+            R[r * 4 + c] = acc;
+        }
+    memcpy(C, R, sizeof(R));
+}
+
+int orc_icp(const void *src, size_t n, size_t sstride, const void *tgt, size_t m,
+            size_t tstride, int max_iter, int fixed, float T[16], double *fitness,
+            int32_t *corr_idx, double *iter_mse) {
+    orc_kdtree *tree = orc_kdtree_build(tgt, m, tstride);
+    float *cur = (float *)malloc(sizeof(float) * 3 * (n ? n : 1));
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    float *d2 = (float *)malloc(sizeof(float) * (n ? n : 1));
+    float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(T, I, sizeof(I));
+    orc_transform(I, src, n, sstride, cur); /* input_transformed = *input_ */
+    int it = 0;
+    double prev_mse = DBL_MAX;
+    while (tree && it < max_iter) {
+        double sums[17];
+        orc_icp_step_sums(tree, tgt, tstride, cur, n, 12, idx, d2, sums);
+        float Ti[16];
+        if (orc_umeyama_from_sums(sums, Ti) != 0) break;
+        orc_transform(Ti, cur, n, 12, cur);
+        mat4_mul(Ti, T, T); /* final = T * final */
+        double mse = sums[15] / sums[16];
+        if (iter_mse) iter_mse[it] = mse;
+        ++it;
+        if (!fixed) { /* DefaultConvergenceCriteria, absolute MSE 1e-12 */
+            if (fabs(mse - prev_mse) < 1e-12) break;
+        }
+        prev_mse = mse;
+    }
+    if (corr_idx) memcpy(corr_idx, idx, sizeof(int32_t) * n);
+    /* getFitnessScore: transform input with the final matrix, one more NN pass */
+    if (fitness) {
+        orc_transform(T, src, n, sstride, cur);
+        double score = 0;
+        size_t nr = 0;
+        if (tree) {
+            orc_kdtree_nn1_batch(tree, cur, n, 12, idx, d2);
+            for (size_t i = 0; i < n; ++i)
+                if (idx[i] >= 0) { score += d2[i]; ++nr; }
+        }
+        *fitness = nr ? score / (double)nr : DBL_MAX;
+    }
+    free(cur); free(idx); free(d2);
+    orc_kdtree_free(tree);
+    return it;
+}

@@ -1,0 +1,126 @@
+/*
+ * pcc_oracle.h -- CPU restatement of the reference's nearest-neighbour path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pointcloudcomparator_amd/ (the
+ * product) may include, link or load this.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() use it, as the checker.
+ *
+ * PARITY UNPINNED: the reference (adr-arroyo/PointCloudComparator) ships no
+ * tests, golden vectors or fixtures for this path, and the arithmetic lives in
+ * PCL 1.7 / FLANN 1.8.4, which are not vendored under /root/reference and not
+ * installed here.  This file restates FLANN's published single-kd-tree
+ * algorithm (KDTreeSingleIndex, L2_Simple<float>, KNNSimpleResultSet,
+ * RadiusResultSet) and the PCL wrappers around it as described in SURVEY.md
+ * section 9, anchored on the reference's call sites:
+ *   src/comparator.cpp:560-588   matchRIFTFeaturesKnn  (k = 1)
+ *   src/comparator.cpp:1089-1110 performICP            (k = 1, <= 20 iterations + fitness)
+ *   src/comparator.cpp:1520-1549 StatisticalOutlierRemoval (k = 51)
+ *   src/segmentation.cpp:119-131 EuclideanClusterExtraction (radius 0.05)
+ */
+#ifndef PCC_ORACLE_H
+#define PCC_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- exhaustive definitional oracle (lowest-index tie-break) ------------- */
+/* points are AoS with a byte stride; the first three floats are x,y,z.
+ * Reference points with a non-finite coordinate are skipped (PCL
+ * KdTreeFLANN::convertCloudToArray); indices are ORIGINAL indices.
+ * d2 = ((dx*dx)+dy*dy)+dz*dz, each op rounded to fp32 (FLANN L2_Simple, 9.2).
+ * A non-finite query yields idx=-1, d2=+inf. */
+void orc_nn1_exhaustive(const void *ref, size_t m, size_t rstride,
+                        const void *qry, size_t n, size_t qstride,
+                        int32_t *idx, float *d2);
+/* k nearest, ascending by (d2, idx); rows padded with idx=-1,d2=+inf when
+ * fewer than k valid references exist.  Returns min(k, valid refs). */
+int orc_knn_exhaustive(const void *ref, size_t m, size_t rstride,
+                       const void *qry, size_t n, size_t qstride, int k,
+                       int32_t *idx, float *d2);
+/* strict d2 < r2 neighbour counts per query */
+void orc_radius_count_exhaustive(const void *ref, size_t m, size_t rstride,
+                                 const void *qry, size_t n, size_t qstride,
+                                 float r2, int32_t *counts);
+
+/* ---- FLANN KDTreeSingleIndex restatement ---------------- */
+typedef struct orc_kdtree orc_kdtree;
+/* Builds on the finite points of the cloud (leaf_max_size 15, middle split,
+ * reorder).  Returns NULL when no valid point exists (PCL prints an error). */
+orc_kdtree *orc_kdtree_build(const void *pts, size_t m, size_t stride);
+void orc_kdtree_free(orc_kdtree *t);
+size_t orc_kdtree_size(const orc_kdtree *t);
+/* pcl::KdTreeFLANN::nearestKSearch for one query: returns number found
+ * (k clamped to the number of valid points), ascending distance,
+ * first-visited wins among exact ties (KNNSimpleResultSet). */
+int orc_kdtree_knn(const orc_kdtree *t, const float q[3], int k,
+                   int32_t *idx, float *d2);
+/* pcl::KdTreeFLANN::radiusSearch(point, radius, ..., max_nn = 0): r2 is
+ * float(radius*radius) evaluated in double by the caller; results sorted by
+ * (d2, idx) when sorted != 0.  Returns the neighbour count; writes at most
+ * cap entries. */
+int orc_kdtree_radius(const orc_kdtree *t, const float q[3], float r2,
+                      int sorted, int32_t *idx, float *d2, int cap);
+/* batch helpers (the reference's per-query loops, src/comparator.cpp:571-577) */
+void orc_kdtree_nn1_batch(const orc_kdtree *t, const void *qry, size_t n,
+                          size_t qstride, int32_t *idx, float *d2);
+/* same, spread over nthreads host threads (reported-only CPU baseline) */
+void orc_kdtree_nn1_batch_mt(const orc_kdtree *t, const void *qry, size_t n,
+                             size_t qstride, int32_t *idx, float *d2,
+                             int nthreads);
+
+/* ---- PCL algorithm restatements on top of the tree ----------------------- */
+/* matchRIFTFeaturesKnn (src/comparator.cpp:560-588): tree on des1, one k=1
+ * query per element of des2, keep when found==1 && d2 < 0.05f.  out[0] is the
+ * dummy 0 the reference's vector starts with (:568).  Returns size() (= 1 +
+ * matches); out needs n2+1 slots. */
+int orc_match_rift_knn(const void *des1, size_t n1, const void *des2, size_t n2,
+                       size_t stride, int32_t *out);
+
+/* pcl::extractEuclideanClusters + EuclideanClusterExtraction::extract
+ * (src/segmentation.cpp:125-131).  labels[i] = cluster id in the
+ * returned order (size-descending, ties by lowest member index; -1 = not in
+ * any kept cluster).  cluster_sizes gets up to max_clusters sizes.
+ * Returns the number of kept clusters. */
+int orc_euclidean_clusters(const void *pts, size_t m, size_t stride,
+                           float tolerance, uint32_t min_size, uint32_t max_size,
+                           int32_t *labels, int32_t *cluster_sizes,
+                           int max_clusters);
+
+/* pcl::StatisticalOutlierRemoval::applyFilterIndices (src/comparator.cpp:
+ * 1523-1541): mean_dist[i] (float), inlier[i] (0/1), *thresh.
+ * Returns the number of inliers. */
+size_t orc_sor(const void *pts, size_t n, size_t stride, int mean_k,
+               double stddev_mult, float *mean_dist, uint8_t *inlier,
+               double *thresh);
+
+/* pcl::IterativeClosestPoint (src/comparator.cpp:1089-1110) with
+ * fixed iteration count (no early exit when fixed != 0).  T is the final 4x4
+ * row-major float transform source->target.  corr_idx (optional) receives
+ * the correspondence indices of the LAST iteration.  iter_mse (optional, len
+ * max_iter) receives the per-iteration mean squared correspondence distance.
+ * Returns iterations done; *fitness = getFitnessScore(). */
+int orc_icp(const void *src, size_t n, size_t sstride,
+            const void *tgt, size_t m, size_t tstride,
+            int max_iter, int fixed, float T[16], double *fitness,
+            int32_t *corr_idx, double *iter_mse);
+
+/* one ICP building block on identical inputs: NN of every (already
+ * transformed) source point + the double-precision sums Umeyama needs.
+ * sums[0..2]=sum p, [3..5]=sum q, [6..14]=sum q p^T (row-major 3x3:
+ * q_r * p_c), [15]=sum d2, [16]=count. */
+void orc_icp_step_sums(const orc_kdtree *tgt_tree, const void *tgt, size_t tstride,
+                       const void *src, size_t n, size_t sstride,
+                       int32_t *idx, float *d2, double sums[17]);
+/* rigid transform (no scaling) from the sums above, Umeyama/Kabsch in double,
+ * cast to float 4x4 row-major.  Returns 0 on success. */
+int orc_umeyama_from_sums(const double sums[17], float T[16]);
+/* pcl::transformPointCloud arithmetic: ((m0*x + m1*y) + m2*z) + m3, unfused */
+void orc_transform(const float T[16], const void *src, size_t n, size_t sstride,
+                   float *dst_xyz /* n*3 packed */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,232 @@
+"""ctypes loader of oracle/pcc_oracle.c plus a numpy definitional oracle.
+
+TEST INFRASTRUCTURE ONLY / PARITY UNPINNED (see oracle/pcc_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libpcc_oracle.so"
+
+
+def build(force: bool = False) -> Path:
+    src = _HERE / "pcc_oracle.c"
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        _SO.parent.mkdir(exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                               "-pthread", "-o", str(_SO), str(src), "-lm"])
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        L = C.CDLL(str(build()))
+        vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+        L.orc_nn1_exhaustive.argtypes = [vp, sz, sz, vp, sz, sz, vp, vp]
+        L.orc_nn1_exhaustive.restype = None
+        L.orc_knn_exhaustive.argtypes = [vp, sz, sz, vp, sz, sz, i32, vp, vp]
+        L.orc_radius_count_exhaustive.argtypes = [vp, sz, sz, vp, sz, sz, C.c_float, vp]
+        L.orc_radius_count_exhaustive.restype = None
+        L.orc_kdtree_build.argtypes = [vp, sz, sz]
+        L.orc_kdtree_build.restype = vp
+        L.orc_kdtree_free.argtypes = [vp]
+        L.orc_kdtree_free.restype = None
+        L.orc_kdtree_size.argtypes = [vp]
+        L.orc_kdtree_size.restype = sz
+        L.orc_kdtree_knn.argtypes = [vp, vp, i32, vp, vp]
+        L.orc_kdtree_radius.argtypes = [vp, vp, C.c_float, i32, vp, vp, i32]
+        L.orc_kdtree_nn1_batch.argtypes = [vp, vp, sz, sz, vp, vp]
+        L.orc_kdtree_nn1_batch.restype = None
+        L.orc_kdtree_nn1_batch_mt.argtypes = [vp, vp, sz, sz, vp, vp, i32]
+        L.orc_kdtree_nn1_batch_mt.restype = None
+        L.orc_match_rift_knn.argtypes = [vp, sz, vp, sz, sz, vp]
+        L.orc_euclidean_clusters.argtypes = [vp, sz, sz, C.c_float, C.c_uint32, C.c_uint32, vp, vp, i32]
+        L.orc_sor.argtypes = [vp, sz, sz, i32, C.c_double, vp, vp, C.POINTER(C.c_double)]
+        L.orc_sor.restype = sz
+        L.orc_icp.argtypes = [vp, sz, sz, vp, sz, sz, i32, i32, vp, C.POINTER(C.c_double), vp, vp]
+        L.orc_icp_step_sums.argtypes = [vp, vp, sz, vp, sz, sz, vp, vp, vp]
+        L.orc_icp_step_sums.restype = None
+        L.orc_umeyama_from_sums.argtypes = [vp, vp]
+        L.orc_transform.argtypes = [vp, vp, sz, sz, vp]
+        L.orc_transform.restype = None
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    a = np.asarray(a)
+    assert a.dtype == np.float32 and a.ndim == 2 and a.shape[1] >= 3 and a.strides[1] == 4
+    return a, a.ctypes.data, a.shape[0], (a.strides[0] if a.shape[0] > 1 else a.shape[1] * 4)
+
+
+# ---- numpy definitional oracle (SURVEY 8c golden vectors (1)) ---------------------
+def nn1_numpy(ref: np.ndarray, qry: np.ndarray, chunk: int = 256):
+    """float32 exhaustive: d=((dx*dx)+dy*dy)+dz*dz with each ufunc rounding separately
+    (same bits as unfused C); argmin = lowest index; non-finite refs skipped."""
+    ref = np.asarray(ref, dtype=np.float32)[:, :3]
+    qry = np.asarray(qry, dtype=np.float32)[:, :3]
+    valid = np.isfinite(ref).all(1)
+    vidx = np.nonzero(valid)[0].astype(np.int32)
+    r = ref[valid]
+    n = len(qry)
+    idx = np.full(n, -1, dtype=np.int32)
+    d2 = np.full(n, np.inf, dtype=np.float32)
+    if len(r) == 0:
+        return idx, d2
+    for s in range(0, n, chunk):
+        q = qry[s:s + chunk]
+        dx = q[:, None, 0] - r[None, :, 0]
+        d = dx * dx
+        dy = q[:, None, 1] - r[None, :, 1]
+        d = d + dy * dy
+        dz = q[:, None, 2] - r[None, :, 2]
+        d = d + dz * dz
+        a = np.argmin(d, axis=1)  # first occurrence = lowest index
+        ok = np.isfinite(q).all(1)
+        idx[s:s + chunk] = np.where(ok, vidx[a], -1)
+        d2[s:s + chunk] = np.where(ok, d[np.arange(len(q)), a], np.inf)
+    return idx, d2
+
+
+# ---- C restatement wrappers ---------------------------------------------------------
+def nn1_exhaustive(ref, qry):
+    r, rp, m, rs = _f32(ref)
+    q, qp, n, qs = _f32(qry)
+    idx = np.empty(n, np.int32)
+    d2 = np.empty(n, np.float32)
+    lib().orc_nn1_exhaustive(rp, m, rs, qp, n, qs, idx.ctypes.data, d2.ctypes.data)
+    return idx, d2
+
+
+def knn_exhaustive(ref, qry, k):
+    r, rp, m, rs = _f32(ref)
+    q, qp, n, qs = _f32(qry)
+    idx = np.empty((n, k), np.int32)
+    d2 = np.empty((n, k), np.float32)
+    lib().orc_knn_exhaustive(rp, m, rs, qp, n, qs, k, idx.ctypes.data, d2.ctypes.data)
+    return idx, d2
+
+
+def radius_count_exhaustive(ref, qry, radius):
+    r, rp, m, rs = _f32(ref)
+    q, qp, n, qs = _f32(qry)
+    r2 = np.float32(np.float64(radius) * np.float64(radius))
+    cnt = np.empty(n, np.int32)
+    lib().orc_radius_count_exhaustive(rp, m, rs, qp, n, qs, r2, cnt.ctypes.data)
+    return cnt
+
+
+class KdTree:
+    """FLANN KDTreeSingleIndex restatement behind pcl::KdTreeFLANN semantics."""
+
+    def __init__(self, pts):
+        self._pts, p, m, s = _f32(pts)
+        self._h = lib().orc_kdtree_build(p, m, s)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_kdtree_free(self._h)
+            self._h = None
+
+    @property
+    def size(self):
+        return lib().orc_kdtree_size(self._h) if self._h else 0
+
+    def knn(self, q, k):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        idx = np.empty(k, np.int32)
+        d2 = np.empty(k, np.float32)
+        c = lib().orc_kdtree_knn(self._h, q.ctypes.data, k, idx.ctypes.data, d2.ctypes.data)
+        return idx[:c], d2[:c]
+
+    def radius(self, q, radius, sorted=True, cap=4096):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        r2 = np.float32(np.float64(radius) * np.float64(radius))
+        idx = np.empty(cap, np.int32)
+        d2 = np.empty(cap, np.float32)
+        c = lib().orc_kdtree_radius(self._h, q.ctypes.data, r2, int(sorted), idx.ctypes.data, d2.ctypes.data, cap)
+        if c > cap:
+            return self.radius(q, radius, sorted, cap=c)
+        return idx[:c], d2[:c]
+
+    def nn1_batch(self, qry, nthreads=1):
+        q, qp, n, qs = _f32(qry)
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        if nthreads > 1:
+            lib().orc_kdtree_nn1_batch_mt(self._h, qp, n, qs, idx.ctypes.data, d2.ctypes.data, nthreads)
+        else:
+            lib().orc_kdtree_nn1_batch(self._h, qp, n, qs, idx.ctypes.data, d2.ctypes.data)
+        return idx, d2
+
+    def icp_step_sums(self, tgt, src):
+        t, tp, m, ts = _f32(tgt)
+        s, sp, n, ss = _f32(src)
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        sums = np.zeros(17, np.float64)
+        lib().orc_icp_step_sums(self._h, tp, ts, sp, n, ss, idx.ctypes.data, d2.ctypes.data, sums.ctypes.data)
+        return idx, d2, sums
+
+
+def match_rift_knn(des1, des2):
+    a, ap, n1, s1 = _f32(des1)
+    b, bp, n2, s2 = _f32(des2)
+    assert s1 == s2
+    out = np.empty(n2 + 1, np.int32)
+    c = lib().orc_match_rift_knn(ap, n1, bp, n2, s1, out.ctypes.data)
+    return out[:c]
+
+
+def euclidean_clusters(pts, tolerance, min_size, max_size, max_clusters=65536):
+    a, p, m, s = _f32(pts)
+    labels = np.empty(m, np.int32)
+    sizes = np.zeros(max_clusters, np.int32)
+    n = lib().orc_euclidean_clusters(p, m, s, np.float32(tolerance), min_size, max_size, labels.ctypes.data,
+                                     sizes.ctypes.data, max_clusters)
+    return labels, n, sizes[:min(n, max_clusters)]
+
+
+def sor(pts, mean_k=50, stddev_mult=1.5):
+    a, p, n, s = _f32(pts)
+    md = np.empty(n, np.float32)
+    inl = np.empty(n, np.uint8)
+    thr = C.c_double(0)
+    kept = lib().orc_sor(p, n, s, mean_k, stddev_mult, md.ctypes.data, inl.ctypes.data, C.byref(thr))
+    return md, inl, thr.value, kept
+
+
+def umeyama_from_sums(sums):
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    T = np.zeros(16, np.float32)
+    rc = lib().orc_umeyama_from_sums(sums.ctypes.data, T.ctypes.data)
+    return rc, T.reshape(4, 4)
+
+
+def transform(T, src):
+    s, sp, n, ss = _f32(src)
+    Tm = np.ascontiguousarray(np.asarray(T, np.float32).reshape(16))
+    out = np.empty((n, 3), np.float32)
+    lib().orc_transform(Tm.ctypes.data, sp, n, ss, out.ctypes.data)
+    return out
+
+
+def icp(src, tgt, max_iter=20, fixed=False):
+    s, sp, n, ss = _f32(src)
+    t, tp, m, ts = _f32(tgt)
+    T = np.zeros(16, np.float32)
+    fit = C.c_double(0)
+    corr = np.empty(n, np.int32)
+    mse = np.zeros(max_iter, np.float64)
+    it = lib().orc_icp(sp, n, ss, tp, m, ts, max_iter, int(fixed), T.ctypes.data, C.byref(fit), corr.ctypes.data,
+                       mse.ctypes.data)
+    return T.reshape(4, 4), fit.value, it, corr, mse[:it]

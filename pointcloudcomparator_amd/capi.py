@@ -1,0 +1,283 @@
+"""ctypes binding of the libpcc_nn C-ABI (include/pcc_nn.h).
+
+Thin by design: every method maps 1:1 onto one exported function; numpy arrays
+are passed as host pointers, torch CUDA tensors as device pointers.  No search
+is ever computed in Python -- a missing library is a hard error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+MEM_HOST, MEM_DEVICE = 0, 1
+ENGINE_AUTO, ENGINE_BRUTE, ENGINE_GRID = 0, 1, 2
+KNN_MAX_K = 128
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("PCC_LIB", _HERE / "lib" / "libpcc_nn.so"))
+
+# every symbol include/pcc_nn.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "pcc_version", "pcc_last_error", "pcc_device_count",
+    "pcc_index_create", "pcc_index_destroy", "pcc_index_size", "pcc_index_set_stream",
+    "pcc_index_sync", "pcc_index_engine", "pcc_index_set_engine",
+    "pcc_nn1", "pcc_knn", "pcc_radius_count", "pcc_radius_fill",
+    "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
+    "pcc_match_knn", "pcc_index_stats",
+]
+
+
+class PccError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libpcc_nn status {status}: {msg}")
+        self.status = status
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make lib` (or __graft_entry__.build()). "
+            "pointcloudcomparator_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    lib.pcc_last_error.restype = C.c_char_p
+    lib.pcc_index_create.argtypes = [vp, sz, sz, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.pcc_index_destroy.argtypes = [vp]
+    lib.pcc_index_size.argtypes = [vp, C.POINTER(sz)]
+    lib.pcc_index_set_stream.argtypes = [vp, vp]
+    lib.pcc_index_sync.argtypes = [vp]
+    lib.pcc_index_engine.argtypes = [vp, C.POINTER(i32)]
+    lib.pcc_index_set_engine.argtypes = [vp, i32]
+    lib.pcc_index_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.pcc_device_count.argtypes = [C.POINTER(i32)]
+    lib.pcc_nn1.argtypes = [vp, vp, sz, sz, i32, vp, vp]
+    lib.pcc_knn.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp]
+    lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
+    lib.pcc_radius_fill.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, vp]
+    lib.pcc_euclidean_clusters.argtypes = [vp, C.c_double, C.c_uint32, C.c_uint32, i32, vp,
+                                           C.POINTER(C.c_int32), vp, i32]
+    lib.pcc_sor.argtypes = [vp, i32, C.c_double, i32, vp, vp, C.POINTER(C.c_double), C.POINTER(sz)]
+    lib.pcc_icp_step.argtypes = [vp, vp, sz, sz, i32, vp, vp, C.POINTER(C.c_double)]
+    lib.pcc_transform.argtypes = [vp, C.POINTER(C.c_float), vp, sz, sz, vp, sz, i32]
+    lib.pcc_icp_align.argtypes = [vp, vp, sz, sz, i32, i32, i32, C.POINTER(C.c_float),
+                                  C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]
+    lib.pcc_match_knn.argtypes = [vp, vp, sz, sz, i32, C.c_float, vp, C.POINTER(C.c_int32)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
+        if name != "pcc_last_error":
+            fn.restype = C.c_int
+    return lib
+
+
+LIB = _load()
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        raise PccError(status, (LIB.pcc_last_error() or b"").decode())
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(LIB.pcc_device_count(C.byref(n)))
+    return n.value
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _points(x):
+    """(pointer, n, stride_bytes, mem) of an (n, >=3) float32 numpy array or torch tensor."""
+    if _is_torch(x):
+        assert x.dtype.is_floating_point and x.element_size() == 4 and x.dim() == 2 and x.shape[1] >= 3
+        assert x.stride(1) == 1
+        mem = MEM_DEVICE if x.is_cuda else MEM_HOST
+        return x.data_ptr(), x.shape[0], x.stride(0) * 4 if x.shape[0] > 1 else x.shape[1] * 4, mem
+    a = x
+    assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] >= 3
+    assert a.strides[1] == 4
+    stride = a.strides[0] if a.shape[0] > 1 else a.shape[1] * 4
+    return a.ctypes.data, a.shape[0], stride, MEM_HOST
+
+
+def _out(like, shape, dtype):
+    """allocate an output in the memory space of `like`."""
+    if _is_torch(like) and like.is_cuda:
+        import torch
+        tdt = {np.int32: torch.int32, np.float32: torch.float32, np.uint8: torch.uint8,
+               np.int64: torch.int64}[dtype]
+        t = torch.empty(shape, dtype=tdt, device=like.device)
+        return t, t.data_ptr()
+    a = np.empty(shape, dtype=dtype)
+    return a, a.ctypes.data
+
+
+class Index:
+    """Owner of one pcc_index handle (the role pcl::KdTreeFLANN plays in the reference)."""
+
+    def __init__(self, points, engine: int = ENGINE_AUTO, device: int = 0):
+        ptr, n, stride, mem = _points(points)
+        if _is_torch(points) and points.is_cuda:
+            device = points.device.index or 0
+        h = C.c_void_p()
+        _check(LIB.pcc_index_create(ptr, n, stride, 3, mem, device, engine, C.byref(h)))
+        self._h = h
+        self.n_original = n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            LIB.pcc_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def size(self) -> int:
+        n = C.c_size_t(0)
+        _check(LIB.pcc_index_size(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def engine(self) -> int:
+        e = C.c_int(0)
+        _check(LIB.pcc_index_engine(self._h, C.byref(e)))
+        return e.value
+
+    def set_engine(self, engine: int):
+        _check(LIB.pcc_index_set_engine(self._h, engine))
+
+    def set_stream(self, stream_ptr: int):
+        _check(LIB.pcc_index_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        _check(LIB.pcc_index_sync(self._h))
+
+    def stats(self):
+        s = (C.c_uint64 * 8)()
+        _check(LIB.pcc_index_stats(self._h, s))
+        return list(s)
+
+    # -- searches ------------------------------------------------------------
+    def nn1(self, queries, out_idx=None, out_d2=None):
+        ptr, n, stride, mem = _points(queries)
+        if out_idx is None:
+            out_idx, pi = _out(queries, (n,), np.int32)
+        else:
+            pi = out_idx.data_ptr() if _is_torch(out_idx) else out_idx.ctypes.data
+        if out_d2 is None:
+            out_d2, pd = _out(queries, (n,), np.float32)
+        else:
+            pd = out_d2.data_ptr() if _is_torch(out_d2) else out_d2.ctypes.data
+        _check(LIB.pcc_nn1(self._h, ptr, n, stride, mem, pi, pd))
+        return out_idx, out_d2
+
+    def knn(self, queries, k: int):
+        ptr, n, stride, mem = _points(queries)
+        idx, pi = _out(queries, (n, k), np.int32)
+        d2, pd = _out(queries, (n, k), np.float32)
+        _check(LIB.pcc_knn(self._h, ptr, n, stride, mem, k, pi, pd))
+        return idx, d2
+
+    def radius_count(self, queries, radius: float):
+        ptr, n, stride, mem = _points(queries)
+        cnt, pc = _out(queries, (n,), np.int32)
+        _check(LIB.pcc_radius_count(self._h, ptr, n, stride, mem, float(radius), pc))
+        return cnt
+
+    def radius_search(self, queries, radius: float, sorted: bool = True):
+        """CSR (offsets, idx, d2) of all neighbours with d2 < float(radius^2)."""
+        ptr, n, stride, mem = _points(queries)
+        cnt = self.radius_count(queries, radius)
+        if _is_torch(cnt):
+            import torch
+            offs = torch.zeros(n + 1, dtype=torch.int64, device=cnt.device)
+            offs[1:] = torch.cumsum(cnt.to(torch.int64), 0)
+            total = int(offs[-1].item())
+            po = offs.data_ptr()
+        else:
+            offs = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(cnt, out=offs[1:])
+            total = int(offs[-1])
+            po = offs.ctypes.data
+        idx, pi = _out(queries, (max(total, 1),), np.int32)
+        d2, pd = _out(queries, (max(total, 1),), np.float32)
+        _check(LIB.pcc_radius_fill(self._h, ptr, n, stride, mem, float(radius), int(sorted), po, pi, pd))
+        return offs, idx[:total], d2[:total]
+
+    def euclidean_clusters(self, tolerance: float, min_size: int, max_size: int, device_out=None,
+                           max_sizes: int = 65536):
+        if device_out is not None:
+            labels, pl = _out(device_out, (self.n_original,), np.int32)
+            mem = MEM_DEVICE
+        else:
+            labels = np.empty(self.n_original, dtype=np.int32)
+            pl, mem = labels.ctypes.data, MEM_HOST
+        ncl = C.c_int32(0)
+        sizes = np.zeros(max_sizes, dtype=np.int32)
+        _check(LIB.pcc_euclidean_clusters(self._h, float(tolerance), min_size, max_size, mem, pl,
+                                          C.byref(ncl), sizes.ctypes.data, max_sizes))
+        return labels, ncl.value, sizes[:min(ncl.value, max_sizes)]
+
+    def sor(self, mean_k: int = 50, stddev_mult: float = 1.5):
+        md = np.empty(self.n_original, dtype=np.float32)
+        inl = np.empty(self.n_original, dtype=np.uint8)
+        thr = C.c_double(0)
+        kept = C.c_size_t(0)
+        _check(LIB.pcc_sor(self._h, mean_k, float(stddev_mult), MEM_HOST, md.ctypes.data, inl.ctypes.data,
+                           C.byref(thr), C.byref(kept)))
+        return md, inl, thr.value, kept.value
+
+    def icp_step(self, src, want_corr: bool = True):
+        ptr, n, stride, mem = _points(src)
+        sums = (C.c_double * 17)()
+        if want_corr:
+            idx, pi = _out(src, (n,), np.int32)
+            d2, pd = _out(src, (n,), np.float32)
+        else:
+            idx = d2 = None
+            pi = pd = None
+        _check(LIB.pcc_icp_step(self._h, ptr, n, stride, mem, pi, pd, sums))
+        return idx, d2, np.array(list(sums), dtype=np.float64)
+
+    def transform(self, T, src, dst=None):
+        ptr, n, stride, mem = _points(src)
+        Tm = np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(16))
+        if dst is None:
+            if _is_torch(src):
+                import torch
+                dst = torch.empty((n, 3), dtype=torch.float32, device=src.device)
+            else:
+                dst = np.empty((n, 3), dtype=np.float32)
+        dptr, dn, dstride, dmem = _points(dst)
+        assert dn == n and dmem == mem
+        _check(LIB.pcc_transform(self._h, Tm.ctypes.data_as(C.POINTER(C.c_float)), ptr, n, stride, dptr,
+                                 dstride, mem))
+        return dst
+
+    def icp_align(self, src, max_iter: int = 20, fixed: bool = False):
+        ptr, n, stride, mem = _points(src)
+        T = (C.c_float * 16)()
+        fit = C.c_double(0)
+        it = C.c_int(0)
+        conv = C.c_int(0)
+        _check(LIB.pcc_icp_align(self._h, ptr, n, stride, mem, max_iter, int(fixed), T, C.byref(fit),
+                                 C.byref(it), C.byref(conv)))
+        return np.array(list(T), dtype=np.float32).reshape(4, 4), fit.value, it.value, bool(conv.value)
+
+    def match_knn(self, des2, threshold: float = 0.05):
+        ptr, n, stride, mem = _points(des2)
+        out = np.empty(n + 1, dtype=np.int32)
+        sz = C.c_int32(0)
+        _check(LIB.pcc_match_knn(self._h, ptr, n, stride, mem, np.float32(threshold), out.ctypes.data,
+                                 C.byref(sz)))
+        return out[:sz.value]

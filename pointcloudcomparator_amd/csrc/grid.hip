@@ -1,0 +1,314 @@
+// grid.hip -- GRID engine of libpcc_nn (gfx950): cell-sorted references and exact,
+// conservatively bounded ring search.  Plays the role the kd-tree plays inside
+// pcl::KdTreeFLANN (reference src/comparator.cpp:564-577, src/segmentation.cpp:120-131):
+// prune the exhaustive scan without changing a single result bit.
+//
+// Index layout in HBM:
+//   cell_refs  float4[n_valid]   (x, y, z, bits(original index)), sorted by linear
+//                                cell id with x fastest, so one row of cells along x
+//                                is ONE contiguous span of points
+//   cell_start uint32[ncells+1]  CSR starts
+// Search of one query: scan the cube of cells [c-k, c+k]^3 row by row, keep
+// min (d2, index) as one 64-bit key, then bound everything outside the cube from
+// below by the distance to the cube's open faces; if the bound cannot exclude a
+// closer (or equal, lower-index) point the cube grows, and past KMAX the query is
+// handed to the exhaustive kernel.  Distances use the same unfused fp32 arithmetic
+// as nn1_brute.hip (-ffp-contract=off), so both engines return identical bits.
+#include "pcc_internal.hpp"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+namespace pcc {
+
+constexpr int GRID_KMAX = 8;           // largest cube half-width before the exhaustive fallback
+constexpr float GRID_TARGET_PPC = 4.f; // mean points per cell the cell size aims for
+constexpr unsigned int GRID_MAX_CELLS = 1u << 25;
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+    unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+static inline float ord2f(unsigned int u) {
+    unsigned int b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+// ---- bounding box ---------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_bbox(const float4* __restrict__ p, unsigned int n, unsigned int* __restrict__ mm /* min[3], max[3] (ordered uints) */) {
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = p[i];
+        lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+        lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+        lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&mm[a], f2ord(lo[a]));
+            atomicMax(&mm[3 + a], f2ord(hi[a]));
+        }
+    }
+}
+
+__device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int dim) {
+    // clamp in float first (no int overflow); the SAME expression runs at build and query time
+    float t = fminf(fmaxf((v - org) * inv_h, 0.f), (float)(dim - 1));
+    return (int)t;
+}
+__device__ __forceinline__ unsigned int cell_id(const float4& v, const GridParams& g) {
+    int cx = cell_coord(v.x, g.org[0], g.inv_h, g.dim[0]);
+    int cy = cell_coord(v.y, g.org[1], g.inv_h, g.dim[1]);
+    int cz = cell_coord(v.z, g.org[2], g.inv_h, g.dim[2]);
+    return ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+}
+
+// ---- counting sort by cell ----------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_cell_count(const float4* __restrict__ p, unsigned int n, GridParams g, unsigned int* __restrict__ count) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = p[i];
+        if (__float_as_int(v.w) < 0) continue;  // invalid query (references are always valid)
+        atomicAdd(&count[cell_id(v, g)], 1u);
+    }
+}
+// cursor[] starts as a copy of the CSR starts and is bumped per point
+__global__ void __launch_bounds__(256)
+k_cell_scatter_refs(const float4* __restrict__ p, unsigned int n, GridParams g,
+                    unsigned int* __restrict__ cursor, float4* __restrict__ out) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = p[i];
+        unsigned int pos = atomicAdd(&cursor[cell_id(v, g)], 1u);
+        out[pos] = v;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_cell_scatter_ids(const float4* __restrict__ p, unsigned int n, GridParams g,
+                   unsigned int* __restrict__ cursor, unsigned int* __restrict__ order,
+                   unsigned int* __restrict__ n_sorted) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = p[i];
+        if (__float_as_int(v.w) < 0) continue;
+        unsigned int pos = atomicAdd(&cursor[cell_id(v, g)], 1u);
+        order[pos] = i;
+    }
+    (void)n_sorted;
+}
+
+static inline int grid1d(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+int grid_build(pcc_index* ix) {
+    hipStream_t s = ix->stream;
+    const unsigned int n = (unsigned int)ix->n_valid;
+    const float4* refs = ix->refs.as<float4>();
+    // 1. bounding box
+    unsigned int* d_mm = ix->small.as<unsigned int>() + 16;
+    unsigned int init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    PCC_HIP(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bbox, dim3(grid1d(n)), dim3(256), 0, s, refs, n, d_mm);
+    PCC_HIP(hipGetLastError());
+    unsigned int* h = static_cast<unsigned int*>(ix->pinned) + 16;
+    PCC_HIP(hipMemcpyAsync(h, d_mm, 24, hipMemcpyDeviceToHost, s));
+    PCC_HIP(hipStreamSynchronize(s));
+    float lo[3], hi[3], ext[3];
+    float maxext = 0.f, maxabs = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = ord2f(h[a]);
+        hi[a] = ord2f(h[3 + a]);
+        ext[a] = hi[a] - lo[a];
+        if (!(ext[a] >= 0.f) || !std::isfinite(ext[a])) ext[a] = 0.f;  // overflowed extents fall back to one cell
+        maxext = std::max(maxext, ext[a]);
+        maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    // 2. cell size: GRID_TARGET_PPC points per cell on average over the non-flat dimensions
+    GridParams g;
+    int nd = 0;
+    double vol = 1.0;
+    for (int a = 0; a < 3; ++a)
+        if (ext[a] > 1e-6f * maxext && ext[a] > 0.f) { vol *= ext[a]; ++nd; }
+    double cells_wanted = std::max(1.0, (double)n / GRID_TARGET_PPC);
+    const char* env = getenv("PCC_GRID_PPC");
+    if (env && atof(env) > 0) cells_wanted = std::max(1.0, (double)n / atof(env));
+    if (cells_wanted > GRID_MAX_CELLS) cells_wanted = GRID_MAX_CELLS;
+    double hcell = nd ? std::pow(vol / cells_wanted, 1.0 / nd) : 1.0;
+    if (!(hcell > 0) || !std::isfinite(hcell)) hcell = 1.0;
+    for (int iter = 0; iter < 64; ++iter) {  // grow h until the cell count fits
+        double tot = 1;
+        for (int a = 0; a < 3; ++a) tot *= std::floor(ext[a] / hcell) + 1;
+        if (tot <= (double)GRID_MAX_CELLS) break;
+        hcell *= 1.26;
+    }
+    g.h = (float)hcell;
+    g.inv_h = 1.0f / g.h;
+    if (!std::isfinite(g.inv_h) || g.inv_h <= 0) { g.h = 1.f; g.inv_h = 1.f; }
+    double tot = 1;
+    for (int a = 0; a < 3; ++a) {
+        g.org[a] = lo[a];
+        double d = std::floor((double)ext[a] * g.inv_h) + 1;
+        if (d > 1 << 20) d = 1 << 20;
+        g.dim[a] = (int)d;
+        tot *= d;
+    }
+    if (tot > (double)GRID_MAX_CELLS * 2) { set_error("grid sizing failed"); return PCC_ERR_INVALID; }
+    g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
+    ix->grid = g;
+    ix->stats[3] = (uint64_t)g.ncells;
+    // 3. counting sort
+    size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
+    PCC_TRY(ix->cell_start.reserve(cs_bytes));
+    PCC_TRY(ix->cell_refs.reserve((size_t)n * sizeof(float4)));
+    PCC_TRY(ix->scratch_b.reserve(cs_bytes));
+    unsigned int* cstart = ix->cell_start.as<unsigned int>();
+    unsigned int* cursor = ix->scratch_b.as<unsigned int>();
+    PCC_HIP(hipMemsetAsync(cstart, 0, cs_bytes, s));
+    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, refs, n, g, cstart);
+    PCC_HIP(hipGetLastError());
+    PCC_TRY(launch_exclusive_scan(s, cstart, (size_t)g.ncells + 1, ix->scratch_a));
+    PCC_HIP(hipMemcpyAsync(cursor, cstart, cs_bytes, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_cell_scatter_refs, dim3(grid1d(n)), dim3(256), 0, s, refs, n, g, cursor,
+                       ix->cell_refs.as<float4>());
+    PCC_HIP(hipGetLastError());
+    ix->has_grid = true;
+    return PCC_OK;
+}
+
+// ---- k = 1 search ------------------------------------------------------------------------
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& r) {
+    float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
+    float d = dx * dx;
+    d = d + dy * dy;
+    d = d + dz * dz;
+    return d;
+}
+
+// lower bound (squared, shrunk) of the distance from q to any point outside the cell cube
+// [x0..x1] x [y0..y1] x [z0..z1]; +inf when the cube covers the whole grid
+__device__ __forceinline__ float outside_bound2(float qx, float qy, float qz, int x0, int x1, int y0,
+                                                int y1, int z0, int z1, const GridParams& g, float slack) {
+    float lb = __builtin_inff();
+    if (x0 > 0) lb = fminf(lb, qx - (g.org[0] + x0 * g.h));
+    if (x1 < g.dim[0] - 1) lb = fminf(lb, (g.org[0] + (x1 + 1) * g.h) - qx);
+    if (y0 > 0) lb = fminf(lb, qy - (g.org[1] + y0 * g.h));
+    if (y1 < g.dim[1] - 1) lb = fminf(lb, (g.org[1] + (y1 + 1) * g.h) - qy);
+    if (z0 > 0) lb = fminf(lb, qz - (g.org[2] + z0 * g.h));
+    if (z1 < g.dim[2] - 1) lb = fminf(lb, (g.org[2] + (z1 + 1) * g.h) - qz);
+    lb = fmaxf(lb - slack, 0.f);      // absolute slack: cell-boundary rounding
+    return lb * lb * 0.9999f;         // relative slack: rounding of the fp32 distances
+}
+
+__global__ void __launch_bounds__(256)
+k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
+           float slack, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+           const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
+           unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
+           unsigned int* __restrict__ fb_count) {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int ns = n_sorted_ptr ? *n_sorted_ptr : n;
+    if (t >= ns) return;
+    const unsigned int qi = order ? order[t] : t;
+    const float4 qv = q[qi];
+    if (__float_as_int(qv.w) < 0) return;
+    const float qx = qv.x, qy = qv.y, qz = qv.z;
+    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
+    int k = 1;
+    bool resolved = false;
+    for (;;) {
+        const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+        const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+        const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+        for (int z = z0; z <= z1; ++z) {
+            for (int y = y0; y <= y1; ++y) {
+                const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                const unsigned int s = cell_start[row + x0];
+                const unsigned int e = cell_start[row + x1 + 1];
+                for (unsigned int p = s; p < e; ++p) {
+                    const float4 r = cell_refs[p];
+                    const float d = dist2(qx, qy, qz, r);
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(r.w);
+                    best = key < best ? key : best;
+                }
+            }
+        }
+        const float bd = __uint_as_float((unsigned int)(best >> 32));
+        const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+        if (best != ~0ull && bd < lb2) { resolved = true; break; }
+        if (lb2 == __builtin_inff() && best != ~0ull) { resolved = true; break; }  // whole grid scanned
+        if (k >= GRID_KMAX) break;
+        int kn = 2 * k;
+        if (best != ~0ull) {
+            float need = sqrtf(bd) * g.inv_h;  // cube half-width whose faces clear the current best
+            kn = need < (float)GRID_KMAX ? (int)need + 1 : GRID_KMAX + 1;
+            kn = max(kn, k + 1);
+        }
+        if (kn > GRID_KMAX) {
+            if (k == GRID_KMAX) break;
+            if (best != ~0ull) break;  // would need a cube beyond KMAX: exhaustive fallback
+            kn = GRID_KMAX;
+        }
+        k = kn;
+    }
+    if (resolved) {
+        out[qi] = best;
+    } else {
+        unsigned int slot = atomicAdd(fb_count, 1u);
+        fb_list[slot] = qi;
+    }
+}
+
+int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out) {
+    hipStream_t s = ix->stream;
+    const GridParams g = ix->grid;
+    const unsigned int n = (unsigned int)nq;
+    // sort the queries by reference-grid cell so neighbouring lanes walk the same rows
+    size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
+    PCC_TRY(ix->scratch_b.reserve(cs_bytes));
+    PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(unsigned int) + 256));
+    PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
+    unsigned int* qcell = ix->scratch_b.as<unsigned int>();
+    unsigned int* order = ix->scratch_c.as<unsigned int>();
+    unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
+    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
+    PCC_HIP(hipMemsetAsync(qcell, 0, cs_bytes, s));
+    PCC_HIP(hipMemsetAsync(fb_count, 0, 16, s));
+    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell);
+    PCC_HIP(hipGetLastError());
+    PCC_TRY(launch_exclusive_scan(s, qcell, (size_t)g.ncells + 1, ix->scratch_a));
+    // qcell[ncells] == number of valid queries; keep it on the device for the search kernel
+    unsigned int* n_sorted = fb_count + 1;
+    PCC_HIP(hipMemcpyAsync(n_sorted, qcell + g.ncells, 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_cell_scatter_ids, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell, order, n_sorted);
+    PCC_HIP(hipGetLastError());
+    float maxabs = 0.f;
+    for (int a = 0; a < 3; ++a)
+        maxabs = std::max(maxabs, std::max(std::fabs(g.org[a]), std::fabs(g.org[a] + g.dim[a] * g.h)));
+    float slack = 4e-6f * maxabs + 1e-6f * g.h;
+    hipLaunchKernelGGL(k_grid_nn1, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                       ix->cell_start.as<unsigned int>(), g, slack, q, order, n_sorted, n, out, fb_list, fb_count);
+    PCC_HIP(hipGetLastError());
+    // queries the cubes could not resolve: exhaustive scan over the original-order references
+    PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_valid, q, n, out, fb_list, fb_count, n));
+    return PCC_OK;
+}
+
+}  // namespace pcc

@@ -1,0 +1,251 @@
+// pack.hip -- streaming helper kernels of libpcc_nn (gfx950): AoS -> float4 pack,
+// order-preserving compaction, exclusive scan, result unpack, rigid transform.
+// All of these are HBM-bound single-pass kernels: 16-byte accesses per lane,
+// grid capped and grid-strided (cdna_hip_programming.md Guideline 11/13).
+#include "pcc_internal.hpp"
+
+namespace pcc {
+
+static inline int grid_for(size_t n, int block, int per_thread = 1) {
+    size_t b = (n + (size_t)block * per_thread - 1) / ((size_t)block * per_thread);
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (int)b;
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    // all three finite <=> none is NaN/Inf; (v - v) == 0 only for finite v
+    return (x - x) == 0.0f && (y - y) == 0.0f && (z - z) == 0.0f;
+}
+
+// ---- pack -------------------------------------------------------------------
+// replaces pcl::KdTreeFLANN::convertCloudToArray's copy loop: the
+// first three floats of every element, invalid points flagged for the compaction.
+template <bool VEC16>
+__global__ void __launch_bounds__(256)
+k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
+       unsigned int* __restrict__ n_invalid) {
+    unsigned int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float x, y, z;
+        if (VEC16) {
+            float4 v = *reinterpret_cast<const float4*>(aos + i * stride);
+            x = v.x; y = v.y; z = v.z;
+        } else {
+            const float* p = reinterpret_cast<const float*>(aos + i * stride);
+            x = p[0]; y = p[1]; z = p[2];
+        }
+        float4 o;
+        if (finite3(x, y, z)) {
+            o = make_float4(x, y, z, __int_as_float((int)i));
+        } else {
+            o = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            ++bad;
+        }
+        out[i] = o;
+    }
+    if (n_invalid) {
+        // wave-level sum, one atomic per wave that saw an invalid point
+        for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+        if ((threadIdx.x & 63) == 0 && bad) atomicAdd(n_invalid, bad);
+    }
+}
+
+int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
+                unsigned int* n_invalid) {
+    if (n == 0) return PCC_OK;
+    bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
+    int g = grid_for(n, 256);
+    if (vec)
+        hipLaunchKernelGGL(k_pack<true>, dim3(g), dim3(256), 0, s, (const char*)aos, n, stride, out, n_invalid);
+    else
+        hipLaunchKernelGGL(k_pack<false>, dim3(g), dim3(256), 0, s, (const char*)aos, n, stride, out, n_invalid);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+// ---- exclusive scan (uint32, in place) ------------------------------------------
+constexpr int SCAN_T = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = SCAN_T * SCAN_ITEMS;  // 2048 elements per workgroup
+
+__device__ __forceinline__ unsigned int block_exclusive_scan(unsigned int v, unsigned int* total) {
+    // exclusive scan of one value per thread over a 256-thread workgroup
+    __shared__ unsigned int wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    unsigned int r = base + inc - v;
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(SCAN_T)
+k_scan_reduce(const unsigned int* __restrict__ data, size_t n, unsigned int* __restrict__ bsum) {
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
+    unsigned int s = 0;
+    if (base + SCAN_ITEMS <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(data + base);
+        uint4 a = p[0], b = p[1];
+        s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < n) s += data[base + k];
+    }
+    unsigned int tot;
+    block_exclusive_scan(s, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T)
+k_scan_apply(unsigned int* __restrict__ data, size_t n, const unsigned int* __restrict__ bprefix) {
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
+    unsigned int v[SCAN_ITEMS];
+    bool full = base + SCAN_ITEMS <= n;
+    if (full) {
+        const uint4* p = reinterpret_cast<const uint4*>(data + base);
+        uint4 a = p[0], b = p[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = (base + k < n) ? data[base + k] : 0u;
+    }
+    unsigned int s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
+    unsigned int off = block_exclusive_scan(s, nullptr) + (bprefix ? bprefix[blockIdx.x] : 0u);
+    unsigned int o[SCAN_ITEMS];
+    for (int k = 0; k < SCAN_ITEMS; ++k) { o[k] = off; off += v[k]; }
+    if (full) {
+        uint4* p = reinterpret_cast<uint4*>(data + base);
+        p[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        p[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < n) data[base + k] = o[k];
+    }
+}
+
+static int scan_rec(hipStream_t s, unsigned int* data, size_t n, unsigned int* tmp, size_t tmp_elems) {
+    size_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nb <= 1) {
+        hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(SCAN_T), 0, s, data, n, (const unsigned int*)nullptr);
+        PCC_HIP(hipGetLastError());
+        return PCC_OK;
+    }
+    if (tmp_elems < nb) { set_error("scan scratch too small"); return PCC_ERR_INVALID; }
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, data, n, tmp);
+    PCC_HIP(hipGetLastError());
+    size_t nb_al = (nb + 3) & ~(size_t)3;  // keep the next level 16-byte aligned
+    PCC_TRY(scan_rec(s, tmp, nb, tmp + nb_al, tmp_elems - nb_al));
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, s, data, n, tmp);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp) {
+    if (n == 0) return PCC_OK;
+    size_t elems = 0;
+    for (size_t k = (n + SCAN_BLOCK - 1) / SCAN_BLOCK; k > 1; k = (k + SCAN_BLOCK - 1) / SCAN_BLOCK)
+        elems += ((k + 3) & ~(size_t)3);
+    elems += 16;
+    PCC_TRY(tmp.reserve(elems * sizeof(unsigned int)));
+    return scan_rec(s, data, n, tmp.as<unsigned int>(), elems);
+}
+
+// ---- order-preserving compaction -------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_flag_valid(const float4* __restrict__ in, size_t n, unsigned int* __restrict__ flags) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n;
+         i += (size_t)gridDim.x * blockDim.x)
+        flags[i] = (i < n && __float_as_int(in[i].w) >= 0) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_scatter_valid(const float4* __restrict__ in, size_t n, const unsigned int* __restrict__ pos,
+                float4* __restrict__ out, unsigned int* __restrict__ d_count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = in[i];
+        if (__float_as_int(v.w) >= 0) out[pos[i]] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_count = pos[n];
+}
+
+int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
+                   unsigned int* d_count, DevBuf& tmp) {
+    // tmp layout: flags[n+1] (16-byte aligned) | scan scratch
+    DevBuf& t = tmp;
+    size_t flag_elems = (n + 1 + 3) & ~(size_t)3;
+    size_t scan_elems = 16;
+    for (size_t k = (n + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK; k > 1; k = (k + SCAN_BLOCK - 1) / SCAN_BLOCK)
+        scan_elems += ((k + 3) & ~(size_t)3);
+    PCC_TRY(t.reserve((flag_elems + scan_elems) * sizeof(unsigned int)));
+    unsigned int* flags = t.as<unsigned int>();
+    hipLaunchKernelGGL(k_flag_valid, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, in, n, flags);
+    PCC_HIP(hipGetLastError());
+    PCC_TRY(scan_rec(s, flags, n + 1, flags + flag_elems, scan_elems));
+    hipLaunchKernelGGL(k_scatter_valid, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, flags, out, d_count);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+// ---- unpack -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_unpack(const unsigned long long* __restrict__ packed, const float4* __restrict__ q, size_t n,
+         int32_t* __restrict__ idx, float* __restrict__ d2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long p = packed[i];
+        bool ok = __float_as_int(q[i].w) >= 0 && p != ~0ull;
+        if (idx) idx[i] = ok ? (int32_t)(unsigned int)(p & 0xffffffffull) : -1;
+        if (d2) d2[i] = ok ? __uint_as_float((unsigned int)(p >> 32)) : __builtin_inff();
+    }
+}
+int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
+                  int32_t* idx, float* d2) {
+    if (n == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, s, packed, q, n, idx, d2);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+// ---- rigid transform ------------------------------------------------------------------
+// pcl::transformPointCloud arithmetic: ((m0*x + m1*y) + m2*z) + m3, every
+// op rounded separately (this file is compiled with -ffp-contract=off).
+struct Mat34 { float m[12]; };
+__global__ void __launch_bounds__(256)
+k_transform(Mat34 T, const float* __restrict__ Tdev, const char* __restrict__ src, size_t n,
+            size_t sstride, char* __restrict__ dst, size_t dstride) {
+    float m[12];
+    for (int k = 0; k < 12; ++k) m[k] = Tdev ? Tdev[k] : T.m[k];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float* p = reinterpret_cast<const float*>(src + i * sstride);
+        float x = p[0], y = p[1], z = p[2];
+        float ox = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+        float oy = ((m[4] * x + m[5] * y) + m[6] * z) + m[7];
+        float oz = ((m[8] * x + m[9] * y) + m[10] * z) + m[11];
+        float* o = reinterpret_cast<float*>(dst + i * dstride);
+        o[0] = ox; o[1] = oy; o[2] = oz;
+    }
+}
+int launch_transform(hipStream_t s, const float* Tdev, const float T[16], const void* src, size_t n,
+                     size_t sstride, void* dst, size_t dstride) {
+    if (n == 0) return PCC_OK;
+    Mat34 M;
+    for (int k = 0; k < 12; ++k) M.m[k] = T ? T[k] : 0.f;
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 256)), dim3(256), 0, s, M, Tdev, (const char*)src, n,
+                       sstride, (char*)dst, dstride);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+}  // namespace pcc

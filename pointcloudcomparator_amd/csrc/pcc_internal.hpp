@@ -1,0 +1,101 @@
+// pcc_internal.hpp -- shared declarations of libpcc_nn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "pcc_nn.h"
+
+namespace pcc {
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define PCC_HIP(expr)                                                            \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) {                                                  \
+            pcc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                  \
+            return PCC_ERR_DEVICE;                                               \
+        }                                                                        \
+    } while (0)
+#define PCC_TRY(expr)                 \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != PCC_OK) return _s;  \
+    } while (0)
+
+// ---- device buffer that only grows ------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // returns pcc_status
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Uniform-grid parameters (device + host copy).  Cell of a point:
+//   c_a = clamp(int((p_a - org_a) * inv_h), 0, dim_a - 1)
+// The same expression (same rounding) is used at build and query time.
+struct GridParams {
+    float org[3];
+    float h;
+    float inv_h;
+    int dim[3];
+    int ncells;
+};
+
+}  // namespace pcc
+
+// The opaque handle of the C-ABI.
+struct pcc_index {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream in use
+    hipStream_t own_stream = nullptr;  // library-owned stream
+    size_t n_orig = 0;                 // points handed to pcc_index_create
+    size_t n_valid = 0;                // finite points (PCL total_nr_points_)
+    int engine = PCC_ENGINE_BRUTE;     // resolved engine
+    // packed references in ORIGINAL order: (x, y, z, bits(orig index)); n_valid entries
+    pcc::DevBuf refs;
+    // GRID engine: references permuted into cell order + CSR cell starts
+    bool has_grid = false;
+    pcc::GridParams grid{};
+    pcc::DevBuf cell_refs;   // float4[n_valid], cell-sorted, .w = orig index
+    pcc::DevBuf cell_start;  // uint32[ncells + 1]
+    // scratch (grow-only, reused across calls on the index's stream)
+    pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
+        scratch_c, scratch_d, small;
+    void* pinned = nullptr;  // small pinned host block for scalar read-backs
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace pcc {
+
+// ---- kernels / launchers (pack.hip) -------------------------------------------
+// AoS (stride bytes, 3 floats at offset 0) -> float4(x,y,z,bits(i)); invalid points
+// (non-finite) are counted into *n_invalid and written with w = -1.
+int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
+                unsigned int* n_invalid);
+// order-preserving compaction of the entries with w >= 0 (stable); d_count gets the
+// number kept.  tmp needs (n/1024 + 2) * 4 * 2 bytes.
+int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
+                   unsigned int* d_count, DevBuf& tmp);
+// exclusive scan of uint32 data[n] in place; data[n] receives the total when
+// write_total.  tmp is grown as needed.
+int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
+// packed u64 (d2 bits << 32 | idx) -> idx, d2; queries flagged invalid (w < 0) get -1/+inf
+int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q,
+                  size_t n, int32_t* idx, float* d2);
+int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[16],
+                     const void* src, size_t n, size_t sstride, void* dst, size_t dstride);
+
+// ---- exhaustive engine (nn1_brute.hip) -------------------------------------------
+// For every query q[i] (float4, w<0 = invalid) min over refs[0..m) of the unfused
+// squared distance, lowest original index on ties, merged into out[i] with a 64-bit
+// atomicMin (out must be pre-set to ~0).  If qlist != nullptr only the queries
+// qlist[0..*qcount) are processed (GRID fallback list; count read on device).
+int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* q,
+                     size_t n, unsigned long long* out, const unsigned int* qlist,
+                     const unsigned int* qcount_dev, size_t qcount_max);
+
+}  // namespace pcc

@@ -1,0 +1,96 @@
+"""GPU parity of pcc_nn1 (through the C-ABI) against the oracle: bit-exact indices and d2."""
+import numpy as np
+import pytest
+
+import oracle
+from pointcloudcomparator_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32)
+
+
+def _check(ref, qry, engine):
+    with capi.Index(ref, engine=engine) as ix:
+        idx, d2 = ix.nn1(qry)
+        stats = ix.stats()
+    oi, od = oracle.nn1_exhaustive(ref, qry)
+    assert (_bits(d2) == _bits(od)).all(), f"d2 bits differ at {np.nonzero(_bits(d2) != _bits(od))[0][:5]}"
+    assert (idx == oi).all(), f"idx differ at {np.nonzero(idx != oi)[0][:5]}"
+    return stats
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+@pytest.mark.parametrize("m,n", [(10000, 10000), (1, 7), (15, 100), (16, 1), (1025, 513), (40000, 3000)])
+def test_nn1_corridor(gpu, engine, m, n):
+    a = synth.corridor_cloud(m, synth.SEED_A)
+    b = synth.corridor_cloud(n, synth.SEED_B)
+    _check(a, b, engine)
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_nn1_strides_and_nonfinite(gpu, engine):
+    a = synth.with_rgb_stride(synth.corridor_cloud(5000, synth.SEED_A))  # 32-byte PointXYZRGB stride
+    b = synth.with_rgb_stride(synth.corridor_cloud(3000, synth.SEED_B))
+    a[17, 0] = np.nan
+    a[99, 2] = np.inf
+    a[4999, 1] = -np.inf
+    b[5, 1] = np.nan
+    b[2999, 0] = np.inf
+    with capi.Index(a, engine=engine) as ix:
+        assert ix.size == 4997
+        idx, d2 = ix.nn1(b)
+    oi, od = oracle.nn1_exhaustive(a, b)
+    assert idx[5] == -1 and np.isinf(d2[5]) and idx[2999] == -1
+    assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+    assert not np.isin(idx, [17, 99, 4999]).any()
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_nn1_duplicates_lowest_index(gpu, engine):
+    rng = np.random.default_rng(7)
+    base = rng.random((2000, 3), dtype=np.float32)
+    a = np.concatenate([base, base[::-1], base[:500]])  # every point duplicated, some tripled
+    q = base[rng.integers(0, 2000, 1500)] + np.float32(0)
+    with capi.Index(a, engine=engine) as ix:
+        idx, d2 = ix.nn1(q)
+    oi, od = oracle.nn1_exhaustive(a, q)
+    assert (d2 == 0).all()
+    assert (idx == oi).all()
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_nn1_queries_far_outside(gpu, engine):
+    a = synth.corridor_cloud(20000, synth.SEED_A)
+    b = synth.corridor_cloud(2000, synth.SEED_B)
+    b[:500] += np.float32(50.0)      # far outside the reference bounding box
+    b[500:1000] *= np.float32(-3.0)
+    stats = _check(a, b, engine)
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_nn1_degenerate_shapes(gpu, engine):
+    rng = np.random.default_rng(3)
+    q = rng.random((700, 3), dtype=np.float32)
+    plane = rng.random((6000, 3), dtype=np.float32)
+    plane[:, 2] = 0.25
+    line = np.zeros((5000, 3), np.float32)
+    line[:, 0] = rng.random(5000, dtype=np.float32)
+    same = np.full((4500, 3), 0.5, np.float32)
+    for ref in (plane, line, same):
+        _check(ref, q, engine)
+
+
+def test_device_memory_path(gpu):
+    torch = pytest.importorskip("torch")
+    a = synth.corridor_cloud(30000, synth.SEED_A)
+    b = synth.corridor_cloud(20000, synth.SEED_B)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with capi.Index(ta, engine=capi.ENGINE_GRID) as ix:
+        idx, d2 = ix.nn1(tb)
+        ix.sync()
+        idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    oi, od = oracle.nn1_exhaustive(a, b)
+    assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
