@@ -5,7 +5,7 @@ HIPCC      ?= /opt/rocm/bin/hipcc
 CC         ?= gcc
 CXX        ?= g++
 ARCH       ?= gfx950
-HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -Iinclude -Ipointcloudcomparator_amd/csrc
+HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -Iinclude -Ipointcloudcomparator_amd/csrc
 CSRC       := pointcloudcomparator_amd/csrc
 LIBDIR     := pointcloudcomparator_amd/lib
 HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip)

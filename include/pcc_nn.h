@@ -73,6 +73,11 @@ int pcc_device_count(int *count);
 int pcc_index_create(const void *pts, size_t n, size_t stride_bytes, int dim,
                      int mem, int device, int engine, pcc_index **out);
 int pcc_index_destroy(pcc_index *index);
+/* KdTreeFLANN::setInputCloud on an existing object (cleanup + rebuild):
+ * replaces the indexed cloud, reusing the handle's device allocations.  On error
+ * the index is left empty (searches return PCC_ERR_EMPTY). */
+int pcc_index_set_input(pcc_index *index, const void *pts, size_t n, size_t stride_bytes,
+                        int dim, int mem);
 /* number of valid (finite) reference points == PCL total_nr_points_ */
 int pcc_index_size(const pcc_index *index, size_t *n_valid);
 /* run this index's work on a caller-owned hipStream_t (NULL = library stream) */
@@ -172,6 +177,17 @@ int pcc_match_knn(pcc_index *index_des1, const void *des2, size_t n2,
  *  fallback, [2] reference points valid, [3] grid cells, [4] pair evaluations
  *  (GRID engine, when counting is compiled in; else 0). */
 int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
+/* HIP-event timing of the library's own kernels, recorded on the index's stream
+ * (events of another stream would not see them).  After enabling, every
+ * set_input / search records events into a 64-call ring without synchronising;
+ * pcc_index_timing synchronises the stream and returns the AVERAGE milliseconds
+ * over the calls recorded since enabling (ms[7] = number of main-kernel samples):
+ *  ms[0] main search kernel (GRID ring search, or the exhaustive kernel under
+ *        ENGINE_BRUTE), ms[1] exhaustive fallback pass of the GRID engine,
+ *  ms[2] whole last search call (first to last kernel), ms[3] whole last
+ *  set_input/build, ms[4] query sort (GRID), ms[5..6] reserved. */
+int pcc_index_enable_timing(pcc_index *index, int on);
+int pcc_index_timing(pcc_index *index, float ms[8]);
 
 #ifdef __cplusplus
 }

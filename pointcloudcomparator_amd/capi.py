@@ -26,7 +26,8 @@ SYMBOLS = [
     "pcc_index_sync", "pcc_index_engine", "pcc_index_set_engine",
     "pcc_nn1", "pcc_knn", "pcc_radius_count", "pcc_radius_fill",
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
-    "pcc_match_knn", "pcc_index_stats",
+    "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
+    "pcc_index_timing",
 ]
 
 
@@ -36,7 +37,22 @@ class PccError(RuntimeError):
         self.status = status
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  torch wheels ship their own libamdhip64.so (SONAME
+    libamdhip64.so.7, same as /opt/rocm's).  If libpcc_nn pulled in /opt/rocm's copy first and
+    torch were imported later, two runtimes would fight over the device ("No HIP GPUs are
+    available").  Loading torch's copy first (without importing torch) makes both resolve to it."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def _load() -> C.CDLL:
+    _preload_hip_runtime()
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make lib` (or __graft_entry__.build()). "
@@ -46,6 +62,9 @@ def _load() -> C.CDLL:
     lib.pcc_last_error.restype = C.c_char_p
     lib.pcc_index_create.argtypes = [vp, sz, sz, i32, i32, i32, i32, C.POINTER(vp)]
     lib.pcc_index_destroy.argtypes = [vp]
+    lib.pcc_index_set_input.argtypes = [vp, vp, sz, sz, i32, i32]
+    lib.pcc_index_enable_timing.argtypes = [vp, i32]
+    lib.pcc_index_timing.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pcc_index_size.argtypes = [vp, C.POINTER(sz)]
     lib.pcc_index_set_stream.argtypes = [vp, vp]
     lib.pcc_index_sync.argtypes = [vp]
@@ -127,6 +146,22 @@ class Index:
         _check(LIB.pcc_index_create(ptr, n, stride, 3, mem, device, engine, C.byref(h)))
         self._h = h
         self.n_original = n
+
+    def set_input(self, points):
+        """pcl::KdTreeFLANN::setInputCloud on an existing object: rebuild over a new cloud,
+        reusing the device allocations."""
+        ptr, n, stride, mem = _points(points)
+        _check(LIB.pcc_index_set_input(self._h, ptr, n, stride, 3, mem))
+        self.n_original = n
+
+    def enable_timing(self, on: bool = True):
+        _check(LIB.pcc_index_enable_timing(self._h, int(on)))
+
+    def timing(self):
+        """ms of the instrumented kernels of the last call (see pcc_index_timing)."""
+        t = (C.c_float * 8)()
+        _check(LIB.pcc_index_timing(self._h, t))
+        return list(t)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -63,14 +63,14 @@ struct DeviceGuard {
 // Stage a caller cloud (host or device AoS) as packed float4 on the device.
 // host: one H2D copy of the raw AoS, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
-                        DevBuf& raw, float4* packed, unsigned int* n_invalid_dev) {
+                        DevBuf& raw, float4* packed, unsigned int* n_invalid_dev, bool bbox = false) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, n_invalid_dev);
+    return launch_pack(ix->stream, src, n, stride, packed, n_invalid_dev, bbox);
 }
 
 static int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -99,7 +99,7 @@ static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) 
     return PCC_OK;
 }
 
-int grid_build(pcc_index* ix);  // grid.hip
+int grid_build(pcc_index* ix, const float lo[3], const float hi[3]);  // grid.hip
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out);
 
 // k = 1 search of ix->q_packed[0..nq) into ix->out_packed (u64 per query)
@@ -110,8 +110,65 @@ static int nn1_packed(pcc_index* ix, size_t nq) {
     if (ix->engine == PCC_ENGINE_GRID) return grid_nn1(ix, ix->q_packed.as<float4>(), nq, out);
     ix->stats[0] = 0;
     ix->stats[1] = nq;
-    return launch_nn1_brute(ix->stream, ix->refs.as<float4>(), ix->n_valid, ix->q_packed.as<float4>(), nq,
-                            out, nullptr, nullptr, 0);
+    ev_mark(ix, EV_MAIN0);
+    int st = launch_nn1_brute(ix->stream, ix->refs.as<float4>(), ix->n_valid, ix->q_packed.as<float4>(), nq,
+                              out, nullptr, nullptr, 0);
+    ev_mark(ix, EV_MAIN1);
+    return st;
+}
+
+static inline float ord2f(unsigned int u) {
+    unsigned int b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+static int resolve_engine(int requested, size_t n_valid) {
+    // the grid build costs a few passes over the cloud; below ~4k points one exhaustive
+    // sweep is cheaper than building it
+    if (requested == PCC_ENGINE_AUTO) return n_valid >= 4096 ? PCC_ENGINE_GRID : PCC_ENGINE_BRUTE;
+    return requested;
+}
+
+// (re)build the index over a new cloud: pack (+ bbox + invalid count in the same pass),
+// optional order-preserving compaction, optional grid build.  One stream sync.
+static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
+    ix->n_valid = 0;
+    ix->has_grid = false;
+    ix->n_orig = n;
+    ev_next(ix);
+    ev_mark(ix, EV_BUILD0);
+    PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
+    unsigned int* d_cnt = ix->small.as<unsigned int>();
+    unsigned int* h = static_cast<unsigned int*>(ix->pinned);
+    for (int i = 0; i < 12; ++i) h[i] = (i >= 4 && i < 7) ? 0xffffffffu : 0u;
+    PCC_HIP(hipMemcpyAsync(d_cnt, h, 48, hipMemcpyHostToDevice, ix->stream));
+    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), d_cnt, true));
+    PCC_HIP(hipMemcpyAsync(h + 16, d_cnt, 48, hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    unsigned int n_invalid = h[16];
+    size_t n_valid = n - n_invalid;
+    if (n_valid == 0) { set_error("Cannot create a KDTree with an empty input cloud (all %zu points non-finite)", n); return PCC_ERR_EMPTY; }
+    if (n_invalid) {
+        // order-preserving compaction == PCL's index_mapping_ (SURVEY 9.1)
+        DevBuf packed2;
+        PCC_TRY(packed2.reserve(n_valid * sizeof(float4)));
+        int st = launch_compact(ix->stream, ix->refs.as<float4>(), n, packed2.as<float4>(), d_cnt + 12, ix->scratch_a);
+        if (st == PCC_OK && hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("compaction failed"); st = PCC_ERR_DEVICE; }
+        if (st != PCC_OK) { packed2.release(); return st; }
+        ix->refs.release();
+        ix->refs = packed2;
+    }
+    ix->n_valid = n_valid;
+    ix->stats[2] = n_valid;
+    ix->engine = resolve_engine(ix->engine_requested, n_valid);
+    for (int a = 0; a < 3; ++a) { ix->bbox_lo[a] = ord2f(h[16 + 4 + a]); ix->bbox_hi[a] = ord2f(h[16 + 8 + a]); }
+    if (ix->engine == PCC_ENGINE_GRID) {
+        PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
+    }
+    ev_mark(ix, EV_BUILD1);
+    return PCC_OK;
 }
 
 }  // namespace pcc
@@ -140,6 +197,9 @@ int pcc_index_destroy(pcc_index* ix) {
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d,
                       &ix->small};
     for (DevBuf* b : bufs) b->release();
+    for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
+        for (int k = 0; k < PCC_EV_KINDS; ++k)
+            if (ix->ev[sl][k]) (void)hipEventDestroy(ix->ev[sl][k]);
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
@@ -166,38 +226,57 @@ int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem,
     if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(PCC_ERR_DEVICE); }
     ix->stream = ix->own_stream;
     if (hipHostMalloc(&ix->pinned, 4096, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
-    ix->n_orig = n;
-    if ((st = ix->refs.reserve(n * sizeof(float4))) != PCC_OK) return fail(st);
     if ((st = ix->small.reserve(4096)) != PCC_OK) return fail(st);
-    unsigned int* d_cnt = ix->small.as<unsigned int>();
-    if (hipMemsetAsync(d_cnt, 0, 64, ix->stream) != hipSuccess) { set_error("memset failed"); return fail(PCC_ERR_DEVICE); }
-    if ((st = stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), d_cnt)) != PCC_OK) return fail(st);
-    unsigned int* h = static_cast<unsigned int*>(ix->pinned);
-    if (hipMemcpyAsync(h, d_cnt, 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-        hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("pack failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
-    unsigned int n_invalid = h[0];
-    ix->n_valid = n - n_invalid;
-    if (ix->n_valid == 0) { set_error("Cannot create a KDTree with an empty input cloud (all %zu points non-finite)", n); return fail(PCC_ERR_EMPTY); }
-    if (n_invalid) {
-        // order-preserving compaction == PCL's index_mapping_ (SURVEY 9.1)
-        DevBuf packed2;
-        if ((st = packed2.reserve(ix->n_valid * sizeof(float4))) != PCC_OK) return fail(st);
-        if ((st = launch_compact(ix->stream, ix->refs.as<float4>(), n, packed2.as<float4>(), d_cnt + 4, ix->scratch_a)) != PCC_OK) { packed2.release(); return fail(st); }
-        if (hipStreamSynchronize(ix->stream) != hipSuccess) { packed2.release(); set_error("compaction failed"); return fail(PCC_ERR_DEVICE); }
-        ix->refs.release();
-        ix->refs = packed2;
-    }
-    ix->stats[2] = ix->n_valid;
-    // engine choice: the grid build costs a few passes over the cloud; below ~4k points a
-    // single exhaustive workgroup sweep is cheaper than building it
-    int eng = engine;
-    if (eng == PCC_ENGINE_AUTO) eng = ix->n_valid >= 4096 ? PCC_ENGINE_GRID : PCC_ENGINE_BRUTE;
-    ix->engine = eng;
-    if (eng == PCC_ENGINE_GRID) {
-        if ((st = grid_build(ix)) != PCC_OK) return fail(st);
-    }
+    ix->engine_requested = engine;
+    ix->engine = engine;
+    if ((st = set_input(ix, pts, n, stride, mem)) != PCC_OK) return fail(st);
     if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
     *out = ix;
+    return PCC_OK;
+}
+
+int pcc_index_set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int dim, int mem) {
+    PCC_ENTER(ix);
+    if (dim != 3) { set_error("dim %d unsupported", dim); return PCC_ERR_UNSUPPORTED; }
+    PCC_TRY(check_points(pts, n, stride, mem));
+    if (n == 0) { ix->n_valid = 0; set_error("Cannot create a KDTree with an empty input cloud"); return PCC_ERR_EMPTY; }
+    return set_input(ix, pts, n, stride, mem);
+}
+
+int pcc_index_enable_timing(pcc_index* ix, int on) {
+    PCC_ENTER(ix);
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    if (on) {
+        for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
+            for (int k = 0; k < PCC_EV_KINDS; ++k)
+                if (!ix->ev[sl][k]) PCC_HIP(hipEventCreate(&ix->ev[sl][k]));
+    }
+    for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
+        for (int k = 0; k < PCC_EV_KINDS; ++k) ix->ev_rec[sl][k] = false;
+    ix->ev_slot = 0;
+    ix->timing = on != 0;
+    return PCC_OK;
+}
+
+int pcc_index_timing(pcc_index* ix, float ms[8]) {
+    PCC_ENTER(ix);
+    if (!ms) { set_error("null ms"); return PCC_ERR_INVALID; }
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    const int pairs[5][2] = {{EV_MAIN0, EV_MAIN1}, {EV_FB0, EV_FB1}, {EV_CALL0, EV_CALL1}, {EV_BUILD0, EV_BUILD1}, {EV_SORT0, EV_SORT1}};
+    for (int i = 0; i < 8; ++i) ms[i] = 0.f;
+    for (int i = 0; i < 5; ++i) {
+        double sum = 0;
+        int cnt = 0;
+        for (int sl = 0; sl < PCC_EV_SLOTS; ++sl) {
+            int a = pairs[i][0], b = pairs[i][1];
+            if (ix->ev[sl][a] && ix->ev[sl][b] && ix->ev_rec[sl][a] && ix->ev_rec[sl][b]) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, ix->ev[sl][a], ix->ev[sl][b]) == hipSuccess) { sum += t; ++cnt; }
+            }
+        }
+        if (cnt) ms[i] = (float)(sum / cnt);
+        if (i == 0) ms[7] = (float)cnt;
+    }
     return PCC_OK;
 }
 
@@ -224,10 +303,11 @@ int pcc_index_engine(const pcc_index* ix, int* engine) {
 }
 int pcc_index_set_engine(pcc_index* ix, int engine) {
     PCC_ENTER(ix);
-    if (engine == PCC_ENGINE_AUTO) engine = ix->n_valid >= 4096 ? PCC_ENGINE_GRID : PCC_ENGINE_BRUTE;
-    if (engine != PCC_ENGINE_BRUTE && engine != PCC_ENGINE_GRID) { set_error("bad engine %d", engine); return PCC_ERR_INVALID; }
-    if (engine == PCC_ENGINE_GRID && !ix->has_grid) {
-        PCC_TRY(grid_build(ix));
+    if (engine < PCC_ENGINE_AUTO || engine > PCC_ENGINE_GRID) { set_error("bad engine %d", engine); return PCC_ERR_INVALID; }
+    ix->engine_requested = engine;
+    engine = resolve_engine(engine, ix->n_valid);
+    if (engine == PCC_ENGINE_GRID && !ix->has_grid && ix->n_valid) {
+        PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
         PCC_HIP(hipStreamSynchronize(ix->stream));
     }
     ix->engine = engine;
@@ -243,6 +323,9 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     PCC_ENTER(ix);
     PCC_TRY(check_points(q, nq, stride, mem));
     if (nq == 0) return PCC_OK;
+    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, q, nq, stride, mem));
     PCC_TRY(nn1_packed(ix, nq));
     int32_t* didx = idx;
@@ -254,6 +337,7 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
     PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq, didx, dd2));
+    ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq, mem));
         PCC_TRY(deliver(ix, dd2, d2, nq, mem));

@@ -25,44 +25,6 @@ constexpr int GRID_KMAX = 8;           // largest cube half-width before the exh
 constexpr float GRID_TARGET_PPC = 4.f; // mean points per cell the cell size aims for
 constexpr unsigned int GRID_MAX_CELLS = 1u << 25;
 
-__device__ __forceinline__ unsigned int f2ord(float f) {
-    unsigned int b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-static inline float ord2f(unsigned int u) {
-    unsigned int b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float f;
-    memcpy(&f, &b, 4);
-    return f;
-}
-
-// ---- bounding box ---------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_bbox(const float4* __restrict__ p, unsigned int n, unsigned int* __restrict__ mm /* min[3], max[3] (ordered uints) */) {
-    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 v = p[i];
-        lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
-        lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
-        lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        for (int off = 32; off > 0; off >>= 1) {
-            lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
-            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&mm[a], f2ord(lo[a]));
-            atomicMax(&mm[3 + a], f2ord(hi[a]));
-        }
-    }
-}
-
 __device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int dim) {
     // clamp in float first (no int overflow); the SAME expression runs at build and query time
     float t = fminf(fmaxf((v - org) * inv_h, 0.f), (float)(dim - 1));
@@ -114,24 +76,15 @@ static inline int grid1d(size_t n) {
     return (int)b;
 }
 
-int grid_build(pcc_index* ix) {
+int grid_build(pcc_index* ix, const float lo_in[3], const float hi_in[3]) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)ix->n_valid;
     const float4* refs = ix->refs.as<float4>();
-    // 1. bounding box
-    unsigned int* d_mm = ix->small.as<unsigned int>() + 16;
-    unsigned int init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    PCC_HIP(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_bbox, dim3(grid1d(n)), dim3(256), 0, s, refs, n, d_mm);
-    PCC_HIP(hipGetLastError());
-    unsigned int* h = static_cast<unsigned int*>(ix->pinned) + 16;
-    PCC_HIP(hipMemcpyAsync(h, d_mm, 24, hipMemcpyDeviceToHost, s));
-    PCC_HIP(hipStreamSynchronize(s));
     float lo[3], hi[3], ext[3];
     float maxext = 0.f, maxabs = 0.f;
     for (int a = 0; a < 3; ++a) {
-        lo[a] = ord2f(h[a]);
-        hi[a] = ord2f(h[3 + a]);
+        lo[a] = lo_in[a];
+        hi[a] = hi_in[a];
         ext[a] = hi[a] - lo[a];
         if (!(ext[a] >= 0.f) || !std::isfinite(ext[a])) ext[a] = 0.f;  // overflowed extents fall back to one cell
         maxext = std::max(maxext, ext[a]);
@@ -289,6 +242,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     unsigned int* order = ix->scratch_c.as<unsigned int>();
     unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
     unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
+    ev_mark(ix, EV_SORT0);
     PCC_HIP(hipMemsetAsync(qcell, 0, cs_bytes, s));
     PCC_HIP(hipMemsetAsync(fb_count, 0, 16, s));
     hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell);
@@ -303,11 +257,16 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     for (int a = 0; a < 3; ++a)
         maxabs = std::max(maxabs, std::max(std::fabs(g.org[a]), std::fabs(g.org[a] + g.dim[a] * g.h)));
     float slack = 4e-6f * maxabs + 1e-6f * g.h;
+    ev_mark(ix, EV_SORT1);
+    ev_mark(ix, EV_MAIN0);
     hipLaunchKernelGGL(k_grid_nn1, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                        ix->cell_start.as<unsigned int>(), g, slack, q, order, n_sorted, n, out, fb_list, fb_count);
     PCC_HIP(hipGetLastError());
+    ev_mark(ix, EV_MAIN1);
     // queries the cubes could not resolve: exhaustive scan over the original-order references
+    ev_mark(ix, EV_FB0);
     PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_valid, q, n, out, fb_list, fb_count, n));
+    ev_mark(ix, EV_FB1);
     return PCC_OK;
 }
 

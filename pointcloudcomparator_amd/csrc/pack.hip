@@ -21,11 +21,21 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 // ---- pack -------------------------------------------------------------------
 // replaces pcl::KdTreeFLANN::convertCloudToArray's copy loop: the
 // first three floats of every element, invalid points flagged for the compaction.
-template <bool VEC16>
+__device__ __forceinline__ unsigned int f2ord(float f) {  // order-preserving float -> uint
+    unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// counters[0] += invalid points; counters[4..6] = min xyz, counters[8..10] = max xyz of the
+// valid points as order-preserving uints (only when BBOX): one pass over the cloud feeds both
+// the compaction decision and the grid sizing.
+template <bool VEC16, bool BBOX>
 __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
        unsigned int* __restrict__ n_invalid) {
     unsigned int bad = 0;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         float x, y, z;
@@ -39,6 +49,11 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
         float4 o;
         if (finite3(x, y, z)) {
             o = make_float4(x, y, z, __int_as_float((int)i));
+            if (BBOX) {
+                lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+                lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+                lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+            }
         } else {
             o = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             ++bad;
@@ -49,18 +64,36 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
         // wave-level sum, one atomic per wave that saw an invalid point
         for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
         if ((threadIdx.x & 63) == 0 && bad) atomicAdd(n_invalid, bad);
+        if (BBOX) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                for (int off = 32; off > 0; off >>= 1) {
+                    lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+                    hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+                }
+            }
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    atomicMin(&n_invalid[4 + a], f2ord(lo[a]));
+                    atomicMax(&n_invalid[8 + a], f2ord(hi[a]));
+                }
+            }
+        }
     }
 }
 
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                unsigned int* n_invalid) {
+                unsigned int* n_invalid, bool bbox) {
     if (n == 0) return PCC_OK;
     bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
     int g = grid_for(n, 256);
-    if (vec)
-        hipLaunchKernelGGL(k_pack<true>, dim3(g), dim3(256), 0, s, (const char*)aos, n, stride, out, n_invalid);
-    else
-        hipLaunchKernelGGL(k_pack<false>, dim3(g), dim3(256), 0, s, (const char*)aos, n, stride, out, n_invalid);
+    if (g > 2048) g = 2048;
+    const char* a = (const char*)aos;
+    if (vec && bbox) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
+    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
+    else if (bbox) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
+    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

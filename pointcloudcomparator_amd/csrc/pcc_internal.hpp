@@ -47,6 +47,8 @@ struct GridParams {
 
 }  // namespace pcc
 
+#define PCC_EV_SLOTS 64
+#define PCC_EV_KINDS 10
 // The opaque handle of the C-ABI.
 struct pcc_index {
     int device = 0;
@@ -55,6 +57,8 @@ struct pcc_index {
     size_t n_orig = 0;                 // points handed to pcc_index_create
     size_t n_valid = 0;                // finite points (PCL total_nr_points_)
     int engine = PCC_ENGINE_BRUTE;     // resolved engine
+    int engine_requested = PCC_ENGINE_AUTO;
+    float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the valid points
     // packed references in ORIGINAL order: (x, y, z, bits(orig index)); n_valid entries
     pcc::DevBuf refs;
     // GRID engine: references permuted into cell order + CSR cell starts
@@ -67,15 +71,37 @@ struct pcc_index {
         scratch_c, scratch_d, small;
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
+    // ring of PCC_EV_SLOTS calls so a timed region of many steps is covered without syncing
+    bool timing = false;
+    hipEvent_t ev[PCC_EV_SLOTS][PCC_EV_KINDS] = {};
+    bool ev_rec[PCC_EV_SLOTS][PCC_EV_KINDS] = {};
+    unsigned int ev_slot = 0;  // slot of the call in flight
 };
 
 namespace pcc {
 
+enum { EV_MAIN0 = 0, EV_MAIN1, EV_FB0, EV_FB1, EV_CALL0, EV_CALL1, EV_BUILD0, EV_BUILD1, EV_SORT0, EV_SORT1 };
+inline void ev_mark(pcc_index* ix, int id) {
+    if (!ix->timing) return;
+    unsigned int s = ix->ev_slot % PCC_EV_SLOTS;
+    if (ix->ev[s][id]) { (void)hipEventRecord(ix->ev[s][id], ix->stream); ix->ev_rec[s][id] = true; }
+}
+// a new instrumented call begins: advance the ring and forget what the slot held
+inline void ev_next(pcc_index* ix) {
+    if (!ix->timing) return;
+    ++ix->ev_slot;
+    unsigned int s = ix->ev_slot % PCC_EV_SLOTS;
+    for (int k = 0; k < PCC_EV_KINDS; ++k) ix->ev_rec[s][k] = false;
+}
+
 // ---- kernels / launchers (pack.hip) -------------------------------------------
 // AoS (stride bytes, 3 floats at offset 0) -> float4(x,y,z,bits(i)); invalid points
 // (non-finite) are counted into *n_invalid and written with w = -1.
+// With bbox, n_invalid[4..6] / [8..10] additionally receive min / max xyz of the valid points as
+// order-preserving uints (pre-set to 0xffffffff / 0).
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                unsigned int* n_invalid);
+                unsigned int* n_invalid, bool bbox);
 // order-preserving compaction of the entries with w >= 0 (stable); d_count gets the
 // number kept.  tmp needs (n/1024 + 2) * 4 * 2 bytes.
 int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
