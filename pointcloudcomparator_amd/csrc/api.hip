@@ -63,14 +63,14 @@ struct DeviceGuard {
 // Stage a caller cloud (host or device AoS) as packed float4 on the device.
 // host: one H2D copy of the raw AoS, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
-                        DevBuf& raw, float4* packed, unsigned int* n_invalid_dev, bool bbox = false) {
+                        DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, n_invalid_dev, bbox);
+    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks);
 }
 
 static int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -84,7 +84,7 @@ static int check_points(const void* pts, size_t n, size_t stride, int mem) {
 // queries -> ix->q_packed (float4, w < 0 marks a non-finite query)
 static int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem) {
     PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
-    return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>(), nullptr);
+    return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>());
 }
 
 // deliver device results to the caller's memory space
@@ -117,13 +117,6 @@ static int nn1_packed(pcc_index* ix, size_t nq) {
     return st;
 }
 
-static inline float ord2f(unsigned int u) {
-    unsigned int b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float f;
-    memcpy(&f, &b, 4);
-    return f;
-}
-
 static int resolve_engine(int requested, size_t n_valid) {
     // the grid build costs a few passes over the cloud; below ~4k points one exhaustive
     // sweep is cheaper than building it
@@ -141,13 +134,23 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     ev_mark(ix, EV_BUILD0);
     PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
     unsigned int* d_cnt = ix->small.as<unsigned int>();
-    unsigned int* h = static_cast<unsigned int*>(ix->pinned);
-    for (int i = 0; i < 12; ++i) h[i] = (i >= 4 && i < 7) ? 0xffffffffu : 0u;
-    PCC_HIP(hipMemcpyAsync(d_cnt, h, 48, hipMemcpyHostToDevice, ix->stream));
-    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), d_cnt, true));
-    PCC_HIP(hipMemcpyAsync(h + 16, d_cnt, 48, hipMemcpyDeviceToHost, ix->stream));
+    float* d_blk = ix->blk_stats.as<float>();
+    float* h_blk = static_cast<float*>(ix->pinned);
+    int nblk = 0;
+    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), d_blk, &nblk));
+    PCC_HIP(hipMemcpyAsync(h_blk, d_blk, (size_t)nblk * 8 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     PCC_HIP(hipStreamSynchronize(ix->stream));
-    unsigned int n_invalid = h[16];
+    size_t n_invalid = 0;
+    for (int a = 0; a < 3; ++a) { ix->bbox_lo[a] = INFINITY; ix->bbox_hi[a] = -INFINITY; }
+    for (int b = 0; b < nblk; ++b) {
+        unsigned int bad;
+        memcpy(&bad, &h_blk[b * 8], 4);
+        n_invalid += bad;
+        for (int a = 0; a < 3; ++a) {
+            ix->bbox_lo[a] = std::min(ix->bbox_lo[a], h_blk[b * 8 + 1 + a]);
+            ix->bbox_hi[a] = std::max(ix->bbox_hi[a], h_blk[b * 8 + 4 + a]);
+        }
+    }
     size_t n_valid = n - n_invalid;
     if (n_valid == 0) { set_error("Cannot create a KDTree with an empty input cloud (all %zu points non-finite)", n); return PCC_ERR_EMPTY; }
     if (n_invalid) {
@@ -163,7 +166,6 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     ix->n_valid = n_valid;
     ix->stats[2] = n_valid;
     ix->engine = resolve_engine(ix->engine_requested, n_valid);
-    for (int a = 0; a < 3; ++a) { ix->bbox_lo[a] = ord2f(h[16 + 4 + a]); ix->bbox_hi[a] = ord2f(h[16 + 8 + a]); }
     if (ix->engine == PCC_ENGINE_GRID) {
         PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
     }
@@ -194,8 +196,8 @@ int pcc_index_destroy(pcc_index* ix) {
     DeviceGuard g(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
-                      &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d,
-                      &ix->small};
+                      &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e,
+                      &ix->small, &ix->blk_stats};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -225,8 +227,9 @@ int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem,
     if (!g.ok) { set_error("hipSetDevice(%d) failed", device); return fail(PCC_ERR_DEVICE); }
     if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(PCC_ERR_DEVICE); }
     ix->stream = ix->own_stream;
-    if (hipHostMalloc(&ix->pinned, 4096, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
+    if (hipHostMalloc(&ix->pinned, PACK_MAX_BLOCKS * 8 * sizeof(float) + 4096, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
     if ((st = ix->small.reserve(4096)) != PCC_OK) return fail(st);
+    if ((st = ix->blk_stats.reserve(PACK_MAX_BLOCKS * 8 * sizeof(float))) != PCC_OK) return fail(st);
     ix->engine_requested = engine;
     ix->engine = engine;
     if ((st = set_input(ix, pts, n, stride, mem)) != PCC_OK) return fail(st);

@@ -22,8 +22,9 @@
 namespace pcc {
 
 constexpr int GRID_KMAX = 8;           // largest cube half-width before the exhaustive fallback
-constexpr float GRID_TARGET_PPC = 4.f; // mean points per cell the cell size aims for
-constexpr unsigned int GRID_MAX_CELLS = 1u << 25;
+constexpr float GRID_TARGET_PPC = 0.5f; // mean points per cell (over the bounding box) the cell size aims for;
+                                         // measured optimum on the corridor scene at 1M and 10M points
+constexpr unsigned int GRID_MAX_CELLS = 1u << 26;
 
 __device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int dim) {
     // clamp in float first (no int overflow); the SAME expression runs at build and query time
@@ -38,35 +39,33 @@ __device__ __forceinline__ unsigned int cell_id(const float4& v, const GridParam
 }
 
 // ---- counting sort by cell ----------------------------------------------------------
+// The counting pass hands every point its rank inside its cell (the value the atomic
+// returns), so the scatter pass needs no second round of atomics: pos = start[cell] + rank.
 __global__ void __launch_bounds__(256)
-k_cell_count(const float4* __restrict__ p, unsigned int n, GridParams g, unsigned int* __restrict__ count) {
+k_cell_count(const float4* __restrict__ p, unsigned int n, GridParams g, unsigned int* __restrict__ count,
+             uint2* __restrict__ cell_rank) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = p[i];
-        if (__float_as_int(v.w) < 0) continue;  // invalid query (references are always valid)
-        atomicAdd(&count[cell_id(v, g)], 1u);
-    }
-}
-// cursor[] starts as a copy of the CSR starts and is bumped per point
-__global__ void __launch_bounds__(256)
-k_cell_scatter_refs(const float4* __restrict__ p, unsigned int n, GridParams g,
-                    unsigned int* __restrict__ cursor, float4* __restrict__ out) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 v = p[i];
-        unsigned int pos = atomicAdd(&cursor[cell_id(v, g)], 1u);
-        out[pos] = v;
+        if (__float_as_int(v.w) < 0) { cell_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // invalid query
+        unsigned int c = cell_id(v, g);
+        cell_rank[i] = make_uint2(c, atomicAdd(&count[c], 1u));
     }
 }
 __global__ void __launch_bounds__(256)
-k_cell_scatter_ids(const float4* __restrict__ p, unsigned int n, GridParams g,
-                   unsigned int* __restrict__ cursor, unsigned int* __restrict__ order,
-                   unsigned int* __restrict__ n_sorted) {
+k_cell_scatter_refs(const float4* __restrict__ p, unsigned int n, const uint2* __restrict__ cell_rank,
+                    const unsigned int* __restrict__ start, float4* __restrict__ out) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 v = p[i];
-        if (__float_as_int(v.w) < 0) continue;
-        unsigned int pos = atomicAdd(&cursor[cell_id(v, g)], 1u);
-        order[pos] = i;
+        uint2 cr = cell_rank[i];
+        out[start[cr.x] + cr.y] = p[i];
     }
-    (void)n_sorted;
+}
+__global__ void __launch_bounds__(256)
+k_cell_scatter_ids(unsigned int n, const uint2* __restrict__ cell_rank, const unsigned int* __restrict__ start,
+                   unsigned int* __restrict__ order) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint2 cr = cell_rank[i];
+        if (cr.x != 0xffffffffu) order[start[cr.x] + cr.y] = i;
+    }
 }
 
 static inline int grid1d(size_t n) {
@@ -127,15 +126,14 @@ int grid_build(pcc_index* ix, const float lo_in[3], const float hi_in[3]) {
     size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
     PCC_TRY(ix->cell_start.reserve(cs_bytes));
     PCC_TRY(ix->cell_refs.reserve((size_t)n * sizeof(float4)));
-    PCC_TRY(ix->scratch_b.reserve(cs_bytes));
+    PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(uint2) + 256));
     unsigned int* cstart = ix->cell_start.as<unsigned int>();
-    unsigned int* cursor = ix->scratch_b.as<unsigned int>();
+    uint2* cell_rank = ix->scratch_c.as<uint2>();
     PCC_HIP(hipMemsetAsync(cstart, 0, cs_bytes, s));
-    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, refs, n, g, cstart);
+    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, refs, n, g, cstart, cell_rank);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, cstart, (size_t)g.ncells + 1, ix->scratch_a));
-    PCC_HIP(hipMemcpyAsync(cursor, cstart, cs_bytes, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_cell_scatter_refs, dim3(grid1d(n)), dim3(256), 0, s, refs, n, g, cursor,
+    hipLaunchKernelGGL(k_cell_scatter_refs, dim3(grid1d(n)), dim3(256), 0, s, refs, n, cell_rank, cstart,
                        ix->cell_refs.as<float4>());
     PCC_HIP(hipGetLastError());
     ix->has_grid = true;
@@ -166,6 +164,36 @@ __device__ __forceinline__ float outside_bound2(float qx, float qy, float qz, in
     return lb * lb * 0.9999f;         // relative slack: rounding of the fp32 distances
 }
 
+// one candidate folded into the running (d2, index) key
+__device__ __forceinline__ unsigned long long fold(unsigned long long best, float qx, float qy, float qz,
+                                                   const float4& r) {
+    const float d = dist2(qx, qy, qz, r);
+    const unsigned long long key =
+        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(r.w);
+    return key < best ? key : best;
+}
+
+// scan the contiguous span [s, e) of cell-sorted references.  Four independent 16-byte loads
+// are in flight per lane (the loop is latency-bound otherwise); the tail re-reads the last
+// point of the span, which cannot change the minimum.
+__device__ __forceinline__ unsigned long long scan_span(const float4* __restrict__ cell_refs, unsigned int s,
+                                                        unsigned int e, float qx, float qy, float qz,
+                                                        unsigned long long best) {
+    if (s >= e) return best;
+    const unsigned int last = e - 1;
+    for (unsigned int p = s; p < e; p += 4) {
+        const float4 r0 = cell_refs[p];
+        const float4 r1 = cell_refs[min(p + 1, last)];
+        const float4 r2 = cell_refs[min(p + 2, last)];
+        const float4 r3 = cell_refs[min(p + 3, last)];
+        best = fold(best, qx, qy, qz, r0);
+        best = fold(best, qx, qy, qz, r1);
+        best = fold(best, qx, qy, qz, r2);
+        best = fold(best, qx, qy, qz, r3);
+    }
+    return best;
+}
+
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
            float slack, const float4* __restrict__ q, const unsigned int* __restrict__ order,
@@ -183,43 +211,56 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
     const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
-    int k = 1;
     bool resolved = false;
-    for (;;) {
+    int k = 1;
+    {
+        // k = 1 fast path: fetch the bounds of all 9 rows first (18 independent loads, one
+        // latency), then stream the rows
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        unsigned int rs[9], re[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
+            const bool ok = z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+            const unsigned int row = ((unsigned int)(ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
+            rs[i] = ok ? cell_start[row + x0] : 0u;
+            re[i] = ok ? cell_start[row + x1 + 1] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) best = scan_span(cell_refs, rs[i], re[i], qx, qy, qz, best);
+        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
+        const float bd = __uint_as_float((unsigned int)(best >> 32));
+        const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+        if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
+    }
+    while (!resolved) {
+        // grow the cube: straight to the half-width whose faces clear the current best, or
+        // double it while nothing has been found
+        const float bd = __uint_as_float((unsigned int)(best >> 32));
+        int kn = 2 * k;
+        if (best != ~0ull) {
+            const float need = sqrtf(bd) * g.inv_h;
+            kn = need < (float)GRID_KMAX ? (int)need + 1 : GRID_KMAX + 1;
+            kn = max(kn, k + 1);
+            if (kn > GRID_KMAX) break;  // beyond KMAX: exhaustive fallback
+        } else if (kn > GRID_KMAX) {
+            if (k >= GRID_KMAX) break;
+            kn = GRID_KMAX;
+        }
+        k = kn;
         const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
         const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
         const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
         for (int z = z0; z <= z1; ++z) {
             for (int y = y0; y <= y1; ++y) {
                 const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
-                const unsigned int s = cell_start[row + x0];
-                const unsigned int e = cell_start[row + x1 + 1];
-                for (unsigned int p = s; p < e; ++p) {
-                    const float4 r = cell_refs[p];
-                    const float d = dist2(qx, qy, qz, r);
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(r.w);
-                    best = key < best ? key : best;
-                }
+                best = scan_span(cell_refs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best);
             }
         }
-        const float bd = __uint_as_float((unsigned int)(best >> 32));
+        const float bd2 = __uint_as_float((unsigned int)(best >> 32));
         const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
-        if (best != ~0ull && bd < lb2) { resolved = true; break; }
-        if (lb2 == __builtin_inff() && best != ~0ull) { resolved = true; break; }  // whole grid scanned
-        if (k >= GRID_KMAX) break;
-        int kn = 2 * k;
-        if (best != ~0ull) {
-            float need = sqrtf(bd) * g.inv_h;  // cube half-width whose faces clear the current best
-            kn = need < (float)GRID_KMAX ? (int)need + 1 : GRID_KMAX + 1;
-            kn = max(kn, k + 1);
-        }
-        if (kn > GRID_KMAX) {
-            if (k == GRID_KMAX) break;
-            if (best != ~0ull) break;  // would need a cube beyond KMAX: exhaustive fallback
-            kn = GRID_KMAX;
-        }
-        k = kn;
+        if (best != ~0ull && (bd2 < lb2 || lb2 == __builtin_inff())) resolved = true;
     }
     if (resolved) {
         out[qi] = best;
@@ -236,22 +277,24 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     // sort the queries by reference-grid cell so neighbouring lanes walk the same rows
     size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
     PCC_TRY(ix->scratch_b.reserve(cs_bytes));
-    PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(unsigned int) + 256));
+    PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(uint2) + 256));
     PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
+    PCC_TRY(ix->scratch_e.reserve((size_t)n * sizeof(unsigned int) + 256));
     unsigned int* qcell = ix->scratch_b.as<unsigned int>();
-    unsigned int* order = ix->scratch_c.as<unsigned int>();
+    uint2* cell_rank = ix->scratch_c.as<uint2>();
+    unsigned int* order = ix->scratch_e.as<unsigned int>();
     unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
     unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
     ev_mark(ix, EV_SORT0);
     PCC_HIP(hipMemsetAsync(qcell, 0, cs_bytes, s));
     PCC_HIP(hipMemsetAsync(fb_count, 0, 16, s));
-    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell);
+    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell, cell_rank);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, qcell, (size_t)g.ncells + 1, ix->scratch_a));
     // qcell[ncells] == number of valid queries; keep it on the device for the search kernel
     unsigned int* n_sorted = fb_count + 1;
     PCC_HIP(hipMemcpyAsync(n_sorted, qcell + g.ncells, 4, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_cell_scatter_ids, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell, order, n_sorted);
+    hipLaunchKernelGGL(k_cell_scatter_ids, dim3(grid1d(n)), dim3(256), 0, s, n, cell_rank, qcell, order);
     PCC_HIP(hipGetLastError());
     float maxabs = 0.f;
     for (int a = 0; a < 3; ++a)

@@ -21,18 +21,14 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 // ---- pack -------------------------------------------------------------------
 // replaces pcl::KdTreeFLANN::convertCloudToArray's copy loop: the
 // first three floats of every element, invalid points flagged for the compaction.
-__device__ __forceinline__ unsigned int f2ord(float f) {  // order-preserving float -> uint
-    unsigned int b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-// counters[0] += invalid points; counters[4..6] = min xyz, counters[8..10] = max xyz of the
-// valid points as order-preserving uints (only when BBOX): one pass over the cloud feeds both
-// the compaction decision and the grid sizing.
-template <bool VEC16, bool BBOX>
+// Per-workgroup partial results instead of global atomics: blk[b*8 + 0] = invalid points seen
+// by workgroup b, blk[b*8 + 1..3] = min xyz, blk[b*8 + 4..6] = max xyz of its valid points
+// (floats; +inf/-inf when it saw none).  The host reduces the <= PACK_MAX_BLOCKS rows it
+// reads back.  (Atomics on six shared words serialise: 0.56 ms for 1M points, measured.)
+template <bool VEC16, bool STATS>
 __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
-       unsigned int* __restrict__ n_invalid) {
+       float* __restrict__ blk) {
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -49,7 +45,7 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
         float4 o;
         if (finite3(x, y, z)) {
             o = make_float4(x, y, z, __int_as_float((int)i));
-            if (BBOX) {
+            if (STATS) {
                 lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
                 lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
                 lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
@@ -60,40 +56,52 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
         }
         out[i] = o;
     }
-    if (n_invalid) {
-        // wave-level sum, one atomic per wave that saw an invalid point
+    if (STATS) {
+        __shared__ float red[4][8];
         for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
-        if ((threadIdx.x & 63) == 0 && bad) atomicAdd(n_invalid, bad);
-        if (BBOX) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                for (int off = 32; off > 0; off >>= 1) {
-                    lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
-                    hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
-                }
+        for (int a = 0; a < 3; ++a) {
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+                hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
             }
-            if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    atomicMin(&n_invalid[4 + a], f2ord(lo[a]));
-                    atomicMax(&n_invalid[8 + a], f2ord(hi[a]));
-                }
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            red[wave][0] = __uint_as_float(bad);
+            for (int a = 0; a < 3; ++a) { red[wave][1 + a] = lo[a]; red[wave][4 + a] = hi[a]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int b = 0;
+            float l[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+            float h[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            for (int w = 0; w < 4; ++w) {
+                b += __float_as_uint(red[w][0]);
+                for (int a = 0; a < 3; ++a) { l[a] = fminf(l[a], red[w][1 + a]); h[a] = fmaxf(h[a], red[w][4 + a]); }
             }
+            float* o = blk + (size_t)blockIdx.x * 8;
+            o[0] = __uint_as_float(b);
+            for (int a = 0; a < 3; ++a) { o[1 + a] = l[a]; o[4 + a] = h[a]; }
+            o[7] = 0.f;
         }
     }
 }
 
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                unsigned int* n_invalid, bool bbox) {
+                float* blk_stats, int* n_blocks) {
+    if (n_blocks) *n_blocks = 0;
     if (n == 0) return PCC_OK;
     bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
-    int g = grid_for(n, 256);
-    if (g > 2048) g = 2048;
+    int g = grid_for(n, 256, 2);
+    if (g > PACK_MAX_BLOCKS) g = PACK_MAX_BLOCKS;
+    if (n_blocks) *n_blocks = g;
     const char* a = (const char*)aos;
-    if (vec && bbox) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
-    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
-    else if (bbox) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
-    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, n_invalid);
+    bool st = blk_stats != nullptr;
+    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats);
+    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats);
+    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats);
+    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -68,7 +68,7 @@ struct pcc_index {
     pcc::DevBuf cell_start;  // uint32[ncells + 1]
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
-        scratch_c, scratch_d, small;
+        scratch_c, scratch_d, scratch_e, small, blk_stats;
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
@@ -96,12 +96,12 @@ inline void ev_next(pcc_index* ix) {
 }
 
 // ---- kernels / launchers (pack.hip) -------------------------------------------
-// AoS (stride bytes, 3 floats at offset 0) -> float4(x,y,z,bits(i)); invalid points
-// (non-finite) are counted into *n_invalid and written with w = -1.
-// With bbox, n_invalid[4..6] / [8..10] additionally receive min / max xyz of the valid points as
-// order-preserving uints (pre-set to 0xffffffff / 0).
+// AoS (stride bytes, 3 floats at offset 0) -> float4(x,y,z,bits(i)); non-finite points are
+// written with w = -1.  With blk_stats != nullptr every workgroup b also writes 8 floats:
+// [0] bits(invalid count), [1..3] min xyz, [4..6] max xyz of its valid points; *n_blocks rows.
+constexpr int PACK_MAX_BLOCKS = 1024;
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                unsigned int* n_invalid, bool bbox);
+                float* blk_stats, int* n_blocks);
 // order-preserving compaction of the entries with w >= 0 (stable); d_count gets the
 // number kept.  tmp needs (n/1024 + 2) * 4 * 2 bytes.
 int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
