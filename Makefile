@@ -17,7 +17,7 @@ lib: $(LIBDIR)/libpcc_nn.so
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp include/pcc_nn.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp include/pcc_nn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 

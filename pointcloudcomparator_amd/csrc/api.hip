@@ -99,8 +99,6 @@ static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) 
     return PCC_OK;
 }
 
-int grid_build(pcc_index* ix, const float lo[3], const float hi[3]);  // grid.hip
-int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out);
 
 // k = 1 search of ix->q_packed[0..nq) into ix->out_packed (u64 per query)
 static int nn1_packed(pcc_index* ix, size_t nq) {
@@ -197,7 +195,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e,
-                      &ix->small, &ix->blk_stats};
+                      &ix->small, &ix->blk_stats, &ix->icp_src};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -339,7 +337,8 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq, didx, dd2));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq,
+                          ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq, mem));
@@ -349,16 +348,420 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     return PCC_OK;
 }
 
-// ---- entry points still to be wired to kernels (round-1 work in progress) ----------------
-#define PCC_NOT_YET(name) pcc::set_error(name " is not implemented yet"); return PCC_ERR_UNSUPPORTED
-int pcc_knn(pcc_index*, const void*, size_t, size_t, int, int, int32_t*, float*) { PCC_NOT_YET("pcc_knn"); }
-int pcc_radius_count(pcc_index*, const void*, size_t, size_t, int, double, int32_t*) { PCC_NOT_YET("pcc_radius_count"); }
-int pcc_radius_fill(pcc_index*, const void*, size_t, size_t, int, double, int, const int64_t*, int32_t*, float*) { PCC_NOT_YET("pcc_radius_fill"); }
-int pcc_euclidean_clusters(pcc_index*, double, uint32_t, uint32_t, int, int32_t*, int32_t*, int32_t*, int) { PCC_NOT_YET("pcc_euclidean_clusters"); }
-int pcc_sor(pcc_index*, int, double, int, float*, uint8_t*, double*, size_t*) { PCC_NOT_YET("pcc_sor"); }
-int pcc_icp_step(pcc_index*, const void*, size_t, size_t, int, int32_t*, float*, double*) { PCC_NOT_YET("pcc_icp_step"); }
-int pcc_transform(pcc_index*, const float*, const void*, size_t, size_t, void*, size_t, int) { PCC_NOT_YET("pcc_transform"); }
-int pcc_icp_align(pcc_index*, const void*, size_t, size_t, int, int, int, float*, double*, int*, int*) { PCC_NOT_YET("pcc_icp_align"); }
-int pcc_match_knn(pcc_index*, const void*, size_t, size_t, int, float, int32_t*, int32_t*) { PCC_NOT_YET("pcc_match_knn"); }
+// the searches below need the cell grid whatever engine k=1 uses
+static int ensure_grid(pcc_index* ix) {
+    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    if (!ix->has_grid) PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
+    return PCC_OK;
+}
+
+int pcc_knn(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int k, int32_t* idx, float* d2) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(q, nq, stride, mem));
+    if (k < 1 || k > PCC_KNN_MAX_K) { set_error("k=%d outside [1, %d]", k, PCC_KNN_MAX_K); return PCC_ERR_UNSUPPORTED; }
+    if (nq == 0) return PCC_OK;
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, q, nq, stride, mem));
+    PCC_TRY(ix->out_packed.reserve(nq * (size_t)k * sizeof(unsigned long long)));
+    auto* keys = ix->out_packed.as<unsigned long long>();
+    PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, k, keys));
+    int32_t* didx = idx;
+    float* dd2 = d2;
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(ix->out_idx.reserve(nq * (size_t)k * sizeof(int32_t)));
+        PCC_TRY(ix->out_d2.reserve(nq * (size_t)k * sizeof(float)));
+        didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
+        dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
+    }
+    // rows of invalid queries were never touched (all ~0) and unpack to -1 / +inf
+    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, nq * (size_t)k, ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, didx, idx, nq * (size_t)k, mem));
+        PCC_TRY(deliver(ix, dd2, d2, nq * (size_t)k, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+// radiusSearch(pt, double radius): r2 = float(radius*radius) evaluated in double
+static inline float radius2(double radius) { return (float)(radius * radius); }
+
+int pcc_radius_count(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int32_t* counts) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(q, nq, stride, mem));
+    if (!counts) { set_error("null counts"); return PCC_ERR_INVALID; }
+    if (!(radius >= 0)) { set_error("bad radius"); return PCC_ERR_INVALID; }
+    if (nq == 0) return PCC_OK;
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, q, nq, stride, mem));
+    int32_t* dcnt = counts;
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(nq * sizeof(int32_t))); dcnt = ix->out_idx.as<int32_t>(); }
+    PCC_HIP(hipMemsetAsync(dcnt, 0, nq * sizeof(int32_t), ix->stream));
+    PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), dcnt, nullptr, nullptr, 0));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, dcnt, counts, nq, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int sorted,
+                    const int64_t* offsets, int32_t* idx, float* d2) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(q, nq, stride, mem));
+    if (!offsets) { set_error("null offsets"); return PCC_ERR_INVALID; }
+    if (nq == 0) return PCC_OK;
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, q, nq, stride, mem));
+    // total = offsets[nq]; offsets live in the caller's memory space
+    int64_t total = 0;
+    const int64_t* doff = offsets;
+    if (mem == PCC_MEM_HOST) {
+        total = offsets[nq];
+        PCC_TRY(ix->scratch_d.reserve((nq + 1) * sizeof(int64_t)));
+        PCC_HIP(hipMemcpyAsync(ix->scratch_d.p, offsets, (nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+        doff = ix->scratch_d.as<int64_t>();
+    } else {
+        PCC_HIP(hipMemcpyAsync(&total, offsets + nq, sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    if (total < 0) { set_error("negative total"); return PCC_ERR_INVALID; }
+    if (total == 0) return PCC_OK;
+    PCC_TRY(ix->out_packed.reserve((size_t)total * sizeof(unsigned long long)));
+    auto* keys = ix->out_packed.as<unsigned long long>();
+    PCC_HIP(hipMemsetAsync(keys, 0xff, (size_t)total * sizeof(unsigned long long), ix->stream));
+    PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), nullptr, doff, keys, sorted));
+    int32_t* didx = idx;
+    float* dd2 = d2;
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(ix->out_idx.reserve((size_t)total * sizeof(int32_t)));
+        PCC_TRY(ix->out_d2.reserve((size_t)total * sizeof(float)));
+        didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
+        dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
+    }
+    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, (size_t)total, ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, didx, idx, (size_t)total, mem));
+        PCC_TRY(deliver(ix, dd2, d2, (size_t)total, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+int pcc_euclidean_clusters(pcc_index* ix, double tolerance, uint32_t min_size, uint32_t max_size, int mem,
+                           int32_t* labels, int32_t* n_clusters, int32_t* sizes, int max_sizes) {
+    PCC_ENTER(ix);
+    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
+    if (!labels) { set_error("null labels"); return PCC_ERR_INVALID; }
+    if (!(tolerance >= 0)) { set_error("bad tolerance"); return PCC_ERR_INVALID; }
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    // EuclideanClusterExtraction stores the tolerance as double, extractEuclideanClusters takes
+    // it as float, radiusSearch squares it in double: r2 = float(double(float(tol))^2)
+    const float tol_f = (float)tolerance;
+    const float r2 = radius2((double)tol_f);
+    int32_t* dl = labels;
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(ix->n_orig * sizeof(int32_t))); dl = ix->out_idx.as<int32_t>(); }
+    PCC_TRY(grid_clusters(ix, tol_f, r2, min_size, max_size, dl, n_clusters, sizes, max_sizes));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, dl, labels, ix->n_orig, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_dist, uint8_t* inlier,
+            double* threshold, size_t* kept) {
+    PCC_ENTER(ix);
+    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
+    if (mean_k < 1 || mean_k + 1 > PCC_KNN_MAX_K) { set_error("mean_k=%d outside [1, %d]", mean_k, PCC_KNN_MAX_K - 1); return PCC_ERR_UNSUPPORTED; }
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    const size_t n = ix->n_valid, no = ix->n_orig;
+    const int K = mean_k + 1;
+    // self query: the packed references ARE the queries (non-finite points are not in refs and
+    // keep distance 0, as in PCL's applyFilterIndices)
+    PCC_TRY(ix->out_packed.reserve(n * (size_t)K * sizeof(unsigned long long)));
+    auto* keys = ix->out_packed.as<unsigned long long>();
+    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, K, keys));
+    PCC_TRY(ix->out_d2.reserve(no * sizeof(float)));
+    float* dmean = ix->out_d2.as<float>();
+    PCC_HIP(hipMemsetAsync(dmean, 0, no * sizeof(float), ix->stream));
+    PCC_TRY(launch_sor_mean(ix->stream, keys, ix->refs.as<float4>(), n, K, dmean));
+    ev_mark(ix, EV_CALL1);
+    std::vector<float> hm(no);
+    PCC_HIP(hipMemcpyAsync(hm.data(), dmean, no * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    // PCL: sum / sq_sum over ALL entries in index order (double), valid = points with a full
+    // neighbourhood.  Invalid points and points without k neighbours contribute 0.
+    size_t valid = ix->n_valid >= (size_t)K ? n : 0;
+    double sum = 0, sq = 0;
+    for (size_t i = 0; i < no; ++i) { sum += hm[i]; sq += (double)hm[i] * hm[i]; }
+    double mean = sum / (double)valid;
+    double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
+    double thr = mean + stddev_mult * std::sqrt(var);
+    std::vector<uint8_t> hin(no);
+    size_t k_in = 0;
+    for (size_t i = 0; i < no; ++i) { hin[i] = !(hm[i] > thr); k_in += hin[i]; }
+    if (threshold) *threshold = thr;
+    if (kept) *kept = k_in;
+    if (mem == PCC_MEM_HOST) {
+        if (mean_dist) memcpy(mean_dist, hm.data(), no * sizeof(float));
+        if (inlier) memcpy(inlier, hin.data(), no);
+    } else {
+        if (mean_dist) PCC_HIP(hipMemcpyAsync(mean_dist, dmean, no * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
+        if (inlier) PCC_HIP(hipMemcpyAsync(inlier, hin.data(), no, hipMemcpyHostToDevice, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+// ---- ICP ------------------------------------------------------------------------------------
+// reduce the per-workgroup partial rows in a fixed order
+static int icp_reduce(pcc_index* ix, size_t n, double sums[17]) {
+    PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
+    int nb = 0;
+    PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
+                            ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb));
+    std::vector<double> h((size_t)nb * 17);
+    PCC_HIP(hipMemcpyAsync(h.data(), ix->scratch_a.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    for (int k = 0; k < 17; ++k) sums[k] = 0;
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < 17; ++k) sums[k] += h[(size_t)b * 17 + k];
+    return PCC_OK;
+}
+
+// largest eigenvector of a symmetric 4x4 (cyclic Jacobi), for Horn's closed-form absolute orientation
+static void sym4_max_eigvec(double A[4][4], double v[4]) {
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (std::fabs(A[p][q]) < 1e-300) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (A[i][i] > A[best][best]) best = i;
+    for (int k = 0; k < 4; ++k) v[k] = V[k][best];
+}
+
+// rigid transform (rotation + translation, no scale) minimising sum |R p + t - q|^2 from the sums:
+// the same optimum TransformationEstimationSVD / Eigen::umeyama(src, tgt, false) returns, obtained
+// with Horn's unit-quaternion method in double.  Returns 0, or -1 with < 3 correspondences.
+static int rigid_from_sums(const double sums[17], float T[16]) {
+    const double n = sums[16];
+    if (n < 3) return -1;  // min_number_correspondences_
+    double pm[3], qm[3], S[3][3];
+    for (int a = 0; a < 3; ++a) { pm[a] = sums[a] / n; qm[a] = sums[3 + a] / n; }
+    for (int a = 0; a < 3; ++a)      // S[a][b] = sum (p_a - pm_a)(q_b - qm_b)
+        for (int b = 0; b < 3; ++b) S[a][b] = sums[6 + b * 3 + a] - n * pm[a] * qm[b];
+    double N[4][4] = {
+        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+    double qv[4];
+    sym4_max_eigvec(N, qv);
+    double nrm = std::sqrt(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3]);
+    if (!(nrm > 0)) return -1;
+    const double w = qv[0] / nrm, x = qv[1] / nrm, y = qv[2] / nrm, z = qv[3] / nrm;
+    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                            {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                            {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    for (int r = 0; r < 3; ++r) {
+        double t = qm[r];
+        for (int c = 0; c < 3; ++c) { T[r * 4 + c] = (float)R[r][c]; t -= R[r][c] * pm[c]; }
+        T[r * 4 + 3] = (float)t;
+    }
+    T[12] = T[13] = T[14] = 0.f;
+    T[15] = 1.f;
+    return 0;
+}
+
+static void mat4_mul_f(const float A[16], const float B[16], float C[16]) {
+    float R[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0;
+            for (int k = 0; k < 4; ++k) acc += A[r * 4 + k] * B[k * 4 + c];
+            R[r * 4 + c] = acc;
+        }
+    memcpy(C, R, sizeof(R));
+}
+
+int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int mem, int32_t* idx, float* d2,
+                 double sums[17]) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(src, n, stride, mem));
+    if (!sums) { set_error("null sums"); return PCC_ERR_INVALID; }
+    for (int k = 0; k < 17; ++k) sums[k] = 0;
+    if (n == 0) return PCC_OK;
+    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, src, n, stride, mem));
+    PCC_TRY(nn1_packed(ix, n));
+    PCC_TRY(icp_reduce(ix, n, sums));
+    ev_mark(ix, EV_CALL1);
+    if (idx || d2) {
+        int32_t* didx = idx;
+        float* dd2 = d2;
+        if (mem == PCC_MEM_HOST) {
+            PCC_TRY(ix->out_idx.reserve(n * sizeof(int32_t)));
+            PCC_TRY(ix->out_d2.reserve(n * sizeof(float)));
+            didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
+            dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
+        }
+        PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n,
+                              ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+        if (mem == PCC_MEM_HOST) {
+            PCC_TRY(deliver(ix, didx, idx, n, mem));
+            PCC_TRY(deliver(ix, dd2, d2, n, mem));
+            PCC_HIP(hipStreamSynchronize(ix->stream));
+        }
+    }
+    return PCC_OK;
+}
+
+int pcc_transform(pcc_index* ix, const float T[16], const void* src, size_t n, size_t sstride, void* dst,
+                  size_t dstride, int mem) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(src, n, sstride, mem));
+    PCC_TRY(check_points(dst, n, dstride, mem));
+    if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
+    if (n == 0) return PCC_OK;
+    if (mem == PCC_MEM_DEVICE) return launch_transform(ix->stream, nullptr, T, src, n, sstride, dst, dstride);
+    // host: stage src (and dst, so that its other fields survive) on the device
+    PCC_TRY(ix->q_raw.reserve(n * sstride));
+    PCC_HIP(hipMemcpyAsync(ix->q_raw.p, src, (n - 1) * sstride + 12, hipMemcpyHostToDevice, ix->stream));
+    void* ddst = ix->q_raw.p;
+    size_t dbytes = (n - 1) * dstride + 12;
+    if (dst != src || dstride != sstride) {
+        PCC_TRY(ix->scratch_d.reserve(n * dstride));
+        PCC_HIP(hipMemcpyAsync(ix->scratch_d.p, dst, dbytes, hipMemcpyHostToDevice, ix->stream));
+        ddst = ix->scratch_d.p;
+    }
+    PCC_TRY(launch_transform(ix->stream, nullptr, T, ix->q_raw.p, n, sstride, ddst, dstride));
+    PCC_HIP(hipMemcpyAsync(dst, ddst, dbytes, hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    return PCC_OK;
+}
+
+int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int mem, int max_iter, int fixed,
+                  float T[16], double* fitness, int* iterations, int* converged) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(src, n, stride, mem));
+    if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
+    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(T, I, sizeof(I));
+    if (iterations) *iterations = 0;
+    if (converged) *converged = 0;
+    if (n == 0) return PCC_OK;
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    // the source stays resident: q_packed is the moving cloud, icp_src keeps the input
+    PCC_TRY(stage_queries(ix, src, n, stride, mem));
+    PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
+    PCC_HIP(hipMemcpyAsync(ix->icp_src.p, ix->q_packed.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ix->stream));
+    int it = 0;
+    bool conv = false;
+    double prev_mse = 1.79769313486231570e308;
+    while (it < max_iter) {
+        PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
+        double sums[17];
+        PCC_TRY(icp_reduce(ix, n, sums));
+        float Ti[16];
+        if (rigid_from_sums(sums, Ti) != 0) { conv = false; break; }  // < 3 correspondences: not converged
+        PCC_TRY(launch_transform(ix->stream, nullptr, Ti, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
+        mat4_mul_f(Ti, T, T);  // final = T_i * final
+        const double mse = sums[15] / sums[16];
+        ++it;
+        if (it >= max_iter) { conv = true; break; }  // DefaultConvergenceCriteria: iteration cap counts as converged
+        if (!fixed && std::fabs(mse - prev_mse) < 1e-12) { conv = true; break; }
+        prev_mse = mse;
+    }
+    if (iterations) *iterations = it;
+    if (converged) *converged = conv ? 1 : 0;
+    if (fitness) {
+        // getFitnessScore: re-transform the INPUT with the final matrix, one more NN pass, mean d2
+        PCC_TRY(launch_transform(ix->stream, nullptr, T, ix->icp_src.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
+        // launch_transform writes x,y,z only: refresh the validity flags from the input
+        PCC_TRY(launch_copy_w(ix->stream, ix->icp_src.as<float4>(), ix->q_packed.as<float4>(), n));
+        PCC_TRY(nn1_packed(ix, n));
+        double sums[17];
+        PCC_TRY(icp_reduce(ix, n, sums));
+        *fitness = sums[16] > 0 ? sums[15] / sums[16] : 1.79769313486231570e308;
+    }
+    ev_mark(ix, EV_CALL1);
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    return PCC_OK;
+}
+
+int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int mem, float threshold,
+                  int32_t* out, int32_t* out_size) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(des2, n2, stride, mem));
+    if (!out || !out_size) { set_error("null output"); return PCC_ERR_INVALID; }
+    out[0] = 0;  // std::vector<int> correspondence(1) -- reference src/comparator.cpp:568
+    *out_size = 1;
+    if (n2 == 0) return PCC_OK;
+    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
+    PCC_TRY(nn1_packed(ix, n2));
+    PCC_TRY(ix->out_idx.reserve(n2 * sizeof(int32_t)));
+    PCC_TRY(ix->out_d2.reserve(n2 * sizeof(float)));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n2,
+                          ix->refs.as<float4>(), ix->n_valid == ix->n_orig, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));
+    ev_mark(ix, EV_CALL1);
+    std::vector<int32_t> hi(n2);
+    std::vector<float> hd(n2);
+    PCC_HIP(hipMemcpyAsync(hi.data(), ix->out_idx.p, n2 * sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipMemcpyAsync(hd.data(), ix->out_d2.p, n2 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    int32_t c = 1;
+    for (size_t i = 0; i < n2; ++i)  // neighborCount == 1 && squaredDistances[0] < threshold (:579)
+        if (hi[i] >= 0 && hd[i] < threshold) out[c++] = hi[i];
+    *out_size = c;
+    return PCC_OK;
+}
 
 }  // extern "C"

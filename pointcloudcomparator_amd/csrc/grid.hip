@@ -4,7 +4,7 @@
 // prune the exhaustive scan without changing a single result bit.
 //
 // Index layout in HBM:
-//   cell_refs  float4[n_valid]   (x, y, z, bits(original index)), sorted by linear
+//   cell_refs  float4[n_valid]   (x, y, z, bits(position in the packed original-order array)), sorted by linear
 //                                cell id with x fastest, so one row of cells along x
 //                                is ONE contiguous span of points
 //   cell_start uint32[ncells+1]  CSR starts
@@ -15,28 +15,16 @@
 // handed to the exhaustive kernel.  Distances use the same unfused fp32 arithmetic
 // as nn1_brute.hip (-ffp-contract=off), so both engines return identical bits.
 #include "pcc_internal.hpp"
+#include "grid_device.hpp"
 #include <cmath>
 #include <cstring>
 #include <algorithm>
 
 namespace pcc {
 
-constexpr int GRID_KMAX = 8;           // largest cube half-width before the exhaustive fallback
 constexpr float GRID_TARGET_PPC = 0.5f; // mean points per cell (over the bounding box) the cell size aims for;
                                          // measured optimum on the corridor scene at 1M and 10M points
 constexpr unsigned int GRID_MAX_CELLS = 1u << 26;
-
-__device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int dim) {
-    // clamp in float first (no int overflow); the SAME expression runs at build and query time
-    float t = fminf(fmaxf((v - org) * inv_h, 0.f), (float)(dim - 1));
-    return (int)t;
-}
-__device__ __forceinline__ unsigned int cell_id(const float4& v, const GridParams& g) {
-    int cx = cell_coord(v.x, g.org[0], g.inv_h, g.dim[0]);
-    int cy = cell_coord(v.y, g.org[1], g.inv_h, g.dim[1]);
-    int cz = cell_coord(v.z, g.org[2], g.inv_h, g.dim[2]);
-    return ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
-}
 
 // ---- counting sort by cell ----------------------------------------------------------
 // The counting pass hands every point its rank inside its cell (the value the atomic
@@ -56,7 +44,9 @@ k_cell_scatter_refs(const float4* __restrict__ p, unsigned int n, const uint2* _
                     const unsigned int* __restrict__ start, float4* __restrict__ out) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint2 cr = cell_rank[i];
-        out[start[cr.x] + cr.y] = p[i];
+        float4 v = p[i];
+        v.w = __int_as_float((int)i);  // cell-sorted copies carry the packed POSITION, not the original index
+        out[start[cr.x] + cr.y] = v;
     }
 }
 __global__ void __launch_bounds__(256)
@@ -141,29 +131,6 @@ int grid_build(pcc_index* ix, const float lo_in[3], const float hi_in[3]) {
 }
 
 // ---- k = 1 search ------------------------------------------------------------------------
-__device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& r) {
-    float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
-    float d = dx * dx;
-    d = d + dy * dy;
-    d = d + dz * dz;
-    return d;
-}
-
-// lower bound (squared, shrunk) of the distance from q to any point outside the cell cube
-// [x0..x1] x [y0..y1] x [z0..z1]; +inf when the cube covers the whole grid
-__device__ __forceinline__ float outside_bound2(float qx, float qy, float qz, int x0, int x1, int y0,
-                                                int y1, int z0, int z1, const GridParams& g, float slack) {
-    float lb = __builtin_inff();
-    if (x0 > 0) lb = fminf(lb, qx - (g.org[0] + x0 * g.h));
-    if (x1 < g.dim[0] - 1) lb = fminf(lb, (g.org[0] + (x1 + 1) * g.h) - qx);
-    if (y0 > 0) lb = fminf(lb, qy - (g.org[1] + y0 * g.h));
-    if (y1 < g.dim[1] - 1) lb = fminf(lb, (g.org[1] + (y1 + 1) * g.h) - qy);
-    if (z0 > 0) lb = fminf(lb, qz - (g.org[2] + z0 * g.h));
-    if (z1 < g.dim[2] - 1) lb = fminf(lb, (g.org[2] + (z1 + 1) * g.h) - qz);
-    lb = fmaxf(lb - slack, 0.f);      // absolute slack: cell-boundary rounding
-    return lb * lb * 0.9999f;         // relative slack: rounding of the fp32 distances
-}
-
 // one candidate folded into the running (d2, index) key
 __device__ __forceinline__ unsigned long long fold(unsigned long long best, float qx, float qy, float qz,
                                                    const float4& r) {
@@ -270,37 +237,53 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
-int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out) {
+float grid_slack(const GridParams& g) {
+    float maxabs = 0.f;
+    for (int a = 0; a < 3; ++a)
+        maxabs = std::max(maxabs, std::max(std::fabs(g.org[a]), std::fabs(g.org[a] + g.dim[a] * g.h)));
+    return 4e-6f * maxabs + 1e-6f * g.h;
+}
+
+// sort the queries by reference-grid cell so neighbouring lanes walk the same rows
+int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
+                      unsigned int** n_sorted_dev) {
     hipStream_t s = ix->stream;
     const GridParams g = ix->grid;
     const unsigned int n = (unsigned int)nq;
-    // sort the queries by reference-grid cell so neighbouring lanes walk the same rows
     size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
     PCC_TRY(ix->scratch_b.reserve(cs_bytes));
     PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(uint2) + 256));
-    PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
     PCC_TRY(ix->scratch_e.reserve((size_t)n * sizeof(unsigned int) + 256));
     unsigned int* qcell = ix->scratch_b.as<unsigned int>();
     uint2* cell_rank = ix->scratch_c.as<uint2>();
     unsigned int* order = ix->scratch_e.as<unsigned int>();
-    unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
-    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
+    unsigned int* n_sorted = ix->small.as<unsigned int>() + 33;
     ev_mark(ix, EV_SORT0);
     PCC_HIP(hipMemsetAsync(qcell, 0, cs_bytes, s));
-    PCC_HIP(hipMemsetAsync(fb_count, 0, 16, s));
     hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell, cell_rank);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, qcell, (size_t)g.ncells + 1, ix->scratch_a));
-    // qcell[ncells] == number of valid queries; keep it on the device for the search kernel
-    unsigned int* n_sorted = fb_count + 1;
+    // qcell[ncells] == number of valid queries; keep it on the device for the search kernels
     PCC_HIP(hipMemcpyAsync(n_sorted, qcell + g.ncells, 4, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_cell_scatter_ids, dim3(grid1d(n)), dim3(256), 0, s, n, cell_rank, qcell, order);
     PCC_HIP(hipGetLastError());
-    float maxabs = 0.f;
-    for (int a = 0; a < 3; ++a)
-        maxabs = std::max(maxabs, std::max(std::fabs(g.org[a]), std::fabs(g.org[a] + g.dim[a] * g.h)));
-    float slack = 4e-6f * maxabs + 1e-6f * g.h;
     ev_mark(ix, EV_SORT1);
+    *order_dev = order;
+    *n_sorted_dev = n_sorted;
+    return PCC_OK;
+}
+
+int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out) {
+    hipStream_t s = ix->stream;
+    const GridParams g = ix->grid;
+    const unsigned int n = (unsigned int)nq;
+    PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
+    unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
+    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
+    PCC_HIP(hipMemsetAsync(fb_count, 0, 4, s));
+    unsigned int *order = nullptr, *n_sorted = nullptr;
+    PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
+    const float slack = grid_slack(g);
     ev_mark(ix, EV_MAIN0);
     hipLaunchKernelGGL(k_grid_nn1, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                        ix->cell_start.as<unsigned int>(), g, slack, q, order, n_sorted, n, out, fb_list, fb_count);

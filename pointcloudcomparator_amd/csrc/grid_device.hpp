@@ -1,0 +1,52 @@
+// grid_device.hpp -- device helpers shared by the GRID-engine kernels (grid.hip, knn.hip,
+// cluster.hip).  Built with -ffp-contract=off: dist2 must round like FLANN's L2_Simple.
+#pragma once
+#include "pcc_internal.hpp"
+
+namespace pcc {
+
+constexpr int GRID_KMAX = 8;  // largest cube half-width before the exhaustive fallback
+
+__device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int dim) {
+    // clamp in float first (no int overflow); the SAME expression runs at build and query time
+    float t = fminf(fmaxf((v - org) * inv_h, 0.f), (float)(dim - 1));
+    return (int)t;
+}
+__device__ __forceinline__ unsigned int cell_id(const float4& v, const GridParams& g) {
+    int cx = cell_coord(v.x, g.org[0], g.inv_h, g.dim[0]);
+    int cy = cell_coord(v.y, g.org[1], g.inv_h, g.dim[1]);
+    int cz = cell_coord(v.z, g.org[2], g.inv_h, g.dim[2]);
+    return ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& r) {
+    float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
+    float d = dx * dx;
+    d = d + dy * dy;
+    d = d + dz * dz;
+    return d;
+}
+
+// lower bound (squared, shrunk) of the distance from q to any point outside the cell cube
+// [x0..x1] x [y0..y1] x [z0..z1]; +inf when the cube covers the whole grid
+__device__ __forceinline__ float outside_bound2(float qx, float qy, float qz, int x0, int x1, int y0,
+                                                int y1, int z0, int z1, const GridParams& g, float slack) {
+    float lb = __builtin_inff();
+    if (x0 > 0) lb = fminf(lb, qx - (g.org[0] + x0 * g.h));
+    if (x1 < g.dim[0] - 1) lb = fminf(lb, (g.org[0] + (x1 + 1) * g.h) - qx);
+    if (y0 > 0) lb = fminf(lb, qy - (g.org[1] + y0 * g.h));
+    if (y1 < g.dim[1] - 1) lb = fminf(lb, (g.org[1] + (y1 + 1) * g.h) - qy);
+    if (z0 > 0) lb = fminf(lb, qz - (g.org[2] + z0 * g.h));
+    if (z1 < g.dim[2] - 1) lb = fminf(lb, (g.org[2] + (z1 + 1) * g.h) - qz);
+    lb = fmaxf(lb - slack, 0.f);      // absolute slack: cell-boundary rounding
+    return lb * lb * 0.9999f;         // relative slack: rounding of the fp32 distances
+}
+
+
+// range of cells [c0, c1] along one axis that can hold points within r of coordinate v
+__device__ __forceinline__ void cell_range(float v, float r, float org, float inv_h, int dim, int& c0, int& c1) {
+    c0 = cell_coord(v - r, org, inv_h, dim);
+    c1 = cell_coord(v + r, org, inv_h, dim);
+}
+
+}  // namespace pcc

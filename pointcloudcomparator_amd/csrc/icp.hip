@@ -1,0 +1,58 @@
+// icp.hip -- the reduction ICP needs after every correspondence pass (gfx950).
+//
+// Replaces the host loop of pcl::registration::TransformationEstimationSVD::
+// estimateRigidTransformation (reached from the reference's icp.align(),
+// src/comparator.cpp:1096): PCL copies the matched pairs into two 3xN float matrices and
+// calls Eigen's umeyama(); all umeyama needs from them are sum p, sum q and sum q p^T.
+// The sums are accumulated in double (PCL/Eigen use float; compared with a tolerance,
+// SURVEY hard part 6) as one partial row per workgroup, reduced on the host in a fixed
+// order -> bitwise reproducible run to run (no float atomics).
+#include "pcc_internal.hpp"
+
+namespace pcc {
+
+__global__ void __launch_bounds__(256)
+k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long long* __restrict__ keys,
+           const float4* __restrict__ refs, double* __restrict__ partials) {
+    double acc[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = 0.0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long key = keys[i];
+        const float4 p = src[i];
+        if (key == ~0ull || __float_as_int(p.w) < 0) continue;  // no correspondence
+        const float4 t = refs[(unsigned int)(key & 0xffffffffull)];
+        const double px = p.x, py = p.y, pz = p.z, qx = t.x, qy = t.y, qz = t.z;
+        acc[0] += px; acc[1] += py; acc[2] += pz;
+        acc[3] += qx; acc[4] += qy; acc[5] += qz;
+        acc[6] += qx * px; acc[7] += qx * py; acc[8] += qx * pz;
+        acc[9] += qy * px; acc[10] += qy * py; acc[11] += qy * pz;
+        acc[12] += qz * px; acc[13] += qz * py; acc[14] += qz * pz;
+        acc[15] += (double)__uint_as_float((unsigned int)(key >> 32));
+        acc[16] += 1.0;
+    }
+    __shared__ double red[4][17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17)
+        partials[(size_t)blockIdx.x * 17 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
+                    const float4* refs, double* partials, int* n_blocks) {
+    size_t b = (n + 256 * 8 - 1) / (256 * 8);
+    if (b < 1) b = 1;
+    if (b > ICP_MAX_BLOCKS) b = ICP_MAX_BLOCKS;
+    *n_blocks = (int)b;
+    hipLaunchKernelGGL(k_icp_sums, dim3((unsigned)b), dim3(256), 0, s, src, (unsigned int)n, keys, refs, partials);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+}  // namespace pcc

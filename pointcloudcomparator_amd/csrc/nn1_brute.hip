@@ -145,7 +145,7 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
         unsigned int widx = 0xffffffffu;
         if (bchunk[k] < 0) {
             // every distance overflowed to +inf: the oracle keeps the first reference
-            widx = (unsigned int)__float_as_int(refs[rbeg].w);
+            widx = rbeg;
         } else {
             unsigned int base = rbeg + (unsigned int)bchunk[k] * BR_CH;
             for (int j = 0; j < BR_CH; ++j) {
@@ -153,7 +153,7 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
                 if (p >= rend) break;
                 float4 r = refs[p];
                 if (dist2(qx[k], qy[k], qz[k], r) == best[k]) {
-                    widx = (unsigned int)__float_as_int(r.w);
+                    widx = p;  // packed position; positions ascend with the original index
                     break;
                 }
             }

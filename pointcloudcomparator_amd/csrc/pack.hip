@@ -239,21 +239,24 @@ int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
 }
 
 // ---- unpack -------------------------------------------------------------------------
+// search keys hold (d2 bits << 32 | packed position); positions map to ORIGINAL indices through
+// refs[pos].w (PCL's index_mapping_), which is the identity when no point was dropped.
 __global__ void __launch_bounds__(256)
 k_unpack(const unsigned long long* __restrict__ packed, const float4* __restrict__ q, size_t n,
-         int32_t* __restrict__ idx, float* __restrict__ d2) {
+         const float4* __restrict__ refs, int identity, int32_t* __restrict__ idx, float* __restrict__ d2) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         unsigned long long p = packed[i];
-        bool ok = __float_as_int(q[i].w) >= 0 && p != ~0ull;
-        if (idx) idx[i] = ok ? (int32_t)(unsigned int)(p & 0xffffffffull) : -1;
+        bool ok = (!q || __float_as_int(q[i].w) >= 0) && p != ~0ull;
+        unsigned int pos = (unsigned int)(p & 0xffffffffull);
+        if (idx) idx[i] = ok ? (identity ? (int32_t)pos : __float_as_int(refs[pos].w)) : -1;
         if (d2) d2[i] = ok ? __uint_as_float((unsigned int)(p >> 32)) : __builtin_inff();
     }
 }
 int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
-                  int32_t* idx, float* d2) {
+                  const float4* refs, bool identity, int32_t* idx, float* d2) {
     if (n == 0) return PCC_OK;
-    hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, s, packed, q, n, idx, d2);
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, s, packed, q, n, refs, identity ? 1 : 0, idx, d2);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
@@ -285,6 +288,40 @@ int launch_transform(hipStream_t s, const float* Tdev, const float T[16], const 
     for (int k = 0; k < 12; ++k) M.m[k] = T ? T[k] : 0.f;
     hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 256)), dim3(256), 0, s, M, Tdev, (const char*)src, n,
                        sstride, (char*)dst, dstride);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+
+__global__ void __launch_bounds__(256)
+k_copy_w(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i].w = src[i].w;
+}
+int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n) {
+    if (n == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_copy_w, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+// pcl::StatisticalOutlierRemoval::applyFilterIndices inner loop: neighbour 0 is the
+// point itself; dist_sum (double) += sqrt(d2_j) for j = 1..mean_k; distances[i] = float(dist_sum / mean_k)
+__global__ void __launch_bounds__(256)
+k_sor_mean(const unsigned long long* __restrict__ keys, const float4* __restrict__ refs, size_t n, int K,
+           float* __restrict__ mean_dist) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long* row = keys + i * (size_t)K;
+        if (row[K - 1] == ~0ull) continue;  // fewer than K neighbours: distance stays 0
+        double s = 0.0;
+        for (int j = 1; j < K; ++j) s += sqrt((double)__uint_as_float((unsigned int)(row[j] >> 32)));
+        mean_dist[__float_as_int(refs[i].w)] = (float)(s / (double)(K - 1));
+    }
+}
+int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
+                    float* mean_dist) {
+    if (n == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_sor_mean, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, refs, n, K, mean_dist);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -45,6 +45,7 @@ struct GridParams {
     int ncells;
 };
 
+
 }  // namespace pcc
 
 #define PCC_EV_SLOTS 64
@@ -68,7 +69,7 @@ struct pcc_index {
     pcc::DevBuf cell_start;  // uint32[ncells + 1]
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
-        scratch_c, scratch_d, scratch_e, small, blk_stats;
+        scratch_c, scratch_d, scratch_e, small, blk_stats, icp_src;
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
@@ -109,11 +110,18 @@ int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
 // exclusive scan of uint32 data[n] in place; data[n] receives the total when
 // write_total.  tmp is grown as needed.
 int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
-// packed u64 (d2 bits << 32 | idx) -> idx, d2; queries flagged invalid (w < 0) get -1/+inf
-int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q,
-                  size_t n, int32_t* idx, float* d2);
+// packed u64 keys (d2 bits << 32 | packed position) -> original idx, d2; n keys; q (nullable,
+// one per key) flags invalid queries (w < 0) which get -1/+inf, as do empty keys (~0)
+int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
+                  const float4* refs, bool identity, int32_t* idx, float* d2);
 int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[16],
                      const void* src, size_t n, size_t sstride, void* dst, size_t dstride);
+// dst[i].w = src[i].w (validity flags of packed points)
+int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n);
+// SOR: mean_dist[orig(i)] = float(sum_{j=1..K-1} sqrt(double(d2_j)) / (K-1)) from the K-NN keys of
+// the self query; rows with fewer than K neighbours keep 0
+int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
+                    float* mean_dist);
 
 // ---- exhaustive engine (nn1_brute.hip) -------------------------------------------
 // For every query q[i] (float4, w<0 = invalid) min over refs[0..m) of the unfused
@@ -123,5 +131,27 @@ int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[
 int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* q,
                      size_t n, unsigned long long* out, const unsigned int* qlist,
                      const unsigned int* qcount_dev, size_t qcount_max);
+
+// ---- grid.hip --------------------------------------------------------------------------
+int grid_build(pcc_index* ix, const float lo[3], const float hi[3]);
+int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out);
+// sort queries by reference-grid cell: order[0..*n_sorted) (device) lists the valid queries
+int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
+                      unsigned int** n_sorted_dev);
+float grid_slack(const GridParams& g);
+// ---- knn.hip: k-NN, radius search (GRID engine) ----------------------------------------
+// keys[nq][K] (pre-set to ~0) receive the K smallest (d2, position) keys ascending
+int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys);
+// counts[i] = #refs with d2 < r2; with fill != 0 also writes keys at offsets[i]..
+int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
+                const int64_t* offsets, unsigned long long* keys, int sorted);
+// ---- cluster.hip ------------------------------------------------------------------------
+int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t max_size,
+                  int32_t* labels_dev /* n_orig, device */, int32_t* n_clusters, int32_t* sizes, int max_sizes);
+// ---- icp.hip -----------------------------------------------------------------------------
+// per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
+int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
+                    const float4* refs, double* partials, int* n_blocks);
+constexpr int ICP_MAX_BLOCKS = 512;
 
 }  // namespace pcc
