@@ -100,9 +100,10 @@ def _check(status: int) -> None:
 
 
 def device_count() -> int:
+    """number of HIP devices; 0 when the runtime reports none (no exception)."""
     n = C.c_int(0)
-    _check(LIB.pcc_device_count(C.byref(n)))
-    return n.value
+    st = LIB.pcc_device_count(C.byref(n))
+    return n.value if st == 0 else 0
 
 
 def _is_torch(x) -> bool:

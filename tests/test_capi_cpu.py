@@ -1,0 +1,63 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/pcc_nn.h declares, and
+fails loudly (never falls back to a CPU path) when no GPU is present."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "pcc_nn.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from pointcloudcomparator_amd import capi
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(capi.LIB, name), f"{name} declared in pcc_nn.h but not exported"
+    assert sorted(capi.SYMBOLS) == declared
+
+
+def test_version_and_error_string():
+    from pointcloudcomparator_amd import capi
+    assert capi.LIB.pcc_version() == 100
+    assert isinstance(capi.LIB.pcc_last_error(), bytes)
+
+
+def test_argument_validation_needs_no_gpu():
+    from pointcloudcomparator_amd import capi
+    pts = np.zeros((4, 3), np.float32)
+    h = ctypes.c_void_p()
+    L = capi.LIB
+    assert L.pcc_index_create(pts.ctypes.data, 4, 12, 5, 0, 0, 0, ctypes.byref(h)) == -5   # dim != 3
+    assert L.pcc_index_create(pts.ctypes.data, 4, 10, 3, 0, 0, 0, ctypes.byref(h)) == -1   # bad stride
+    assert L.pcc_index_create(pts.ctypes.data, 0, 12, 3, 0, 0, 0, ctypes.byref(h)) == -2   # empty cloud
+    assert L.pcc_index_create(None, 4, 12, 3, 0, 0, 0, ctypes.byref(h)) == -1              # null points
+    assert b"empty input cloud" in L.pcc_last_error() or b"null" in L.pcc_last_error()
+    assert L.pcc_nn1(None, pts.ctypes.data, 4, 12, 0, None, None) == -1                     # null index
+
+
+def test_no_cpu_fallback_without_device():
+    from pointcloudcomparator_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.PccError) as e:
+        capi.Index(np.zeros((10, 3), np.float32))
+    assert e.value.status == -3 and "no CPU path" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    for f in (ROOT / "pointcloudcomparator_amd").rglob("*"):
+        if f.suffix in {".py", ".hip", ".hpp", ".cpp", ".h"}:
+            t = f.read_text()
+            assert "import oracle" not in t and "pcc_oracle" not in t and "orc_" not in t, f
+    for f in (ROOT / "include").rglob("*"):
+        if f.is_file():
+            assert "orc_" not in f.read_text(), f

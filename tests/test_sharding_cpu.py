@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the query-sharding path on CPU: broadcast of the reference cloud,
+contiguous shards, gathered results == unsharded results.  The search itself is the oracle
+here (the GPU library has no CPU path); what is under test is the N>1 plumbing bench.py uses."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from pointcloudcomparator_amd import sharding, synth  # noqa: E402
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_ref, n_q = 3000, 2501
+    ref = torch.from_numpy(synth.corridor_cloud(n_ref, synth.SEED_A)) if rank == 0 else torch.zeros((n_ref, 3))
+    sharding.broadcast_cloud(ref, dist, src=0)
+    qry = synth.corridor_cloud(n_q, synth.SEED_B)
+    tree = oracle.KdTree(ref.numpy())
+    start, idx, d2 = sharding.sharded_search(lambda s: tree.nn1_batch(s), qry, rank, world)
+    gi, gd = sharding.gather_shards(idx, d2, n_q, dist)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the bench's max-over-ranks timing reduction
+    if rank == 0:
+        fi, fd = oracle.KdTree(synth.corridor_cloud(n_ref, synth.SEED_A)).nn1_batch(qry)
+        q.put(((gi.numpy() == fi).all() and (gd.numpy().view(np.uint32) == fd.view(np.uint32)).all(), float(t.item()), start))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_search_matches_unsharded():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, tmax, start0 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and tmax == 2.0 and start0 == 0
