@@ -11,11 +11,12 @@ LIBDIR     := pointcloudcomparator_amd/lib
 HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip)
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 
-all: lib oracle
+all: lib oracle hosttest
 
 lib: $(LIBDIR)/libpcc_nn.so
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu
+hosttest: build/test_host_mirror
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp include/pcc_nn.h
 	@mkdir -p build
@@ -33,7 +34,11 @@ build/ubench_valu: $(CSRC)/ubench_valu.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
+build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/_build
 
-.PHONY: all lib oracle ubench clean
+.PHONY: all lib oracle ubench hosttest clean

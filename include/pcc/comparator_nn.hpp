@@ -1,0 +1,159 @@
+// comparator_nn.hpp -- host-side mirror of the reference's functions and PCL algorithm objects
+// that sit on the nearest-neighbour path, re-hosted on libpcc_nn (same names, argument meaning,
+// printed lines and error behaviour):
+//   matchRIFTFeaturesKnn            reference src/comparator.cpp:560-588
+//   performICP                      reference src/comparator.cpp:1089-1110
+//   IterativeClosestPoint           the PCL object performICP drives (:1091-1099)
+//   StatisticalOutlierRemoval       the -n noise pass (:1520-1549)
+//   EuclideanClusterExtraction      the -e path (src/segmentation.cpp:119-131)
+// Everything numerical happens behind the C-ABI; this header is plumbing a maintainer of the
+// reference can include instead of the PCL headers for these five call sites.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cfloat>
+#include <iostream>
+#include "pcc/search.hpp"
+
+namespace pcc {
+
+typedef Histogram<32> RIFT32;  // reference src/comparator.cpp:9
+
+// ---- matchRIFTFeaturesKnn (src/comparator.cpp:560-588) --------------------------------------
+// Tree on descriptors1, one k=1 query per element of descriptors2, match kept when
+// neighborCount == 1 && d2 < 0.05f.  The returned vector STARTS WITH ONE DUMMY 0 (:568), so
+// size() == matches + 1 -- callers divide size() by descriptor counts (:1336-1338).
+inline std::vector<int> matchRIFTFeaturesKnn(const PointCloud<RIFT32>::Ptr& descriptors1,
+                                             const PointCloud<RIFT32>::Ptr& descriptors2) {
+    std::vector<int> correspondence(1);
+    KdTreeFLANN<RIFT32> matching;  // `= new KdTreeFLANN<RIFT32>(false)` in the reference: sorted == true
+    matching.setInputCloud(descriptors1);
+    if (!matching.handle() || !descriptors2 || descriptors2->empty()) return correspondence;
+    std::vector<int> out(descriptors2->size() + 1);
+    int32_t n = 0;
+    check(pcc_match_knn(matching.handle(), descriptors2->points.data(), descriptors2->size(), sizeof(RIFT32),
+                        PCC_MEM_HOST, 0.05f, out.data(), &n));
+    out.resize(n);
+    return out;
+}
+
+// ---- pcl::IterativeClosestPoint ---------------------------------------------------------------
+template <class PointSource, class PointTarget>
+class IterativeClosestPoint {
+public:
+    typedef std::array<float, 16> Matrix4;  // row-major 4x4
+    void setMaximumIterations(int n) { max_iterations_ = n; }
+    void setInputSource(const typename PointCloud<PointSource>::ConstPtr& c) { source_ = c; }
+    void setInputTarget(const typename PointCloud<PointTarget>::ConstPtr& c) { target_ = c; tree_.setInputCloud(c); }
+    // align: the ICP loop with PCL's defaults (no distance threshold, SVD/Umeyama estimate,
+    // DefaultConvergenceCriteria: iteration cap or |mse - prev| < 1e-12); output = transformed source
+    void align(PointCloud<PointSource>& output) {
+        converged_ = false;
+        final_ = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        fitness_ = DBL_MAX;
+        output = *source_;
+        if (!tree_.handle() || source_->empty()) return;
+        int conv = 0, it = 0;
+        check(pcc_icp_align(tree_.handle(), source_->points.data(), source_->size(), sizeof(PointSource), PCC_MEM_HOST,
+                            max_iterations_, 0, final_.data(), &fitness_, &it, &conv));
+        converged_ = conv != 0;
+        iterations_ = it;
+        check(pcc_transform(tree_.handle(), final_.data(), source_->points.data(), source_->size(), sizeof(PointSource),
+                            output.points.data(), sizeof(PointSource), PCC_MEM_HOST));
+    }
+    bool hasConverged() const { return converged_; }
+    double getFitnessScore() const { return fitness_; }
+    Matrix4 getFinalTransformation() const { return final_; }
+    int getIterations() const { return iterations_; }
+
+private:
+    int max_iterations_ = 10;  // PCL default; the reference sets 20
+    int iterations_ = 0;
+    bool converged_ = false;
+    double fitness_ = DBL_MAX;
+    Matrix4 final_{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+    typename PointCloud<PointSource>::ConstPtr source_;
+    typename PointCloud<PointTarget>::ConstPtr target_;
+    search::KdTree<PointTarget> tree_;
+};
+
+// ---- performICP (src/comparator.cpp:1089-1110), same printed lines ----------------------------
+inline bool performICP(const PointCloud<PointXYZRGB>::Ptr& point_cloud1, const PointCloud<PointXYZRGB>::Ptr& point_cloud2) {
+    IterativeClosestPoint<PointXYZRGB, PointXYZRGB> icp;
+    icp.setMaximumIterations(20);
+    icp.setInputSource(point_cloud1);
+    icp.setInputTarget(point_cloud2);
+    PointCloud<PointXYZRGB> Final;
+    icp.align(Final);
+    std::cout << "has converged:" << icp.hasConverged() << " ICP fitness score: " << icp.getFitnessScore() << std::endl;
+    if (icp.hasConverged() == 1)
+        std::cout << "ICP has converged; starting comparison of point clouds" << std::endl;
+    else
+        std::cout << "ICP has not converged; point clouds too much different to perform a specific comparison" << std::endl;
+    return icp.hasConverged() == 1;
+}
+
+// ---- pcl::StatisticalOutlierRemoval (src/comparator.cpp:1523-1527) ---------------------------------
+template <class PointT>
+class StatisticalOutlierRemoval {
+public:
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    void setMeanK(int k) { mean_k_ = k; }
+    void setStddevMulThresh(double m) { std_mul_ = m; }
+    void filter(PointCloud<PointT>& output) {
+        output.points.clear();
+        if (!input_ || input_->empty()) return;
+        search::KdTree<PointT> tree(false);
+        tree.setInputCloud(input_);
+        if (!tree.handle()) return;
+        std::vector<std::uint8_t> inlier(input_->size());
+        size_t kept = 0;
+        check(pcc_sor(tree.handle(), mean_k_, std_mul_, PCC_MEM_HOST, nullptr, inlier.data(), &threshold_, &kept));
+        output.points.reserve(kept);
+        for (size_t i = 0; i < input_->size(); ++i)
+            if (inlier[i]) output.points.push_back(input_->points[i]);
+        output.width = (std::uint32_t)output.points.size();
+        output.height = 1;
+    }
+    double getThreshold() const { return threshold_; }
+
+private:
+    typename PointCloud<PointT>::ConstPtr input_;
+    int mean_k_ = 1;
+    double std_mul_ = 0.0, threshold_ = 0.0;
+};
+
+// ---- pcl::EuclideanClusterExtraction (src/segmentation.cpp:125-131) ------------------------------------
+template <class PointT>
+class EuclideanClusterExtraction {
+public:
+    void setClusterTolerance(double t) { tolerance_ = t; }
+    void setMinClusterSize(int n) { min_ = n; }
+    void setMaxClusterSize(int n) { max_ = n; }
+    void setSearchMethod(const typename search::KdTree<PointT>::Ptr& tree) { tree_ = tree; }
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    // PCL re-runs tree_->setInputCloud(input_) inside extract; an index already
+    // built on the same cloud is reused here.
+    void extract(std::vector<PointIndices>& clusters) {
+        clusters.clear();
+        if (!input_ || input_->empty()) return;
+        if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
+        if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
+        if (!tree_->handle()) return;
+        std::vector<int32_t> labels(input_->size());
+        int32_t ncl = 0;
+        check(pcc_euclidean_clusters(tree_->handle(), tolerance_, (uint32_t)min_, (uint32_t)max_, PCC_MEM_HOST,
+                                     labels.data(), &ncl, nullptr, 0));
+        clusters.resize(ncl);
+        for (size_t i = 0; i < labels.size(); ++i)  // ascending i == PCL's sorted indices per cluster
+            if (labels[i] >= 0) clusters[labels[i]].indices.push_back((int)i);
+    }
+
+private:
+    double tolerance_ = 0.0;
+    int min_ = 1, max_ = 0x7fffffff;
+    typename search::KdTree<PointT>::Ptr tree_;
+    typename PointCloud<PointT>::ConstPtr input_;
+};
+
+}  // namespace pcc

@@ -1,0 +1,115 @@
+// search.hpp -- pcc::search::KdTree<PointT> / pcc::KdTreeFLANN<PointT>: the PCL-shaped search
+// object the reference constructs (src/comparator.cpp:564-577 pcl::KdTreeFLANN<RIFT32>;
+// src/segmentation.cpp:120-122,129 pcl::search::KdTree<pcl::PointXYZRGB> injected with
+// setSearchMethod).  Same method names, argument meaning and return conventions
+// (SURVEY.md 8b): returns the number of neighbours found, distances are squared, indices
+// refer to the original cloud, k is clamped to the number of valid points.  Header-only on
+// top of the C-ABI (include/pcc_nn.h); the per-point methods are batches of one for
+// compatibility, callers that care about speed use the *Batch methods.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "pcc_nn.h"
+#include "pcc/point_types.hpp"
+
+namespace pcc {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const char* what) : std::runtime_error(std::string("libpcc_nn: ") + what), status(s) {}
+};
+inline void check(int status) {
+    if (status != PCC_OK) throw Error(status, pcc_last_error());
+}
+
+namespace search {
+
+template <class PointT>
+class KdTree {
+public:
+    typedef typename PointCloud<PointT>::ConstPtr CloudConstPtr;
+    typedef std::shared_ptr<KdTree<PointT>> Ptr;
+
+    // pcl::KdTreeFLANN(bool sorted = true); the reference writes `= new KdTreeFLANN<T>(false)`,
+    // a pointer-to-bool conversion that yields sorted == TRUE
+    explicit KdTree(bool sorted = true, int device = 0, int engine = PCC_ENGINE_AUTO)
+        : sorted_(sorted), device_(device), engine_(engine) {}
+    ~KdTree() { if (index_) pcc_index_destroy(index_); }
+    KdTree(const KdTree&) = delete;
+    KdTree& operator=(const KdTree&) = delete;
+
+    // PCL prints "Cannot create a KDTree with an empty input cloud" and returns; so do we.
+    void setInputCloud(const CloudConstPtr& cloud) {
+        input_ = cloud;
+        if (index_) { pcc_index_destroy(index_); index_ = nullptr; }
+        if (!cloud || cloud->empty()) return;
+        int st = pcc_index_create(cloud->points.data(), cloud->size(), sizeof(PointT), 3, PCC_MEM_HOST, device_,
+                                  engine_, &index_);
+        if (st == PCC_ERR_EMPTY) { index_ = nullptr; return; }
+        check(st);
+    }
+    CloudConstPtr getInputCloud() const { return input_; }
+    bool getSortedResults() const { return sorted_; }
+    pcc_index* handle() const { return index_; }
+
+    int nearestKSearch(const PointT& p, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const {
+        if (!index_ || !isFinite(p)) { k_indices.clear(); k_sqr_distances.clear(); return 0; }  // PCL asserts here
+        size_t total = 0;
+        check(pcc_index_size(index_, &total));
+        if ((size_t)k > total) k = (int)total;
+        k_indices.resize(k);
+        k_sqr_distances.resize(k);
+        if (k == 0) return 0;
+        if (k == 1) check(pcc_nn1(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, k_indices.data(), k_sqr_distances.data()));
+        else check(pcc_knn(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, k, k_indices.data(), k_sqr_distances.data()));
+        return k;
+    }
+    int nearestKSearch(int index, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const {
+        return nearestKSearch(input_->points.at(index), k, k_indices, k_sqr_distances);
+    }
+    int radiusSearch(const PointT& p, double radius, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances,
+                     unsigned int max_nn = 0) const {
+        k_indices.clear();
+        k_sqr_distances.clear();
+        if (!index_ || !isFinite(p)) return 0;
+        int32_t cnt = 0;
+        check(pcc_radius_count(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, &cnt));
+        if (cnt == 0) return 0;
+        int64_t offs[2] = {0, cnt};
+        k_indices.resize(cnt);
+        k_sqr_distances.resize(cnt);
+        // max_nn != 0 truncates the SORTED list (FLANN keeps the max_nn nearest)
+        check(pcc_radius_fill(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, (sorted_ || max_nn) ? 1 : 0, offs,
+                              k_indices.data(), k_sqr_distances.data()));
+        if (max_nn && (unsigned)cnt > max_nn) { k_indices.resize(max_nn); k_sqr_distances.resize(max_nn); cnt = (int32_t)max_nn; }
+        return cnt;
+    }
+
+    // ---- batch forms: what a GPU wants (one call for the whole query cloud) ----
+    void nearestKSearchBatch(const PointCloud<PointT>& queries, std::vector<int>& idx, std::vector<float>& d2) const {
+        idx.assign(queries.size(), -1);
+        d2.assign(queries.size(), 0.f);
+        if (!index_ || queries.empty()) return;
+        check(pcc_nn1(index_, queries.points.data(), queries.size(), sizeof(PointT), PCC_MEM_HOST, idx.data(), d2.data()));
+    }
+    void nearestKSearchBatch(const PointCloud<PointT>& queries, int k, std::vector<int>& idx, std::vector<float>& d2) const {
+        idx.assign(queries.size() * (size_t)k, -1);
+        d2.assign(queries.size() * (size_t)k, 0.f);
+        if (!index_ || queries.empty()) return;
+        check(pcc_knn(index_, queries.points.data(), queries.size(), sizeof(PointT), PCC_MEM_HOST, k, idx.data(), d2.data()));
+    }
+
+private:
+    bool sorted_;
+    int device_, engine_;
+    CloudConstPtr input_;
+    pcc_index* index_ = nullptr;
+};
+
+}  // namespace search
+
+template <class PointT>
+using KdTreeFLANN = search::KdTree<PointT>;
+
+}  // namespace pcc

@@ -14,7 +14,7 @@ import numpy as np
 
 MEM_HOST, MEM_DEVICE = 0, 1
 ENGINE_AUTO, ENGINE_BRUTE, ENGINE_GRID = 0, 1, 2
-KNN_MAX_K = 128
+KNN_MAX_K = 65536
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PCC_LIB", _HERE / "lib" / "libpcc_nn.so"))

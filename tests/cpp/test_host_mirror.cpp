@@ -1,0 +1,86 @@
+// test_host_mirror.cpp -- the C++ host mirror (include/pcc/*.hpp) exercised the way the
+// reference's call sites use PCL: matchRIFTFeaturesKnn, performICP, SOR, EuclideanClusterExtraction,
+// per-point KdTree calls.  Checks are self-consistency properties (the bit-level parity against the
+// oracle lives in the Python GPU tests, through the same C-ABI).  Exit code 0 = pass, 77 = no GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include "pcc/comparator_nn.hpp"
+
+using namespace pcc;
+
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static float brute_d2(const PointXYZRGB& a, const PointXYZRGB& b) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    float d = dx * dx; d = d + dy * dy; d = d + dz * dz;
+    return d;
+}
+
+int main() {
+    int ndev = 0;
+    if (pcc_device_count(&ndev) != PCC_OK || ndev == 0) { std::printf("no HIP device: skipped\n"); return 77; }
+    std::mt19937 rng(42);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+
+    // clouds: three blobs of 400 points + 50 stragglers
+    PointCloud<PointXYZRGB>::Ptr cloud(new PointCloud<PointXYZRGB>);
+    const float centres[3][3] = {{0, 0, 0}, {2, 0, 0}, {0, 2, 1}};
+    for (int b = 0; b < 3; ++b)
+        for (int i = 0; i < 400; ++i) {
+            PointXYZRGB p;
+            p.x = centres[b][0] + 0.1f * U(rng); p.y = centres[b][1] + 0.1f * U(rng); p.z = centres[b][2] + 0.1f * U(rng);
+            cloud->push_back(p);
+        }
+    for (int i = 0; i < 50; ++i) { PointXYZRGB p; p.x = 5 + 3 * U(rng); p.y = 5 + 3 * U(rng); p.z = 3 * U(rng); cloud->push_back(p); }
+
+    // per-point KdTree calls (src/comparator.cpp:571-577 shape)
+    search::KdTree<PointXYZRGB>::Ptr tree(new search::KdTree<PointXYZRGB>);
+    tree->setInputCloud(cloud);
+    std::vector<int> idx; std::vector<float> d2;
+    REQUIRE(tree->nearestKSearch(cloud->points[7], 1, idx, d2) == 1 && idx[0] == 7 && d2[0] == 0.f);
+    REQUIRE(tree->nearestKSearch(7, 5, idx, d2) == 5 && idx[0] == 7);
+    for (int j = 1; j < 5; ++j) REQUIRE(d2[j] >= d2[j - 1] && d2[j] == brute_d2(cloud->points[7], cloud->points[idx[j]]));
+    int nr = tree->radiusSearch(cloud->points[7], 0.05, idx, d2);
+    REQUIRE(nr >= 1 && idx[0] == 7);
+    int cnt = 0;
+    for (auto& p : cloud->points) cnt += brute_d2(cloud->points[7], p) < (float)(0.05 * 0.05);
+    REQUIRE(cnt == nr);
+    REQUIRE(tree->nearestKSearch(cloud->points[0], 5000, idx, d2) == (int)cloud->size());  // k clamped
+
+    // EuclideanClusterExtraction (src/segmentation.cpp:125-131)
+    EuclideanClusterExtraction<PointXYZRGB> ec;
+    ec.setClusterTolerance(0.05); ec.setMinClusterSize(100); ec.setMaxClusterSize(250000);
+    ec.setSearchMethod(tree); ec.setInputCloud(cloud);
+    std::vector<PointIndices> clusters;
+    ec.extract(clusters);
+    REQUIRE(clusters.size() == 3);
+    for (auto& c : clusters) { REQUIRE(c.indices.size() == 400); REQUIRE(std::is_sorted(c.indices.begin(), c.indices.end())); }
+
+    // StatisticalOutlierRemoval (src/comparator.cpp:1523-1527)
+    StatisticalOutlierRemoval<PointXYZRGB> sor;
+    PointCloud<PointXYZRGB> filtered;
+    sor.setInputCloud(cloud); sor.setMeanK(50); sor.setStddevMulThresh(1.5); sor.filter(filtered);
+    REQUIRE(filtered.size() < cloud->size() && filtered.size() >= 1200);  // stragglers are the outliers
+
+    // performICP (src/comparator.cpp:1089-1110): cloud2 = cloud1 shifted slightly
+    PointCloud<PointXYZRGB>::Ptr moved(new PointCloud<PointXYZRGB>(*cloud));
+    for (auto& p : moved->points) { p.x += 0.01f; p.y -= 0.005f; }
+    REQUIRE(performICP(moved, cloud));
+
+    // matchRIFTFeaturesKnn (src/comparator.cpp:560-588): identical descriptor sets match 1:1
+    PointCloud<RIFT32>::Ptr d1(new PointCloud<RIFT32>), dd(new PointCloud<RIFT32>);
+    for (int i = 0; i < 300; ++i) { RIFT32 h; for (float& v : h.histogram) v = U(rng); d1->push_back(h); }
+    *dd = *d1;
+    std::vector<int> m = matchRIFTFeaturesKnn(d1, dd);
+    REQUIRE(m.size() == 301 && m[0] == 0);
+    for (int i = 0; i < 300; ++i) {
+        // duplicates in the first three bins aside, element i matches itself
+        const float* a = d1->points[i].histogram; const float* b = d1->points[m[i + 1]].histogram;
+        REQUIRE(a[0] == b[0] && a[1] == b[1] && a[2] == b[2]);
+    }
+    PointCloud<RIFT32>::Ptr empty(new PointCloud<RIFT32>);
+    REQUIRE(matchRIFTFeaturesKnn(empty, dd).size() == 1);  // empty tree: only the dummy element
+    std::printf("host mirror ok\n");
+    return 0;
+}
