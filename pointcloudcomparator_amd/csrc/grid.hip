@@ -143,24 +143,47 @@ __device__ __forceinline__ unsigned long long fold(unsigned long long best, floa
 // scan the contiguous span [s, e) of cell-sorted references.  Four independent 16-byte loads
 // are in flight per lane (the loop is latency-bound otherwise); the tail re-reads the last
 // point of the span, which cannot change the minimum.
+template <int U>
 __device__ __forceinline__ unsigned long long scan_span(const float4* __restrict__ cell_refs, unsigned int s,
                                                         unsigned int e, float qx, float qy, float qz,
                                                         unsigned long long best) {
     if (s >= e) return best;
     const unsigned int last = e - 1;
-    for (unsigned int p = s; p < e; p += 4) {
-        const float4 r0 = cell_refs[p];
-        const float4 r1 = cell_refs[min(p + 1, last)];
-        const float4 r2 = cell_refs[min(p + 2, last)];
-        const float4 r3 = cell_refs[min(p + 3, last)];
-        best = fold(best, qx, qy, qz, r0);
-        best = fold(best, qx, qy, qz, r1);
-        best = fold(best, qx, qy, qz, r2);
-        best = fold(best, qx, qy, qz, r3);
+    for (unsigned int p = s; p < e; p += U) {
+        float4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = cell_refs[min(p + u, last)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) best = fold(best, qx, qy, qz, r[u]);
     }
     return best;
 }
 
+// scan every row of the cell box; row bounds are fetched four rows at a time (8 independent
+// loads) before the spans are streamed, instead of paying two dependent latencies per row
+template <int U>
+__device__ __forceinline__ unsigned long long scan_box(const float4* __restrict__ cell_refs,
+                                                       const unsigned int* __restrict__ cell_start, const GridParams& g,
+                                                       int x0, int x1, int y0, int y1, int z0, int z1, float qx, float qy,
+                                                       float qz, unsigned long long best) {
+    for (int z = z0; z <= z1; ++z) {
+        for (int yb = y0; yb <= y1; yb += 4) {
+            unsigned int rs[4], re[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = yb + i <= y1;
+                const unsigned int row = ((unsigned int)z * g.dim[1] + (ok ? yb + i : yb)) * g.dim[0];
+                rs[i] = ok ? cell_start[row + x0] : 0u;
+                re[i] = ok ? cell_start[row + x1 + 1] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) best = scan_span<U>(cell_refs, rs[i], re[i], qx, qy, qz, best);
+        }
+    }
+    return best;
+}
+
+template <int U>
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
            float slack, const float4* __restrict__ q, const unsigned int* __restrict__ order,
@@ -179,10 +202,9 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
-    int k = 1;
+    // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (18 independent loads, one
+    // latency), then the rows are streamed.
     {
-        // k = 1 fast path: fetch the bounds of all 9 rows first (18 independent loads, one
-        // latency), then stream the rows
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
         unsigned int rs[9], re[9];
 #pragma unroll
@@ -194,40 +216,42 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
             re[i] = ok ? cell_start[row + x1 + 1] : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) best = scan_span(cell_refs, rs[i], re[i], qx, qy, qz, best);
+        for (int i = 0; i < 9; ++i) best = scan_span<U>(cell_refs, rs[i], re[i], qx, qy, qz, best);
         const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
         const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
         const float bd = __uint_as_float((unsigned int)(best >> 32));
         const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
         if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
     }
-    while (!resolved) {
-        // grow the cube: straight to the half-width whose faces clear the current best, or
-        // double it while nothing has been found
-        const float bd = __uint_as_float((unsigned int)(best >> 32));
-        int kn = 2 * k;
-        if (best != ~0ull) {
-            const float need = sqrtf(bd) * g.inv_h;
-            kn = need < (float)GRID_KMAX ? (int)need + 1 : GRID_KMAX + 1;
-            kn = max(kn, k + 1);
-            if (kn > GRID_KMAX) break;  // beyond KMAX: exhaustive fallback
-        } else if (kn > GRID_KMAX) {
-            if (k >= GRID_KMAX) break;
-            kn = GRID_KMAX;
+    if (!resolved) {
+        // ---- phase 1b: nothing within the 3x3x3 cube -> double the cube until a point shows up
+        bool give_up = false;
+        int k = 1;
+        while (best == ~0ull) {
+            if (k >= GRID_KMAX) { give_up = true; break; }
+            k = min(2 * k, GRID_KMAX);
+            const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+            const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+            const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+            best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
         }
-        k = kn;
-        const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
-        const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
-        const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
-        for (int z = z0; z <= z1; ++z) {
-            for (int y = y0; y <= y1; ++y) {
-                const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
-                best = scan_span(cell_refs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best);
+        // ---- phase 2: cover the ball of radius sqrt(best) -- every cell a closer (or equal,
+        // lower-index) point could live in.  Usually one extra slab of cells on one or two sides,
+        // far fewer rows than the next bigger cube.  Exact by construction: no bound test after it.
+        if (!give_up) {
+            const float rb = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
+            int x0, x1, y0, y1, z0, z1;
+            cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
+            cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
+            cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
+            const int span = 2 * GRID_KMAX + 1;
+            if (!(rb < __builtin_inff()) || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
+                give_up = true;  // the ball is too big for a cell walk: exhaustive fallback
+            } else {
+                best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
+                resolved = true;
             }
         }
-        const float bd2 = __uint_as_float((unsigned int)(best >> 32));
-        const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
-        if (best != ~0ull && (bd2 < lb2 || lb2 == __builtin_inff())) resolved = true;
     }
     if (resolved) {
         out[qi] = best;
@@ -285,8 +309,15 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     const float slack = grid_slack(g);
     ev_mark(ix, EV_MAIN0);
-    hipLaunchKernelGGL(k_grid_nn1, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                       ix->cell_start.as<unsigned int>(), g, slack, q, order, n_sorted, n, out, fb_list, fb_count);
+    static const int U = getenv("PCC_GRID_UNROLL") ? atoi(getenv("PCC_GRID_UNROLL")) : 4;
+    static const int BS = getenv("PCC_GRID_BLOCK") ? atoi(getenv("PCC_GRID_BLOCK")) : 256;
+#define PCC_LAUNCH_NN1(UU)                                                                                       \
+    hipLaunchKernelGGL((k_grid_nn1<UU>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),     \
+                       ix->cell_start.as<unsigned int>(), g, slack, q, order, n_sorted, n, out, fb_list, fb_count)
+    if (U == 1) PCC_LAUNCH_NN1(1);
+    else if (U == 2) PCC_LAUNCH_NN1(2);
+    else if (U == 8) PCC_LAUNCH_NN1(8);
+    else PCC_LAUNCH_NN1(4);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     // queries the cubes could not resolve: exhaustive scan over the original-order references
