@@ -145,10 +145,17 @@ def main():
 
     for _ in range(W):
         step()
-    ix.enable_timing(True)
+    # timed region: only the dominant kernel is bracketed by HIP events (2 per step, recorded by
+    # the library on its own stream into a ring, no sync); a full 10-event breakdown costs
+    # ~48 us per 0.4 ms step, so it runs in a second, untimed pass
+    ix.enable_timing(1)
     dt = timed(step, K)
-    tm = ix.timing()          # averages over the K timed steps (HIP events on the library stream)
-    ix.enable_timing(False)
+    tm_main = ix.timing()     # tm_main[0] = average k_grid_nn1 / k_nn1_brute duration over the K timed steps
+    ix.enable_timing(2)
+    timed(step, min(K, 10))
+    tm = ix.timing()
+    tm[0] = tm_main[0]
+    ix.enable_timing(0)
     stats = ix.stats()
     ms_per_step = dt / K * 1e3
     value = N * n_gpus / (dt / K)
@@ -215,11 +222,11 @@ def main():
         idx_b = torch.empty_like(idx)
         d2_b = torch.empty_like(d2)
         ix.nn1(qry, idx_b, d2_b)
-        ix.enable_timing(True)
+        ix.enable_timing(1)
         kb = 3
         dtb = timed(lambda: ix.nn1(qry, idx_b, d2_b), kb)
         tb = ix.timing()
-        ix.enable_timing(False)
+        ix.enable_timing(0)
         pairs = float(M) * N
         ach = pairs * OPS_PER_PAIR / (tb[0] * 1e-3) / 1e12
         same = bool((idx_b == idx).all().item() and (d2_b.view(torch.int32) == d2.view(torch.int32)).all().item())

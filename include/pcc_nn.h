@@ -186,6 +186,8 @@ int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
  *        ENGINE_BRUTE), ms[1] exhaustive fallback pass of the GRID engine,
  *  ms[2] whole last search call (first to last kernel), ms[3] whole last
  *  set_input/build, ms[4] query sort (GRID), ms[5..6] reserved. */
+/* on: 0 off; 1 only the main search kernel (two events per call -- what a timed region can
+ * afford: every recorded event costs a few microseconds of stream time); 2 full breakdown */
 int pcc_index_enable_timing(pcc_index *index, int on);
 int pcc_index_timing(pcc_index *index, float ms[8]);
 

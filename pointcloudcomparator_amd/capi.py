@@ -155,8 +155,10 @@ class Index:
         _check(LIB.pcc_index_set_input(self._h, ptr, n, stride, 3, mem))
         self.n_original = n
 
-    def enable_timing(self, on: bool = True):
-        _check(LIB.pcc_index_enable_timing(self._h, int(on)))
+    def enable_timing(self, level=2):
+        """0/False off, 1 main kernel only (cheap enough for a timed region), 2/True full breakdown"""
+        level = 2 if level is True else int(level)
+        _check(LIB.pcc_index_enable_timing(self._h, level))
 
     def timing(self):
         """ms of the instrumented kernels of the last call (see pcc_index_timing)."""

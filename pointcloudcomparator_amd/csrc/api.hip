@@ -255,7 +255,7 @@ int pcc_index_enable_timing(pcc_index* ix, int on) {
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k) ix->ev_rec[sl][k] = false;
     ix->ev_slot = 0;
-    ix->timing = on != 0;
+    ix->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     return PCC_OK;
 }
 

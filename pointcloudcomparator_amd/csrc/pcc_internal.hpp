@@ -74,7 +74,7 @@ struct pcc_index {
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
     // ring of PCC_EV_SLOTS calls so a timed region of many steps is covered without syncing
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 main kernel only (2 events per call), 2 full breakdown
     hipEvent_t ev[PCC_EV_SLOTS][PCC_EV_KINDS] = {};
     bool ev_rec[PCC_EV_SLOTS][PCC_EV_KINDS] = {};
     unsigned int ev_slot = 0;  // slot of the call in flight
@@ -84,7 +84,7 @@ namespace pcc {
 
 enum { EV_MAIN0 = 0, EV_MAIN1, EV_FB0, EV_FB1, EV_CALL0, EV_CALL1, EV_BUILD0, EV_BUILD1, EV_SORT0, EV_SORT1 };
 inline void ev_mark(pcc_index* ix, int id) {
-    if (!ix->timing) return;
+    if (!ix->timing || (ix->timing == 1 && id > EV_MAIN1)) return;
     unsigned int s = ix->ev_slot % PCC_EV_SLOTS;
     if (ix->ev[s][id]) { (void)hipEventRecord(ix->ev[s][id], ix->stream); ix->ev_rec[s][id] = true; }
 }
