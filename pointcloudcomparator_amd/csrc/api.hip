@@ -194,7 +194,7 @@ int pcc_index_destroy(pcc_index* ix) {
     DeviceGuard g(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
-                      &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e,
+                      &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
                       &ix->small, &ix->blk_stats, &ix->icp_src};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)

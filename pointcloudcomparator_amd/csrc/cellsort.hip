@@ -1,0 +1,183 @@
+// cellsort.hip -- two-level counting sort of points by grid cell, built on LDS atomics (gfx950).
+//
+// The index build (the role of KDTreeSingleIndex::buildIndex, reference src/comparator.cpp:565)
+// and the per-call query ordering both sort points by linear cell id.  One returning
+// device-scope atomic per point is what the first version did, and that runs at the chip's
+// memory-side atomic rate: 1M scattered atomics = 47 us (1.36 TB/s of 64-byte atomic requests,
+// MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s chip-wide).  This version never issues a
+// global atomic:
+//   pass 1  k_cs_hist     each workgroup histograms its slice over B coarse buckets (bucket = F
+//                         consecutive cells) in LDS; the LDS atomic's return value is the point's
+//                         rank inside (workgroup, bucket).  Histogram rows go out bucket-major.
+//   scan                  exclusive scan of the B x G matrix -> base of every (bucket, workgroup)
+//   pass 2  k_cs_scatter  point -> base + rank: all points of one coarse bucket become contiguous
+//   pass 3  k_cs_fine     one workgroup per coarse bucket: LDS histogram over its F cells, LDS
+//                         scan (= cell_start for those cells), LDS cursor scatter to final order
+// Order inside a cell is arbitrary (LDS atomics race), which no consumer depends on: ties are
+// resolved by the explicit (d2, position) key.
+#include "pcc_internal.hpp"
+#include "grid_device.hpp"
+
+namespace pcc {
+
+constexpr int CS_T = 256;
+constexpr unsigned int CS_SLICE = 4096;    // points per workgroup in passes 1 and 2
+constexpr unsigned int CS_MAX_G = 1024;    // workgroups (slices grow beyond 4M points)
+constexpr unsigned int CS_BUCKETS = 2048;  // coarse buckets aimed for
+constexpr unsigned int CS_MAX_F = 12288;   // cells per bucket: 48 KiB of LDS counters
+
+struct CsPlan {
+    unsigned int F, B, G, slice;
+};
+static CsPlan cs_plan(unsigned int ncells, unsigned int n) {
+    CsPlan p;
+    static const unsigned int buckets = getenv("PCC_CS_BUCKETS") ? (unsigned int)atoi(getenv("PCC_CS_BUCKETS")) : CS_BUCKETS;
+    p.F = (ncells + buckets - 1) / buckets;
+    if (p.F < 64) p.F = 64;
+    if (p.F > CS_MAX_F) p.F = CS_MAX_F;
+    p.B = (ncells + p.F - 1) / p.F;
+    p.G = (n + CS_SLICE - 1) / CS_SLICE;
+    if (p.G > CS_MAX_G) p.G = CS_MAX_G;
+    if (p.G < 1) p.G = 1;
+    p.slice = (n + p.G - 1) / p.G;
+    return p;
+}
+
+// pass 1 ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CS_T)
+k_cs_hist(const float4* __restrict__ pts, unsigned int n, GridParams g, unsigned int F, unsigned int B,
+          unsigned int slice, uint2* __restrict__ key_rank, unsigned int* __restrict__ H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    for (unsigned int b = threadIdx.x; b < B; b += CS_T) lds[b] = 0;
+    __syncthreads();
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int i = beg + threadIdx.x; i < end; i += CS_T) {
+        const float4 v = pts[i];
+        if (__float_as_int(v.w) < 0) { key_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // invalid query
+        const unsigned int c = cell_id(v, g);
+        key_rank[i] = make_uint2(c, atomicAdd(&lds[c / F], 1u));
+    }
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < B; b += CS_T) H[(size_t)b * gridDim.x + blockIdx.x] = lds[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)B * gridDim.x] = 0;  // slot for the grand total
+}
+
+// pass 2 ---------------------------------------------------------------------------------------
+// REFS: move the point (w := its position in the packed array) and its key.  Queries: key + index.
+template <bool REFS>
+__global__ void __launch_bounds__(CS_T)
+k_cs_scatter(const float4* __restrict__ pts, unsigned int n, unsigned int F, unsigned int slice,
+             const uint2* __restrict__ key_rank, const unsigned int* __restrict__ H,
+             float4* __restrict__ tmp_pts, uint2* __restrict__ tmp_kv) {
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int i = beg + threadIdx.x; i < end; i += CS_T) {
+        const uint2 kr = key_rank[i];
+        if (kr.x == 0xffffffffu) continue;
+        const unsigned int dst = H[(size_t)(kr.x / F) * gridDim.x + blockIdx.x] + kr.y;
+        if (REFS) {
+            float4 v = pts[i];
+            v.w = __int_as_float((int)i);
+            tmp_pts[dst] = v;
+        }
+        tmp_kv[dst] = make_uint2(kr.x, i);
+    }
+}
+
+// pass 3 ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsigned int* wsum /* 4 LDS words */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    __syncthreads();
+    return base + inc - v;
+}
+
+template <bool REFS>
+__global__ void __launch_bounds__(CS_T)
+k_cs_fine(unsigned int ncells, unsigned int F, unsigned int G, const unsigned int* __restrict__ H,
+          const float4* __restrict__ tmp_pts, const uint2* __restrict__ tmp_kv,
+          float4* __restrict__ out_pts, unsigned int* __restrict__ out_order,
+          unsigned int* __restrict__ cell_start) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // F counters + 4 scan words
+    unsigned int* cnt = lds;
+    unsigned int* wsum = lds + F;
+    const unsigned int b = blockIdx.x;
+    const unsigned int beg = H[(size_t)b * G];
+    const unsigned int end = H[(size_t)(b + 1) * G];  // next bucket's first base; the last one reads the grand total
+    const unsigned int cell0 = b * F;
+    for (unsigned int f = threadIdx.x; f < F; f += CS_T) cnt[f] = 0;
+    __syncthreads();
+    for (unsigned int j = beg + threadIdx.x; j < end; j += CS_T) atomicAdd(&cnt[tmp_kv[j].x - cell0], 1u);
+    __syncthreads();
+    // exclusive scan of the F counters: thread t owns a contiguous chunk
+    const unsigned int per = (F + CS_T - 1) / CS_T;
+    const unsigned int f0 = threadIdx.x * per, f1 = min(F, f0 + per);
+    unsigned int s = 0;
+    for (unsigned int f = f0; f < f1; ++f) s += cnt[f];
+    unsigned int run = beg + block_excl_scan_256(s, wsum);
+    for (unsigned int f = f0; f < f1; ++f) {
+        const unsigned int c = cnt[f];
+        cnt[f] = run;  // becomes the cursor of cell f
+        if (REFS && cell0 + f < ncells) cell_start[cell0 + f] = run;
+        run += c;
+    }
+    if (REFS && b == gridDim.x - 1 && threadIdx.x == 0) cell_start[ncells] = end;
+    __syncthreads();
+    for (unsigned int j = beg + threadIdx.x; j < end; j += CS_T) {
+        const uint2 kv = tmp_kv[j];
+        const unsigned int pos = atomicAdd(&cnt[kv.x - cell0], 1u);
+        if (REFS) out_pts[pos] = tmp_pts[j];
+        else out_order[pos] = kv.y;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+// Sorts pts[0..n) by cell.  refs: out_pts (float4, w = position) + cell_start[ncells+1].
+// queries: out_order[0..n_sorted) lists the valid queries cell by cell; *n_sorted_dev (device) = count.
+int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4* out_pts, unsigned int* out_order,
+              unsigned int* cell_start, unsigned int* n_sorted_dev) {
+    hipStream_t s = ix->stream;
+    const GridParams g = ix->grid;
+    const unsigned int n = (unsigned int)n_pts;
+    const CsPlan p = cs_plan((unsigned int)g.ncells, n);
+    // scratch: key_rank[n] | tmp_kv[n] | tmp_pts[n] (refs) | H[B*G+1] + scan scratch
+    DevBuf& kr_buf = ix->scratch_c;
+    DevBuf& kv_buf = ix->scratch_e;
+    DevBuf& tp_buf = ix->scratch_f;
+    DevBuf& h_buf = ix->scratch_b;
+    PCC_TRY(kr_buf.reserve((size_t)n * sizeof(uint2) + 256));
+    PCC_TRY(kv_buf.reserve((size_t)n * sizeof(uint2) + 256));
+    if (refs) PCC_TRY(tp_buf.reserve((size_t)n * sizeof(float4) + 256));
+    const size_t h_elems = (size_t)p.B * p.G + 1;
+    PCC_TRY(h_buf.reserve(((h_elems + 3) & ~(size_t)3) * sizeof(unsigned int)));
+    uint2* key_rank = kr_buf.as<uint2>();
+    uint2* tmp_kv = kv_buf.as<uint2>();
+    float4* tmp_pts = tp_buf.as<float4>();
+    unsigned int* H = h_buf.as<unsigned int>();
+    hipLaunchKernelGGL(k_cs_hist, dim3(p.G), dim3(CS_T), p.B * sizeof(unsigned int), s, pts, n, g, p.F, p.B, p.slice,
+                       key_rank, H);
+    PCC_HIP(hipGetLastError());
+    PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
+    if (n_sorted_dev) PCC_HIP(hipMemcpyAsync(n_sorted_dev, H + h_elems - 1, 4, hipMemcpyDeviceToDevice, s));
+    const size_t lds3 = ((size_t)p.F + 4) * sizeof(unsigned int);
+    if (refs) {
+        hipLaunchKernelGGL((k_cs_scatter<true>), dim3(p.G), dim3(CS_T), 0, s, pts, n, p.F, p.slice, key_rank, H, tmp_pts, tmp_kv);
+        hipLaunchKernelGGL((k_cs_fine<true>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, tmp_pts,
+                           tmp_kv, out_pts, out_order, cell_start);
+    } else {
+        hipLaunchKernelGGL((k_cs_scatter<false>), dim3(p.G), dim3(CS_T), 0, s, pts, n, p.F, p.slice, key_rank, H, tmp_pts, tmp_kv);
+        hipLaunchKernelGGL((k_cs_fine<false>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, tmp_pts,
+                           tmp_kv, out_pts, out_order, cell_start);
+    }
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+}  // namespace pcc

@@ -112,10 +112,17 @@ int grid_build(pcc_index* ix, const float lo_in[3], const float hi_in[3]) {
     g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
     ix->grid = g;
     ix->stats[3] = (uint64_t)g.ncells;
-    // 3. counting sort
+    // 3. sort by cell
     size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
     PCC_TRY(ix->cell_start.reserve(cs_bytes));
     PCC_TRY(ix->cell_refs.reserve((size_t)n * sizeof(float4)));
+    static const bool lds_sort = !(getenv("PCC_SORT") && !strcmp(getenv("PCC_SORT"), "atomic"));
+    if (lds_sort) {
+        PCC_TRY(cell_sort(ix, refs, n, true, ix->cell_refs.as<float4>(), nullptr, ix->cell_start.as<unsigned int>(), nullptr));
+        ix->has_grid = true;
+        return PCC_OK;
+    }
+    // first-generation path (one returning device-scope atomic per point), kept for A/B runs
     PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(uint2) + 256));
     unsigned int* cstart = ix->cell_start.as<unsigned int>();
     uint2* cell_rank = ix->scratch_c.as<uint2>();
@@ -281,7 +288,18 @@ int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** 
     unsigned int* qcell = ix->scratch_b.as<unsigned int>();
     uint2* cell_rank = ix->scratch_c.as<uint2>();
     unsigned int* order = ix->scratch_e.as<unsigned int>();
-    unsigned int* n_sorted = ix->small.as<unsigned int>() + 33;
+    unsigned int* n_sorted = ix->small.as<unsigned int>() + 36;
+    static const bool lds_sort = !(getenv("PCC_SORT") && !strcmp(getenv("PCC_SORT"), "atomic"));
+    if (lds_sort) {
+        ev_mark(ix, EV_SORT0);
+        PCC_TRY(ix->scratch_g.reserve((size_t)n * sizeof(unsigned int) + 256));
+        unsigned int* ord = ix->scratch_g.as<unsigned int>();
+        PCC_TRY(cell_sort(ix, q, nq, false, nullptr, ord, nullptr, n_sorted));
+        ev_mark(ix, EV_SORT1);
+        *order_dev = ord;
+        *n_sorted_dev = n_sorted;
+        return PCC_OK;
+    }
     ev_mark(ix, EV_SORT0);
     PCC_HIP(hipMemsetAsync(qcell, 0, cs_bytes, s));
     hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell, cell_rank);

@@ -69,7 +69,7 @@ struct pcc_index {
     pcc::DevBuf cell_start;  // uint32[ncells + 1]
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
-        scratch_c, scratch_d, scratch_e, small, blk_stats, icp_src;
+        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src;
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
@@ -139,6 +139,9 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
                       unsigned int** n_sorted_dev);
 float grid_slack(const GridParams& g);
+// ---- cellsort.hip: LDS-based two-level counting sort by cell ---------------------------------------
+int cell_sort(pcc_index* ix, const float4* pts, size_t n, bool refs, float4* out_pts, unsigned int* out_order,
+              unsigned int* cell_start, unsigned int* n_sorted_dev);
 // ---- knn.hip: k-NN, radius search (GRID engine) ----------------------------------------
 // keys[nq][K] (pre-set to ~0) receive the K smallest (d2, position) keys ascending
 int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys);
