@@ -63,22 +63,16 @@ k_cs_hist(const float4* __restrict__ pts, unsigned int n, GridParams g, unsigned
 }
 
 // pass 2 ---------------------------------------------------------------------------------------
-// REFS: move the point (w := its position in the packed array) and its key.  Queries: key + index.
-template <bool REFS>
+// Only (cell, point index) pairs move here: scattering the 16-byte payload too costs a partial
+// 64-byte line write per point (31 us per 1M points measured); pass 3 gathers it instead.
 __global__ void __launch_bounds__(CS_T)
-k_cs_scatter(const float4* __restrict__ pts, unsigned int n, unsigned int F, unsigned int slice,
-             const uint2* __restrict__ key_rank, const unsigned int* __restrict__ H,
-             float4* __restrict__ tmp_pts, uint2* __restrict__ tmp_kv) {
+k_cs_scatter(unsigned int n, unsigned int F, unsigned int slice, const uint2* __restrict__ key_rank,
+             const unsigned int* __restrict__ H, uint2* __restrict__ tmp_kv) {
     const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
     for (unsigned int i = beg + threadIdx.x; i < end; i += CS_T) {
         const uint2 kr = key_rank[i];
         if (kr.x == 0xffffffffu) continue;
         const unsigned int dst = H[(size_t)(kr.x / F) * gridDim.x + blockIdx.x] + kr.y;
-        if (REFS) {
-            float4 v = pts[i];
-            v.w = __int_as_float((int)i);
-            tmp_pts[dst] = v;
-        }
         tmp_kv[dst] = make_uint2(kr.x, i);
     }
 }
@@ -102,7 +96,7 @@ __device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsi
 template <bool REFS>
 __global__ void __launch_bounds__(CS_T)
 k_cs_fine(unsigned int ncells, unsigned int F, unsigned int G, const unsigned int* __restrict__ H,
-          const float4* __restrict__ tmp_pts, const uint2* __restrict__ tmp_kv,
+          const float4* __restrict__ pts, const uint2* __restrict__ tmp_kv,
           float4* __restrict__ out_pts, unsigned int* __restrict__ out_order,
           unsigned int* __restrict__ cell_start) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // F counters + 4 scan words
@@ -133,8 +127,13 @@ k_cs_fine(unsigned int ncells, unsigned int F, unsigned int G, const unsigned in
     for (unsigned int j = beg + threadIdx.x; j < end; j += CS_T) {
         const uint2 kv = tmp_kv[j];
         const unsigned int pos = atomicAdd(&cnt[kv.x - cell0], 1u);
-        if (REFS) out_pts[pos] = tmp_pts[j];
-        else out_order[pos] = kv.y;
+        if (REFS) {
+            float4 v = pts[kv.y];                 // gather from the original-order array
+            v.w = __int_as_float((int)kv.y);      // cell-sorted copies carry the packed position
+            out_pts[pos] = v;
+        } else {
+            out_order[pos] = kv.y;
+        }
     }
 }
 
@@ -147,19 +146,16 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     const GridParams g = ix->grid;
     const unsigned int n = (unsigned int)n_pts;
     const CsPlan p = cs_plan((unsigned int)g.ncells, n);
-    // scratch: key_rank[n] | tmp_kv[n] | tmp_pts[n] (refs) | H[B*G+1] + scan scratch
+    // scratch: key_rank[n] | tmp_kv[n] | H[B*G+1] + scan scratch
     DevBuf& kr_buf = ix->scratch_c;
     DevBuf& kv_buf = ix->scratch_e;
-    DevBuf& tp_buf = ix->scratch_f;
     DevBuf& h_buf = ix->scratch_b;
     PCC_TRY(kr_buf.reserve((size_t)n * sizeof(uint2) + 256));
     PCC_TRY(kv_buf.reserve((size_t)n * sizeof(uint2) + 256));
-    if (refs) PCC_TRY(tp_buf.reserve((size_t)n * sizeof(float4) + 256));
     const size_t h_elems = (size_t)p.B * p.G + 1;
     PCC_TRY(h_buf.reserve(((h_elems + 3) & ~(size_t)3) * sizeof(unsigned int)));
     uint2* key_rank = kr_buf.as<uint2>();
     uint2* tmp_kv = kv_buf.as<uint2>();
-    float4* tmp_pts = tp_buf.as<float4>();
     unsigned int* H = h_buf.as<unsigned int>();
     hipLaunchKernelGGL(k_cs_hist, dim3(p.G), dim3(CS_T), p.B * sizeof(unsigned int), s, pts, n, g, p.F, p.B, p.slice,
                        key_rank, H);
@@ -167,15 +163,13 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
     if (n_sorted_dev) PCC_HIP(hipMemcpyAsync(n_sorted_dev, H + h_elems - 1, 4, hipMemcpyDeviceToDevice, s));
     const size_t lds3 = ((size_t)p.F + 4) * sizeof(unsigned int);
-    if (refs) {
-        hipLaunchKernelGGL((k_cs_scatter<true>), dim3(p.G), dim3(CS_T), 0, s, pts, n, p.F, p.slice, key_rank, H, tmp_pts, tmp_kv);
-        hipLaunchKernelGGL((k_cs_fine<true>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, tmp_pts,
+    hipLaunchKernelGGL(k_cs_scatter, dim3(p.G), dim3(CS_T), 0, s, n, p.F, p.slice, key_rank, H, tmp_kv);
+    if (refs)
+        hipLaunchKernelGGL((k_cs_fine<true>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, pts,
                            tmp_kv, out_pts, out_order, cell_start);
-    } else {
-        hipLaunchKernelGGL((k_cs_scatter<false>), dim3(p.G), dim3(CS_T), 0, s, pts, n, p.F, p.slice, key_rank, H, tmp_pts, tmp_kv);
-        hipLaunchKernelGGL((k_cs_fine<false>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, tmp_pts,
+    else
+        hipLaunchKernelGGL((k_cs_fine<false>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, pts,
                            tmp_kv, out_pts, out_order, cell_start);
-    }
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
