@@ -108,22 +108,25 @@ static int nn1_packed(pcc_index* ix, size_t nq) {
     if (ix->engine == PCC_ENGINE_GRID) return grid_nn1(ix, ix->q_packed.as<float4>(), nq, out);
     ix->stats[0] = 0;
     ix->stats[1] = nq;
+    ix->stats_pending = false;
     ev_mark(ix, EV_MAIN0);
-    int st = launch_nn1_brute(ix->stream, ix->refs.as<float4>(), ix->n_valid, ix->q_packed.as<float4>(), nq,
+    int st = launch_nn1_brute(ix->stream, ix->refs.as<float4>(), ix->n_orig, ix->q_packed.as<float4>(), nq,
                               out, nullptr, nullptr, 0);
     ev_mark(ix, EV_MAIN1);
     return st;
 }
 
-static int resolve_engine(int requested, size_t n_valid) {
+static int resolve_engine(int requested, size_t n) {
     // the grid build costs a few passes over the cloud; below ~4k points one exhaustive
     // sweep is cheaper than building it
-    if (requested == PCC_ENGINE_AUTO) return n_valid >= 4096 ? PCC_ENGINE_GRID : PCC_ENGINE_BRUTE;
+    if (requested == PCC_ENGINE_AUTO) return n >= 4096 ? PCC_ENGINE_GRID : PCC_ENGINE_BRUTE;
     return requested;
 }
 
-// (re)build the index over a new cloud: pack (+ bbox + invalid count in the same pass),
-// optional order-preserving compaction, optional grid build.  One stream sync.
+// (re)build the index over a new cloud, fully asynchronous on the index's stream:
+// pack (+ per-workgroup bbox / non-finite counts) -> grid sizing ON THE DEVICE -> cell sort.
+// Non-finite points stay in place flagged w = -1 (no compaction: position == original index).
+// Host-visible facts (n_valid, bbox, grid) arrive through a pinned mirror; sync_info() waits.
 static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
     ix->n_valid = 0;
     ix->has_grid = false;
@@ -131,42 +134,11 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     ev_next(ix);
     ev_mark(ix, EV_BUILD0);
     PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
-    unsigned int* d_cnt = ix->small.as<unsigned int>();
-    float* d_blk = ix->blk_stats.as<float>();
-    float* h_blk = static_cast<float*>(ix->pinned);
     int nblk = 0;
-    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), d_blk, &nblk));
-    PCC_HIP(hipMemcpyAsync(h_blk, d_blk, (size_t)nblk * 8 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-    PCC_HIP(hipStreamSynchronize(ix->stream));
-    size_t n_invalid = 0;
-    for (int a = 0; a < 3; ++a) { ix->bbox_lo[a] = INFINITY; ix->bbox_hi[a] = -INFINITY; }
-    for (int b = 0; b < nblk; ++b) {
-        unsigned int bad;
-        memcpy(&bad, &h_blk[b * 8], 4);
-        n_invalid += bad;
-        for (int a = 0; a < 3; ++a) {
-            ix->bbox_lo[a] = std::min(ix->bbox_lo[a], h_blk[b * 8 + 1 + a]);
-            ix->bbox_hi[a] = std::max(ix->bbox_hi[a], h_blk[b * 8 + 4 + a]);
-        }
-    }
-    size_t n_valid = n - n_invalid;
-    if (n_valid == 0) { set_error("Cannot create a KDTree with an empty input cloud (all %zu points non-finite)", n); return PCC_ERR_EMPTY; }
-    if (n_invalid) {
-        // order-preserving compaction == PCL's index_mapping_
-        DevBuf packed2;
-        PCC_TRY(packed2.reserve(n_valid * sizeof(float4)));
-        int st = launch_compact(ix->stream, ix->refs.as<float4>(), n, packed2.as<float4>(), d_cnt + 12, ix->scratch_a);
-        if (st == PCC_OK && hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("compaction failed"); st = PCC_ERR_DEVICE; }
-        if (st != PCC_OK) { packed2.release(); return st; }
-        ix->refs.release();
-        ix->refs = packed2;
-    }
-    ix->n_valid = n_valid;
-    ix->stats[2] = n_valid;
-    ix->engine = resolve_engine(ix->engine_requested, n_valid);
-    if (ix->engine == PCC_ENGINE_GRID) {
-        PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
-    }
+    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk));
+    PCC_TRY(grid_params(ix, ix->blk_stats.as<float>(), nblk));
+    ix->engine = resolve_engine(ix->engine_requested, n);
+    if (ix->engine == PCC_ENGINE_GRID) PCC_TRY(grid_build(ix));
     ev_mark(ix, EV_BUILD1);
     return PCC_OK;
 }
@@ -195,12 +167,13 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->d_grid};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
             if (ix->ev[sl][k]) (void)hipEventDestroy(ix->ev[sl][k]);
     if (ix->pinned) (void)hipHostFree(ix->pinned);
+    if (ix->h_grid) (void)hipHostFree(ix->h_grid);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
     return PCC_OK;
@@ -230,8 +203,12 @@ int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem,
     if ((st = ix->blk_stats.reserve(PACK_MAX_BLOCKS * 8 * sizeof(float))) != PCC_OK) return fail(st);
     ix->engine_requested = engine;
     ix->engine = engine;
+    if (hipHostMalloc((void**)&ix->h_grid, sizeof(GridDev), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
+    memset(ix->h_grid, 0, sizeof(GridDev));
     if ((st = set_input(ix, pts, n, stride, mem)) != PCC_OK) return fail(st);
+    if ((st = sync_info(ix)) != PCC_OK) return fail(st);
     if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
+    if (ix->n_valid == 0) { set_error("Cannot create a KDTree with an empty input cloud (all %zu points non-finite)", n); return fail(PCC_ERR_EMPTY); }
     *out = ix;
     return PCC_OK;
 }
@@ -240,7 +217,9 @@ int pcc_index_set_input(pcc_index* ix, const void* pts, size_t n, size_t stride,
     PCC_ENTER(ix);
     if (dim != 3) { set_error("dim %d unsupported", dim); return PCC_ERR_UNSUPPORTED; }
     PCC_TRY(check_points(pts, n, stride, mem));
-    if (n == 0) { ix->n_valid = 0; set_error("Cannot create a KDTree with an empty input cloud"); return PCC_ERR_EMPTY; }
+    if (n == 0) { ix->n_valid = 0; ix->n_orig = 0; set_error("Cannot create a KDTree with an empty input cloud"); return PCC_ERR_EMPTY; }
+    // asynchronous: a cloud without any finite point is reported by pcc_index_size (0) and by
+    // searches returning idx = -1, not by this call
     return set_input(ix, pts, n, stride, mem);
 }
 
@@ -281,8 +260,11 @@ int pcc_index_timing(pcc_index* ix, float ms[8]) {
     return PCC_OK;
 }
 
-int pcc_index_size(const pcc_index* ix, size_t* n_valid) {
-    if (!ix || !n_valid) { set_error("null argument"); return PCC_ERR_INVALID; }
+int pcc_index_size(const pcc_index* cix, size_t* n_valid) {
+    if (!cix || !n_valid) { set_error("null argument"); return PCC_ERR_INVALID; }
+    pcc_index* ix = const_cast<pcc_index*>(cix);  // may have to wait for the asynchronous build
+    PCC_ENTER(ix);
+    PCC_TRY(sync_info(ix));
     *n_valid = ix->n_valid;
     return PCC_OK;
 }
@@ -306,16 +288,22 @@ int pcc_index_set_engine(pcc_index* ix, int engine) {
     PCC_ENTER(ix);
     if (engine < PCC_ENGINE_AUTO || engine > PCC_ENGINE_GRID) { set_error("bad engine %d", engine); return PCC_ERR_INVALID; }
     ix->engine_requested = engine;
-    engine = resolve_engine(engine, ix->n_valid);
-    if (engine == PCC_ENGINE_GRID && !ix->has_grid && ix->n_valid) {
-        PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
-        PCC_HIP(hipStreamSynchronize(ix->stream));
-    }
+    engine = resolve_engine(engine, ix->n_orig);
+    if (engine == PCC_ENGINE_GRID && !ix->has_grid && ix->n_orig) PCC_TRY(grid_build(ix));
     ix->engine = engine;
     return PCC_OK;
 }
-int pcc_index_stats(const pcc_index* ix, uint64_t stats[8]) {
-    if (!ix || !stats) { set_error("null argument"); return PCC_ERR_INVALID; }
+int pcc_index_stats(const pcc_index* cix, uint64_t stats[8]) {
+    if (!cix || !stats) { set_error("null argument"); return PCC_ERR_INVALID; }
+    pcc_index* ix = const_cast<pcc_index*>(cix);
+    PCC_ENTER(ix);
+    PCC_TRY(sync_info(ix));
+    if (ix->stats_pending) {
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        ix->stats_pending = false;
+        ix->stats[1] = static_cast<unsigned int*>(ix->pinned)[40];
+        ix->stats[0] = ix->last_nq - ix->stats[1];
+    }
     memcpy(stats, ix->stats, sizeof(ix->stats));
     return PCC_OK;
 }
@@ -324,7 +312,7 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     PCC_ENTER(ix);
     PCC_TRY(check_points(q, nq, stride, mem));
     if (nq == 0) return PCC_OK;
-    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, q, nq, stride, mem));
@@ -337,8 +325,7 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq,
-                          ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq, didx, dd2));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq, mem));
@@ -350,8 +337,8 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
 
 // the searches below need the cell grid whatever engine k=1 uses
 static int ensure_grid(pcc_index* ix) {
-    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
-    if (!ix->has_grid) PCC_TRY(grid_build(ix, ix->bbox_lo, ix->bbox_hi));
+    if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    if (!ix->has_grid) PCC_TRY(grid_build(ix));
     return PCC_OK;
 }
 
@@ -376,7 +363,7 @@ int pcc_knn(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
     // rows of invalid queries were never touched (all ~0) and unpack to -1 / +inf
-    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, nq * (size_t)k, ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, nq * (size_t)k, didx, dd2));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq * (size_t)k, mem));
@@ -447,7 +434,7 @@ int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int 
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, (size_t)total, ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, (size_t)total, didx, dd2));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, (size_t)total, mem));
@@ -489,10 +476,10 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     PCC_TRY(ensure_grid(ix));
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
-    const size_t n = ix->n_valid, no = ix->n_orig;
+    const size_t n = ix->n_orig, no = ix->n_orig;
     const int K = mean_k + 1;
-    // self query: the packed references ARE the queries (non-finite points are not in refs and
-    // keep distance 0, as in PCL's applyFilterIndices)
+    // self query: the packed references ARE the queries (non-finite points are flagged, are
+    // skipped by the search and keep distance 0, as in PCL's applyFilterIndices)
     PCC_TRY(ix->out_packed.reserve(n * (size_t)K * sizeof(unsigned long long)));
     auto* keys = ix->out_packed.as<unsigned long long>();
     PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, K, keys));
@@ -506,7 +493,8 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     PCC_HIP(hipStreamSynchronize(ix->stream));
     // PCL: sum / sq_sum over ALL entries in index order (double), valid = points with a full
     // neighbourhood.  Invalid points and points without k neighbours contribute 0.
-    size_t valid = ix->n_valid >= (size_t)K ? n : 0;
+    PCC_TRY(sync_info(ix));
+    size_t valid = ix->n_valid >= (size_t)K ? ix->n_valid : 0;
     double sum = 0, sq = 0;
     for (size_t i = 0; i < no; ++i) { sum += hm[i]; sq += (double)hm[i] * hm[i]; }
     double mean = sum / (double)valid;
@@ -632,7 +620,7 @@ int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int me
     if (!sums) { set_error("null sums"); return PCC_ERR_INVALID; }
     for (int k = 0; k < 17; ++k) sums[k] = 0;
     if (n == 0) return PCC_OK;
-    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, src, n, stride, mem));
@@ -648,8 +636,7 @@ int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int me
             didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
             dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
         }
-        PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n,
-                              ix->refs.as<float4>(), ix->n_valid == ix->n_orig, didx, dd2));
+        PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n, didx, dd2));
         if (mem == PCC_MEM_HOST) {
             PCC_TRY(deliver(ix, didx, idx, n, mem));
             PCC_TRY(deliver(ix, dd2, d2, n, mem));
@@ -688,7 +675,7 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     PCC_ENTER(ix);
     PCC_TRY(check_points(src, n, stride, mem));
     if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
-    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(T, I, sizeof(I));
     if (iterations) *iterations = 0;
@@ -742,15 +729,14 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
     out[0] = 0;  // std::vector<int> correspondence(1) -- reference src/comparator.cpp:568
     *out_size = 1;
     if (n2 == 0) return PCC_OK;
-    if (ix->n_valid == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+    if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
     PCC_TRY(nn1_packed(ix, n2));
     PCC_TRY(ix->out_idx.reserve(n2 * sizeof(int32_t)));
     PCC_TRY(ix->out_d2.reserve(n2 * sizeof(float)));
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n2,
-                          ix->refs.as<float4>(), ix->n_valid == ix->n_orig, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n2, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));
     ev_mark(ix, EV_CALL1);
     std::vector<int32_t> hi(n2);
     std::vector<float> hd(n2);

@@ -45,15 +45,16 @@ static CsPlan cs_plan(unsigned int ncells, unsigned int n) {
 
 // pass 1 ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CS_T)
-k_cs_hist(const float4* __restrict__ pts, unsigned int n, GridParams g, unsigned int F, unsigned int B,
+k_cs_hist(const float4* __restrict__ pts, unsigned int n, const GridDev* __restrict__ gd, unsigned int F, unsigned int B,
           unsigned int slice, uint2* __restrict__ key_rank, unsigned int* __restrict__ H) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    const GridParams g = gd->g;
     for (unsigned int b = threadIdx.x; b < B; b += CS_T) lds[b] = 0;
     __syncthreads();
     const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
     for (unsigned int i = beg + threadIdx.x; i < end; i += CS_T) {
         const float4 v = pts[i];
-        if (__float_as_int(v.w) < 0) { key_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // invalid query
+        if (__float_as_int(v.w) < 0) { key_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // non-finite point: not indexed
         const unsigned int c = cell_id(v, g);
         key_rank[i] = make_uint2(c, atomicAdd(&lds[c / F], 1u));
     }
@@ -95,13 +96,14 @@ __device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsi
 
 template <bool REFS>
 __global__ void __launch_bounds__(CS_T)
-k_cs_fine(unsigned int ncells, unsigned int F, unsigned int G, const unsigned int* __restrict__ H,
+k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const unsigned int* __restrict__ H,
           const float4* __restrict__ pts, const uint2* __restrict__ tmp_kv,
           float4* __restrict__ out_pts, unsigned int* __restrict__ out_order,
           unsigned int* __restrict__ cell_start) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // F counters + 4 scan words
     unsigned int* cnt = lds;
     unsigned int* wsum = lds + F;
+    const unsigned int ncells = (unsigned int)gd->g.ncells;  // actual cell count (<= the host's nc_cap)
     const unsigned int b = blockIdx.x;
     const unsigned int beg = H[(size_t)b * G];
     const unsigned int end = H[(size_t)(b + 1) * G];  // next bucket's first base; the last one reads the grand total
@@ -119,10 +121,9 @@ k_cs_fine(unsigned int ncells, unsigned int F, unsigned int G, const unsigned in
     for (unsigned int f = f0; f < f1; ++f) {
         const unsigned int c = cnt[f];
         cnt[f] = run;  // becomes the cursor of cell f
-        if (REFS && cell0 + f < ncells) cell_start[cell0 + f] = run;
-        run += c;
+        if (REFS && cell0 + f <= ncells) cell_start[cell0 + f] = run;  // cells past ncells are empty: entry
+        run += c;                                                      // [ncells] receives the total
     }
-    if (REFS && b == gridDim.x - 1 && threadIdx.x == 0) cell_start[ncells] = end;
     __syncthreads();
     for (unsigned int j = beg + threadIdx.x; j < end; j += CS_T) {
         const uint2 kv = tmp_kv[j];
@@ -143,9 +144,10 @@ k_cs_fine(unsigned int ncells, unsigned int F, unsigned int G, const unsigned in
 int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4* out_pts, unsigned int* out_order,
               unsigned int* cell_start, unsigned int* n_sorted_dev) {
     hipStream_t s = ix->stream;
-    const GridParams g = ix->grid;
     const unsigned int n = (unsigned int)n_pts;
-    const CsPlan p = cs_plan((unsigned int)g.ncells, n);
+    // planned from the host-known upper bound of the cell count; buckets past the actual grid stay empty
+    const CsPlan p = cs_plan(ix->nc_cap + 1, n);
+    const GridDev* gd = ix->d_grid.as<GridDev>();
     // scratch: key_rank[n] | tmp_kv[n] | H[B*G+1] + scan scratch
     DevBuf& kr_buf = ix->scratch_c;
     DevBuf& kv_buf = ix->scratch_e;
@@ -157,7 +159,7 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     uint2* key_rank = kr_buf.as<uint2>();
     uint2* tmp_kv = kv_buf.as<uint2>();
     unsigned int* H = h_buf.as<unsigned int>();
-    hipLaunchKernelGGL(k_cs_hist, dim3(p.G), dim3(CS_T), p.B * sizeof(unsigned int), s, pts, n, g, p.F, p.B, p.slice,
+    hipLaunchKernelGGL(k_cs_hist, dim3(p.G), dim3(CS_T), p.B * sizeof(unsigned int), s, pts, n, gd, p.F, p.B, p.slice,
                        key_rank, H);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
@@ -165,10 +167,10 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     const size_t lds3 = ((size_t)p.F + 4) * sizeof(unsigned int);
     hipLaunchKernelGGL(k_cs_scatter, dim3(p.G), dim3(CS_T), 0, s, n, p.F, p.slice, key_rank, H, tmp_kv);
     if (refs)
-        hipLaunchKernelGGL((k_cs_fine<true>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, pts,
+        hipLaunchKernelGGL((k_cs_fine<true>), dim3(p.B), dim3(CS_T), lds3, s, gd, p.F, p.G, H, pts,
                            tmp_kv, out_pts, out_order, cell_start);
     else
-        hipLaunchKernelGGL((k_cs_fine<false>), dim3(p.B), dim3(CS_T), lds3, s, (unsigned int)g.ncells, p.F, p.G, H, pts,
+        hipLaunchKernelGGL((k_cs_fine<false>), dim3(p.B), dim3(CS_T), lds3, s, gd, p.F, p.G, H, pts,
                            tmp_kv, out_pts, out_order, cell_start);
     PCC_HIP(hipGetLastError());
     return PCC_OK;

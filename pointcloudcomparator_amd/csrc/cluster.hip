@@ -49,10 +49,12 @@ k_uf_init(unsigned int* __restrict__ parent, unsigned int n) {
 
 // thread t owns the t-th point in CELL order (neighbouring lanes touch neighbouring cells)
 __global__ void __launch_bounds__(256)
-k_uf_link(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
-          float slack, unsigned int n, float r, float r2, unsigned int* __restrict__ parent) {
+k_uf_link(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+          const GridDev* __restrict__ gd, float r, float r2, unsigned int* __restrict__ parent) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    if (t >= gd->n_valid) return;  // cell_refs holds the valid points only
     const float4 me = cell_refs[t];
     const unsigned int mypos = (unsigned int)__float_as_int(me.w);
     int x0, x1, y0, y1, z0, z1;
@@ -73,8 +75,10 @@ k_uf_link(const float4* __restrict__ cell_refs, const unsigned int* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-k_uf_flatten_count(unsigned int* __restrict__ parent, unsigned int n, unsigned int* __restrict__ size) {
+k_uf_flatten_count(const float4* __restrict__ refs, unsigned int* __restrict__ parent, unsigned int n,
+                   unsigned int* __restrict__ size) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (__float_as_int(refs[i].w) < 0) continue;  // non-finite point: in no cluster
         unsigned int r = uf_find(parent, i);
         atomicMin(&parent[i], r);  // other threads still reach the same root through older values
         atomicAdd(&size[r], 1u);
@@ -87,7 +91,8 @@ k_uf_collect(const unsigned int* __restrict__ parent, const unsigned int* __rest
              unsigned int cap) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (parent[i] != i) continue;
-        unsigned int sz = size[i];
+        unsigned int sz = size[i];  // 0 for a non-finite point (never counted)
+        if (sz == 0) continue;
         if (sz < min_size || sz > max_size) continue;
         unsigned int slot = atomicAdd(count, 1u);
         if (slot < cap) list[slot] = make_uint2(i, sz);
@@ -104,7 +109,7 @@ __global__ void __launch_bounds__(256)
 k_uf_label(const float4* __restrict__ refs, const unsigned int* __restrict__ parent, const int* __restrict__ id_of_root,
            unsigned int n, int32_t* __restrict__ labels) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        labels[__float_as_int(refs[i].w)] = id_of_root[parent[i]];
+        if (__float_as_int(refs[i].w) >= 0) labels[i] = id_of_root[parent[i]];  // position == original index
 }
 
 static inline int g1(size_t n) {
@@ -115,8 +120,7 @@ static inline int g1(size_t n) {
 int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t max_size,
                   int32_t* labels_dev, int32_t* n_clusters, int32_t* sizes, int max_sizes) {
     hipStream_t s = ix->stream;
-    const unsigned int n = (unsigned int)ix->n_valid;
-    const GridParams g = ix->grid;
+    const unsigned int n = (unsigned int)ix->n_orig;
     // scratch: parent[n] | size[n] | id_of_root[n] | list[cap]
     const unsigned int cap = min_size > 0 ? n / min_size + 1 : n;
     PCC_TRY(ix->scratch_c.reserve((size_t)n * 4));
@@ -135,8 +139,8 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
     PCC_HIP(hipMemsetAsync(d_count, 0, 4, s));
     PCC_HIP(hipMemsetAsync(labels_dev, 0xff, ix->n_orig * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_uf_link, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                       ix->cell_start.as<unsigned int>(), g, grid_slack(g), n, r, r2, parent);
-    hipLaunchKernelGGL(k_uf_flatten_count, dim3(g1(n)), dim3(256), 0, s, parent, n, size);
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), r, r2, parent);
+    hipLaunchKernelGGL(k_uf_flatten_count, dim3(g1(n)), dim3(256), 0, s, ix->refs.as<float4>(), parent, n, size);
     hipLaunchKernelGGL(k_uf_collect, dim3(g1(n)), dim3(256), 0, s, parent, size, n, min_size, max_size, list, d_count, cap);
     PCC_HIP(hipGetLastError());
     unsigned int* h = static_cast<unsigned int*>(ix->pinned);

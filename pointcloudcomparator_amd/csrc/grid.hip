@@ -4,7 +4,7 @@
 // prune the exhaustive scan without changing a single result bit.
 //
 // Index layout in HBM:
-//   cell_refs  float4[n_valid]   (x, y, z, bits(position in the packed original-order array)), sorted by linear
+//   cell_refs  float4[n_valid]   (x, y, z, bits(position in refs == original index)), sorted by linear
 //                                cell id with x fastest, so one row of cells along x
 //                                is ONE contiguous span of points
 //   cell_start uint32[ncells+1]  CSR starts
@@ -26,36 +26,119 @@ constexpr float GRID_TARGET_PPC = 0.5f; // mean points per cell (over the boundi
                                          // measured optimum on the corridor scene at 1M and 10M points
 constexpr unsigned int GRID_MAX_CELLS = 1u << 26;
 
-// ---- counting sort by cell ----------------------------------------------------------
-// The counting pass hands every point its rank inside its cell (the value the atomic
-// returns), so the scatter pass needs no second round of atomics: pos = start[cell] + rank.
-__global__ void __launch_bounds__(256)
-k_cell_count(const float4* __restrict__ p, unsigned int n, GridParams g, unsigned int* __restrict__ count,
-             uint2* __restrict__ cell_rank) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 v = p[i];
-        if (__float_as_int(v.w) < 0) { cell_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // invalid query
-        unsigned int c = cell_id(v, g);
-        cell_rank[i] = make_uint2(c, atomicAdd(&count[c], 1u));
-    }
+unsigned int grid_nc_cap(size_t n) {
+    // cells the grid may use: twice the target (thin clouds round up a lot per dimension)
+    static const double ppc = (getenv("PCC_GRID_PPC") && atof(getenv("PCC_GRID_PPC")) > 0) ? atof(getenv("PCC_GRID_PPC")) : GRID_TARGET_PPC;
+    double c = 2.0 * (double)n / ppc + 4096.0;
+    if (c > (double)GRID_MAX_CELLS) c = (double)GRID_MAX_CELLS;
+    return (unsigned int)c;
 }
+
+// ---- grid sizing on the device ------------------------------------------------------------------
+// One workgroup reduces the pack kernel's per-workgroup rows (invalid count, bbox) and derives
+// the grid: cell edge so that the mean occupancy over the non-flat dimensions of the bounding
+// box is `ppc` points per cell, grown until the cell count fits nc_cap.  Keeping this on the
+// device removes the host round trip (D2H, wait, launch) from every index build: 46 us of a
+// 385 us step at 1M points.
 __global__ void __launch_bounds__(256)
-k_cell_scatter_refs(const float4* __restrict__ p, unsigned int n, const uint2* __restrict__ cell_rank,
-                    const unsigned int* __restrict__ start, float4* __restrict__ out) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint2 cr = cell_rank[i];
-        float4 v = p[i];
-        v.w = __int_as_float((int)i);  // cell-sorted copies carry the packed POSITION, not the original index
-        out[start[cr.x] + cr.y] = v;
+k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap,
+              GridDev* __restrict__ out) {
+    __shared__ float red[4][8];
+    unsigned int bad = 0;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+        const float* r = blk + (size_t)b * 8;
+        bad += __float_as_uint(r[0]);
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], r[1 + a]); hi[a] = fmaxf(hi[a], r[4 + a]); }
     }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_down(bad, off, 64);
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = __uint_as_float(bad);
+        for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][1 + a] = lo[a]; red[threadIdx.x >> 6][4 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    bad = 0;
+    for (int w = 0; w < 4; ++w) {
+        bad += __float_as_uint(red[w][0]);
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], red[w][1 + a]); hi[a] = fmaxf(hi[a], red[w][4 + a]); }
+    }
+    GridDev d;
+    d.n_invalid = bad;
+    d.n_valid = n - bad;
+    d.pad_ = 0;
+    float ext[3], maxext = 0.f, maxabs = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        if (d.n_valid == 0) { lo[a] = 0.f; hi[a] = 0.f; }
+        d.lo[a] = lo[a];
+        d.hi[a] = hi[a];
+        ext[a] = hi[a] - lo[a];
+        if (!(ext[a] >= 0.f) || !(ext[a] < __builtin_inff())) ext[a] = 0.f;  // overflowed extents: one cell
+        maxext = fmaxf(maxext, ext[a]);
+        maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+    }
+    int nd = 0;
+    double vol = 1.0;
+    for (int a = 0; a < 3; ++a)
+        if (ext[a] > 1e-6f * maxext && ext[a] > 0.f) { vol *= (double)ext[a]; ++nd; }
+    double cells_wanted = fmax(1.0, (double)d.n_valid / (double)ppc);
+    if (cells_wanted > (double)nc_cap) cells_wanted = (double)nc_cap;
+    double hcell = nd ? pow(vol / cells_wanted, 1.0 / (double)nd) : 1.0;
+    if (!(hcell > 0.0) || !(hcell < 1e300)) hcell = 1.0;
+    GridParams g;
+    for (int iter = 0; iter < 200; ++iter) {  // grow the cell until the grid fits nc_cap
+        g.h = (float)hcell;
+        g.inv_h = 1.0f / g.h;
+        if (!(g.inv_h > 0.f) || !(g.inv_h < __builtin_inff()) || !(g.h > 0.f)) { g.h = 1.f; g.inv_h = 1.f; }
+        double tot = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            double dd = floor((double)ext[a] * (double)g.inv_h) + 1.0;
+            if (dd > 1048576.0) dd = 1048576.0;
+            g.dim[a] = (int)dd;
+            tot *= dd;
+        }
+        if (tot <= (double)nc_cap) break;
+        hcell *= 1.26;
+    }
+    if ((double)g.dim[0] * g.dim[1] * g.dim[2] > (double)nc_cap) { g.dim[0] = g.dim[1] = g.dim[2] = 1; }  // cannot happen; stay in bounds
+    for (int a = 0; a < 3; ++a) g.org[a] = lo[a];
+    g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
+    d.g = g;
+    float far = 0.f;
+    for (int a = 0; a < 3; ++a) far = fmaxf(far, fmaxf(fabsf(g.org[a]), fabsf(g.org[a] + g.dim[a] * g.h)));
+    d.slack = 4e-6f * far + 1e-6f * g.h;
+    *out = d;
 }
-__global__ void __launch_bounds__(256)
-k_cell_scatter_ids(unsigned int n, const uint2* __restrict__ cell_rank, const unsigned int* __restrict__ start,
-                   unsigned int* __restrict__ order) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint2 cr = cell_rank[i];
-        if (cr.x != 0xffffffffu) order[start[cr.x] + cr.y] = i;
-    }
+
+int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
+    static const float ppc = (getenv("PCC_GRID_PPC") && atof(getenv("PCC_GRID_PPC")) > 0) ? (float)atof(getenv("PCC_GRID_PPC")) : GRID_TARGET_PPC;
+    PCC_TRY(ix->d_grid.reserve(sizeof(GridDev)));
+    ix->nc_cap = grid_nc_cap(ix->n_orig);
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
+                       ppc, ix->nc_cap, ix->d_grid.as<GridDev>());
+    PCC_HIP(hipGetLastError());
+    PCC_HIP(hipMemcpyAsync(ix->h_grid, ix->d_grid.p, sizeof(GridDev), hipMemcpyDeviceToHost, ix->stream));
+    ix->info_pending = true;
+    return PCC_OK;
+}
+
+int sync_info(pcc_index* ix) {
+    if (!ix->info_pending) return PCC_OK;
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    ix->info_pending = false;
+    ix->grid = ix->h_grid->g;
+    ix->n_valid = ix->h_grid->n_valid;
+    for (int a = 0; a < 3; ++a) { ix->bbox_lo[a] = ix->h_grid->lo[a]; ix->bbox_hi[a] = ix->h_grid->hi[a]; }
+    ix->stats[2] = ix->n_valid;
+    ix->stats[3] = (uint64_t)ix->grid.ncells;
+    return PCC_OK;
 }
 
 static inline int grid1d(size_t n) {
@@ -65,79 +148,18 @@ static inline int grid1d(size_t n) {
     return (int)b;
 }
 
-int grid_build(pcc_index* ix, const float lo_in[3], const float hi_in[3]) {
-    hipStream_t s = ix->stream;
-    const unsigned int n = (unsigned int)ix->n_valid;
-    const float4* refs = ix->refs.as<float4>();
-    float lo[3], hi[3], ext[3];
-    float maxext = 0.f, maxabs = 0.f;
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = lo_in[a];
-        hi[a] = hi_in[a];
-        ext[a] = hi[a] - lo[a];
-        if (!(ext[a] >= 0.f) || !std::isfinite(ext[a])) ext[a] = 0.f;  // overflowed extents fall back to one cell
-        maxext = std::max(maxext, ext[a]);
-        maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
-    }
-    // 2. cell size: GRID_TARGET_PPC points per cell on average over the non-flat dimensions
-    GridParams g;
-    int nd = 0;
-    double vol = 1.0;
-    for (int a = 0; a < 3; ++a)
-        if (ext[a] > 1e-6f * maxext && ext[a] > 0.f) { vol *= ext[a]; ++nd; }
-    double cells_wanted = std::max(1.0, (double)n / GRID_TARGET_PPC);
-    const char* env = getenv("PCC_GRID_PPC");
-    if (env && atof(env) > 0) cells_wanted = std::max(1.0, (double)n / atof(env));
-    if (cells_wanted > GRID_MAX_CELLS) cells_wanted = GRID_MAX_CELLS;
-    double hcell = nd ? std::pow(vol / cells_wanted, 1.0 / nd) : 1.0;
-    if (!(hcell > 0) || !std::isfinite(hcell)) hcell = 1.0;
-    for (int iter = 0; iter < 64; ++iter) {  // grow h until the cell count fits
-        double tot = 1;
-        for (int a = 0; a < 3; ++a) tot *= std::floor(ext[a] / hcell) + 1;
-        if (tot <= (double)GRID_MAX_CELLS) break;
-        hcell *= 1.26;
-    }
-    g.h = (float)hcell;
-    g.inv_h = 1.0f / g.h;
-    if (!std::isfinite(g.inv_h) || g.inv_h <= 0) { g.h = 1.f; g.inv_h = 1.f; }
-    double tot = 1;
-    for (int a = 0; a < 3; ++a) {
-        g.org[a] = lo[a];
-        double d = std::floor((double)ext[a] * g.inv_h) + 1;
-        if (d > 1 << 20) d = 1 << 20;
-        g.dim[a] = (int)d;
-        tot *= d;
-    }
-    if (tot > (double)GRID_MAX_CELLS * 2) { set_error("grid sizing failed"); return PCC_ERR_INVALID; }
-    g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
-    ix->grid = g;
-    ix->stats[3] = (uint64_t)g.ncells;
-    // 3. sort by cell
-    size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
+// cell-sort the references (asynchronous; launch sizes come from n_orig and nc_cap)
+int grid_build(pcc_index* ix) {
+    const size_t n = ix->n_orig;
+    size_t cs_bytes = ((size_t)ix->nc_cap + 1 + 3) / 4 * 4 * sizeof(unsigned int);
     PCC_TRY(ix->cell_start.reserve(cs_bytes));
-    PCC_TRY(ix->cell_refs.reserve((size_t)n * sizeof(float4)));
-    static const bool lds_sort = !(getenv("PCC_SORT") && !strcmp(getenv("PCC_SORT"), "atomic"));
-    if (lds_sort) {
-        PCC_TRY(cell_sort(ix, refs, n, true, ix->cell_refs.as<float4>(), nullptr, ix->cell_start.as<unsigned int>(), nullptr));
-        ix->has_grid = true;
-        return PCC_OK;
-    }
-    // first-generation path (one returning device-scope atomic per point), kept for A/B runs
-    PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(uint2) + 256));
-    unsigned int* cstart = ix->cell_start.as<unsigned int>();
-    uint2* cell_rank = ix->scratch_c.as<uint2>();
-    PCC_HIP(hipMemsetAsync(cstart, 0, cs_bytes, s));
-    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, refs, n, g, cstart, cell_rank);
-    PCC_HIP(hipGetLastError());
-    PCC_TRY(launch_exclusive_scan(s, cstart, (size_t)g.ncells + 1, ix->scratch_a));
-    hipLaunchKernelGGL(k_cell_scatter_refs, dim3(grid1d(n)), dim3(256), 0, s, refs, n, cell_rank, cstart,
-                       ix->cell_refs.as<float4>());
-    PCC_HIP(hipGetLastError());
+    PCC_TRY(ix->cell_refs.reserve(n * sizeof(float4) + 64));
+    PCC_TRY(cell_sort(ix, ix->refs.as<float4>(), n, true, ix->cell_refs.as<float4>(), nullptr,
+                      ix->cell_start.as<unsigned int>(), nullptr));
     ix->has_grid = true;
     return PCC_OK;
 }
 
-// ---- k = 1 search ------------------------------------------------------------------------
 // one candidate folded into the running (d2, index) key
 __device__ __forceinline__ unsigned long long fold(unsigned long long best, float qx, float qy, float qz,
                                                    const float4& r) {
@@ -192,11 +214,13 @@ __device__ __forceinline__ unsigned long long scan_box(const float4* __restrict_
 
 template <int U>
 __global__ void __launch_bounds__(256)
-k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
-           float slack, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+           const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
            const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
            unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
            unsigned int* __restrict__ fb_count) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned int ns = n_sorted_ptr ? *n_sorted_ptr : n;
     if (t >= ns) return;
@@ -268,56 +292,23 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
-float grid_slack(const GridParams& g) {
-    float maxabs = 0.f;
-    for (int a = 0; a < 3; ++a)
-        maxabs = std::max(maxabs, std::max(std::fabs(g.org[a]), std::fabs(g.org[a] + g.dim[a] * g.h)));
-    return 4e-6f * maxabs + 1e-6f * g.h;
-}
-
 // sort the queries by reference-grid cell so neighbouring lanes walk the same rows
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
                       unsigned int** n_sorted_dev) {
-    hipStream_t s = ix->stream;
-    const GridParams g = ix->grid;
     const unsigned int n = (unsigned int)nq;
-    size_t cs_bytes = ((size_t)g.ncells + 1 + 3) / 4 * 4 * sizeof(unsigned int);
-    PCC_TRY(ix->scratch_b.reserve(cs_bytes));
-    PCC_TRY(ix->scratch_c.reserve((size_t)n * sizeof(uint2) + 256));
-    PCC_TRY(ix->scratch_e.reserve((size_t)n * sizeof(unsigned int) + 256));
-    unsigned int* qcell = ix->scratch_b.as<unsigned int>();
-    uint2* cell_rank = ix->scratch_c.as<uint2>();
-    unsigned int* order = ix->scratch_e.as<unsigned int>();
     unsigned int* n_sorted = ix->small.as<unsigned int>() + 36;
-    static const bool lds_sort = !(getenv("PCC_SORT") && !strcmp(getenv("PCC_SORT"), "atomic"));
-    if (lds_sort) {
-        ev_mark(ix, EV_SORT0);
-        PCC_TRY(ix->scratch_g.reserve((size_t)n * sizeof(unsigned int) + 256));
-        unsigned int* ord = ix->scratch_g.as<unsigned int>();
-        PCC_TRY(cell_sort(ix, q, nq, false, nullptr, ord, nullptr, n_sorted));
-        ev_mark(ix, EV_SORT1);
-        *order_dev = ord;
-        *n_sorted_dev = n_sorted;
-        return PCC_OK;
-    }
     ev_mark(ix, EV_SORT0);
-    PCC_HIP(hipMemsetAsync(qcell, 0, cs_bytes, s));
-    hipLaunchKernelGGL(k_cell_count, dim3(grid1d(n)), dim3(256), 0, s, q, n, g, qcell, cell_rank);
-    PCC_HIP(hipGetLastError());
-    PCC_TRY(launch_exclusive_scan(s, qcell, (size_t)g.ncells + 1, ix->scratch_a));
-    // qcell[ncells] == number of valid queries; keep it on the device for the search kernels
-    PCC_HIP(hipMemcpyAsync(n_sorted, qcell + g.ncells, 4, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_cell_scatter_ids, dim3(grid1d(n)), dim3(256), 0, s, n, cell_rank, qcell, order);
-    PCC_HIP(hipGetLastError());
+    PCC_TRY(ix->scratch_g.reserve((size_t)n * sizeof(unsigned int) + 256));
+    unsigned int* ord = ix->scratch_g.as<unsigned int>();
+    PCC_TRY(cell_sort(ix, q, nq, false, nullptr, ord, nullptr, n_sorted));
     ev_mark(ix, EV_SORT1);
-    *order_dev = order;
+    *order_dev = ord;
     *n_sorted_dev = n_sorted;
     return PCC_OK;
 }
 
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out) {
     hipStream_t s = ix->stream;
-    const GridParams g = ix->grid;
     const unsigned int n = (unsigned int)nq;
     PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
     unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
@@ -325,23 +316,27 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     PCC_HIP(hipMemsetAsync(fb_count, 0, 4, s));
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
-    const float slack = grid_slack(g);
     ev_mark(ix, EV_MAIN0);
     static const int U = getenv("PCC_GRID_UNROLL") ? atoi(getenv("PCC_GRID_UNROLL")) : 4;
-    static const int BS = getenv("PCC_GRID_BLOCK") ? atoi(getenv("PCC_GRID_BLOCK")) : 256;
+    const int BS = 256;
 #define PCC_LAUNCH_NN1(UU)                                                                                       \
     hipLaunchKernelGGL((k_grid_nn1<UU>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),     \
-                       ix->cell_start.as<unsigned int>(), g, slack, q, order, n_sorted, n, out, fb_list, fb_count)
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,   \
+                       fb_list, fb_count)
     if (U == 1) PCC_LAUNCH_NN1(1);
     else if (U == 2) PCC_LAUNCH_NN1(2);
     else if (U == 8) PCC_LAUNCH_NN1(8);
     else PCC_LAUNCH_NN1(4);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
-    // queries the cubes could not resolve: exhaustive scan over the original-order references
+    // queries the cell walk could not resolve: exhaustive scan over the original-order references
     ev_mark(ix, EV_FB0);
-    PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_valid, q, n, out, fb_list, fb_count, n));
+    PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_orig, q, n, out, fb_list, fb_count, n));
     ev_mark(ix, EV_FB1);
+    // counters for pcc_index_stats (read lazily): queries sent to the exhaustive fallback, sorted queries
+    PCC_HIP(hipMemcpyAsync(static_cast<unsigned int*>(ix->pinned) + 40, fb_count, 4, hipMemcpyDeviceToHost, s));
+    ix->stats_pending = true;
+    ix->last_nq = nq;
     return PCC_OK;
 }
 

@@ -50,13 +50,16 @@ __device__ __forceinline__ void knn_scan_span(const float4* __restrict__ cell_re
 }
 
 __global__ void __launch_bounds__(256)
-k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
-           float slack, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-           const unsigned int* __restrict__ n_sorted_ptr, unsigned int n, int K, unsigned int n_valid,
+k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+           const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+           const unsigned int* __restrict__ n_sorted_ptr, unsigned int n, int K,
            unsigned long long* __restrict__ keys) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    const unsigned int n_valid = gd->n_valid;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned int ns = *n_sorted_ptr;
-    if (t >= ns) return;
+    if (t >= ns || n_valid == 0) return;
     const unsigned int qi = order[t];
     const float4 qv = q[qi];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
@@ -102,8 +105,7 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
     hipLaunchKernelGGL(k_grid_knn, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                       ix->cell_start.as<unsigned int>(), ix->grid, grid_slack(ix->grid), q, order, n_sorted, n, K,
-                       (unsigned int)ix->n_valid, keys);
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, K, keys);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     return PCC_OK;
@@ -115,11 +117,13 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
 //               with an in-place insertion sort (rows are short: tens to a few hundred entries).
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_grid_radius(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, GridParams g,
-              float slack, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+k_grid_radius(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+              const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
               const unsigned int* __restrict__ n_sorted_ptr, unsigned int n, float r, float r2,
               int32_t* __restrict__ counts, const int64_t* __restrict__ offsets,
               unsigned long long* __restrict__ keys, int sorted) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *n_sorted_ptr) return;
     const unsigned int qi = order[t];
@@ -163,15 +167,15 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
     const unsigned int n = (unsigned int)nq;
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
-    const float slack = grid_slack(ix->grid);
+    const GridDev* gd = ix->d_grid.as<GridDev>();
     ev_mark(ix, EV_MAIN0);
     if (keys)
         hipLaunchKernelGGL((k_grid_radius<true>), dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                           ix->cell_start.as<unsigned int>(), ix->grid, slack, q, order, n_sorted, n, r, r2, counts,
+                           ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, n, r, r2, counts,
                            offsets, keys, sorted);
     else
         hipLaunchKernelGGL((k_grid_radius<false>), dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                           ix->cell_start.as<unsigned int>(), ix->grid, slack, q, order, n_sorted, n, r, r2, counts,
+                           ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, n, r, r2, counts,
                            offsets, keys, sorted);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);

@@ -89,7 +89,7 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
     _Pragma("unroll") for (int l = 0; l < BR_LD; ++l) {                              \
         unsigned int j = rbeg + (TILE_NO) * BR_TILE + l * BR_T + threadIdx.x;        \
         float4 v = refs[min(j, rend - 1)];                                           \
-        bool in = j < rend;                                                          \
+        bool in = j < rend && __float_as_int(v.w) >= 0; /* non-finite refs never win */ \
         sx[l] = in ? v.x : __builtin_inff();                                         \
         sy[l] = in ? v.y : __builtin_inff();                                         \
         sz[l] = in ? v.z : __builtin_inff();                                         \
@@ -144,15 +144,17 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
         if (qi[k] == 0xffffffffu) continue;
         unsigned int widx = 0xffffffffu;
         if (bchunk[k] < 0) {
-            // every distance overflowed to +inf: the oracle keeps the first reference
-            widx = rbeg;
+            // every distance overflowed to +inf: the oracle keeps the first valid reference
+            for (unsigned int p = rbeg; p < rend; ++p)
+                if (__float_as_int(refs[p].w) >= 0) { widx = p; break; }
+            if (widx == 0xffffffffu) continue;  // no valid reference in this split
         } else {
             unsigned int base = rbeg + (unsigned int)bchunk[k] * BR_CH;
             for (int j = 0; j < BR_CH; ++j) {
                 unsigned int p = base + j;
                 if (p >= rend) break;
                 float4 r = refs[p];
-                if (dist2(qx[k], qy[k], qz[k], r) == best[k]) {
+                if (__float_as_int(r.w) >= 0 && dist2(qx[k], qy[k], qz[k], r) == best[k]) {
                     widx = p;  // packed position; positions ascend with the original index
                     break;
                 }

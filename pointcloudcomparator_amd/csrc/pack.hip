@@ -202,61 +202,24 @@ int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& t
     return scan_rec(s, data, n, tmp.as<unsigned int>(), elems);
 }
 
-// ---- order-preserving compaction -------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_flag_valid(const float4* __restrict__ in, size_t n, unsigned int* __restrict__ flags) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n;
-         i += (size_t)gridDim.x * blockDim.x)
-        flags[i] = (i < n && __float_as_int(in[i].w) >= 0) ? 1u : 0u;
-}
-__global__ void __launch_bounds__(256)
-k_scatter_valid(const float4* __restrict__ in, size_t n, const unsigned int* __restrict__ pos,
-                float4* __restrict__ out, unsigned int* __restrict__ d_count) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = in[i];
-        if (__float_as_int(v.w) >= 0) out[pos[i]] = v;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d_count = pos[n];
-}
-
-int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
-                   unsigned int* d_count, DevBuf& tmp) {
-    // tmp layout: flags[n+1] (16-byte aligned) | scan scratch
-    DevBuf& t = tmp;
-    size_t flag_elems = (n + 1 + 3) & ~(size_t)3;
-    size_t scan_elems = 16;
-    for (size_t k = (n + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK; k > 1; k = (k + SCAN_BLOCK - 1) / SCAN_BLOCK)
-        scan_elems += ((k + 3) & ~(size_t)3);
-    PCC_TRY(t.reserve((flag_elems + scan_elems) * sizeof(unsigned int)));
-    unsigned int* flags = t.as<unsigned int>();
-    hipLaunchKernelGGL(k_flag_valid, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, in, n, flags);
-    PCC_HIP(hipGetLastError());
-    PCC_TRY(scan_rec(s, flags, n + 1, flags + flag_elems, scan_elems));
-    hipLaunchKernelGGL(k_scatter_valid, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, flags, out, d_count);
-    PCC_HIP(hipGetLastError());
-    return PCC_OK;
-}
-
 // ---- unpack -------------------------------------------------------------------------
-// search keys hold (d2 bits << 32 | packed position); positions map to ORIGINAL indices through
-// refs[pos].w (PCL's index_mapping_), which is the identity when no point was dropped.
+// search keys hold (d2 bits << 32 | position); non-finite references stay in place (flagged),
+// so a position IS the original index (PCL's index_mapping_ is the identity here).
 __global__ void __launch_bounds__(256)
 k_unpack(const unsigned long long* __restrict__ packed, const float4* __restrict__ q, size_t n,
-         const float4* __restrict__ refs, int identity, int32_t* __restrict__ idx, float* __restrict__ d2) {
+         int32_t* __restrict__ idx, float* __restrict__ d2) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         unsigned long long p = packed[i];
         bool ok = (!q || __float_as_int(q[i].w) >= 0) && p != ~0ull;
-        unsigned int pos = (unsigned int)(p & 0xffffffffull);
-        if (idx) idx[i] = ok ? (identity ? (int32_t)pos : __float_as_int(refs[pos].w)) : -1;
+        if (idx) idx[i] = ok ? (int32_t)(unsigned int)(p & 0xffffffffull) : -1;
         if (d2) d2[i] = ok ? __uint_as_float((unsigned int)(p >> 32)) : __builtin_inff();
     }
 }
 int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
-                  const float4* refs, bool identity, int32_t* idx, float* d2) {
+                  int32_t* idx, float* d2) {
     if (n == 0) return PCC_OK;
-    hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, s, packed, q, n, refs, identity ? 1 : 0, idx, d2);
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for(n, 256)), dim3(256), 0, s, packed, q, n, idx, d2);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
@@ -312,10 +275,10 @@ k_sor_mean(const unsigned long long* __restrict__ keys, const float4* __restrict
            float* __restrict__ mean_dist) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned long long* row = keys + i * (size_t)K;
-        if (row[K - 1] == ~0ull) continue;  // fewer than K neighbours: distance stays 0
+        if (row[K - 1] == ~0ull) continue;  // invalid point or fewer than K neighbours: distance stays 0
         double s = 0.0;
         for (int j = 1; j < K; ++j) s += sqrt((double)__uint_as_float((unsigned int)(row[j] >> 32)));
-        mean_dist[__float_as_int(refs[i].w)] = (float)(s / (double)(K - 1));
+        mean_dist[i] = (float)(s / (double)(K - 1));
     }
 }
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,

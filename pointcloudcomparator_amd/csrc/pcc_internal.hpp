@@ -46,6 +46,18 @@ struct GridParams {
 };
 
 
+// Device-resident description of the grid, written by k_grid_params from the pack kernel's
+// per-workgroup statistics.  The host never waits for it on the build path: launches are sized
+// from upper bounds it knows (n, nc_cap) and kernels read the actual values from here.
+struct GridDev {
+    GridParams g;
+    float slack;            // absolute slack of the outside-of-cube bound (cell-boundary rounding)
+    unsigned int n_valid;   // finite points (PCL total_nr_points_)
+    unsigned int n_invalid;
+    float lo[3], hi[3];     // bounding box of the valid points
+    unsigned int pad_;
+};
+
 }  // namespace pcc
 
 #define PCC_EV_SLOTS 64
@@ -55,12 +67,19 @@ struct pcc_index {
     int device = 0;
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // library-owned stream
-    size_t n_orig = 0;                 // points handed to pcc_index_create
-    size_t n_valid = 0;                // finite points (PCL total_nr_points_)
+    size_t n_orig = 0;                 // points handed to pcc_index_create / set_input
+    size_t n_valid = 0;                // finite points (PCL total_nr_points_); valid after sync_info()
+    unsigned int nc_cap = 0;           // upper bound of the grid's cell count the host sizes launches with
+    pcc::DevBuf d_grid;                // GridDev on the device
+    pcc::GridDev* h_grid = nullptr;    // pinned host mirror, filled asynchronously
+    bool stats_pending = false;        // fallback counter of the last GRID search in flight to pinned[40]
+    size_t last_nq = 0;
+    bool info_pending = false;         // h_grid copy in flight: sync before reading n_valid / grid / bbox
     int engine = PCC_ENGINE_BRUTE;     // resolved engine
     int engine_requested = PCC_ENGINE_AUTO;
     float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the valid points
-    // packed references in ORIGINAL order: (x, y, z, bits(orig index)); n_valid entries
+    // references in ORIGINAL order: (x, y, z, bits(index)), n_orig entries; non-finite points stay
+    // in place flagged w = -1 (every kernel skips them), so position == original index
     pcc::DevBuf refs;
     // GRID engine: references permuted into cell order + CSR cell starts
     bool has_grid = false;
@@ -103,17 +122,13 @@ inline void ev_next(pcc_index* ix) {
 constexpr int PACK_MAX_BLOCKS = 1024;
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
                 float* blk_stats, int* n_blocks);
-// order-preserving compaction of the entries with w >= 0 (stable); d_count gets the
-// number kept.  tmp needs (n/1024 + 2) * 4 * 2 bytes.
-int launch_compact(hipStream_t s, const float4* in, size_t n, float4* out,
-                   unsigned int* d_count, DevBuf& tmp);
 // exclusive scan of uint32 data[n] in place; data[n] receives the total when
 // write_total.  tmp is grown as needed.
 int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
 // packed u64 keys (d2 bits << 32 | packed position) -> original idx, d2; n keys; q (nullable,
 // one per key) flags invalid queries (w < 0) which get -1/+inf, as do empty keys (~0)
 int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
-                  const float4* refs, bool identity, int32_t* idx, float* d2);
+                  int32_t* idx, float* d2);
 int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[16],
                      const void* src, size_t n, size_t sstride, void* dst, size_t dstride);
 // dst[i].w = src[i].w (validity flags of packed points)
@@ -133,7 +148,10 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
                      const unsigned int* qcount_dev, size_t qcount_max);
 
 // ---- grid.hip --------------------------------------------------------------------------
-int grid_build(pcc_index* ix, const float lo[3], const float hi[3]);
+int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks);  // async: d_grid + pinned mirror
+int grid_build(pcc_index* ix);                                             // async: cell sort of the references
+int sync_info(pcc_index* ix);                                              // wait for the pinned mirror, refresh host fields
+unsigned int grid_nc_cap(size_t n);
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out);
 // sort queries by reference-grid cell: order[0..*n_sorted) (device) lists the valid queries
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
