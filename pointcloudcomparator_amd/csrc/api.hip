@@ -63,14 +63,15 @@ struct DeviceGuard {
 // Stage a caller cloud (host or device AoS) as packed float4 on the device.
 // host: one H2D copy of the raw AoS, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
-                        DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr) {
+                        DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr,
+                        unsigned int* zero_word = nullptr) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks);
+    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word);
 }
 
 static int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -84,7 +85,9 @@ static int check_points(const void* pts, size_t n, size_t stride, int mem) {
 // queries -> ix->q_packed (float4, w < 0 marks a non-finite query)
 static int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem) {
     PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
-    return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>());
+    // the pack kernel also zeroes the GRID engine's fallback counter (small + 32)
+    return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>(), nullptr, nullptr,
+                        ix->small.as<unsigned int>() + 32);
 }
 
 // deliver device results to the caller's memory space
@@ -104,8 +107,9 @@ static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) 
 static int nn1_packed(pcc_index* ix, size_t nq) {
     PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
     auto* out = ix->out_packed.as<unsigned long long>();
-    PCC_HIP(hipMemsetAsync(out, 0xff, nq * sizeof(unsigned long long), ix->stream));
+    // GRID: every valid query's key is written by the search kernel itself (no 8 MB memset)
     if (ix->engine == PCC_ENGINE_GRID) return grid_nn1(ix, ix->q_packed.as<float4>(), nq, out);
+    PCC_HIP(hipMemsetAsync(out, 0xff, nq * sizeof(unsigned long long), ix->stream));
     ix->stats[0] = 0;
     ix->stats[1] = nq;
     ix->stats_pending = false;
@@ -325,7 +329,8 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq, didx, dd2));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq, didx, dd2,
+                          ix->small.as<unsigned int>() + 32, static_cast<unsigned int*>(ix->pinned) + 40));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq, mem));

@@ -140,9 +140,9 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
 
 // ---- host side ------------------------------------------------------------------------------------
 // Sorts pts[0..n) by cell.  refs: out_pts (float4, w = position) + cell_start[ncells+1].
-// queries: out_order[0..n_sorted) lists the valid queries cell by cell; *n_sorted_dev (device) = count.
+// queries: out_order[0..n_sorted) lists the valid queries cell by cell; *n_sorted_dev = device address of the count.
 int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4* out_pts, unsigned int* out_order,
-              unsigned int* cell_start, unsigned int* n_sorted_dev) {
+              unsigned int* cell_start, unsigned int** n_sorted_dev) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)n_pts;
     // planned from the host-known upper bound of the cell count; buckets past the actual grid stay empty
@@ -163,7 +163,7 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
                        key_rank, H);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
-    if (n_sorted_dev) PCC_HIP(hipMemcpyAsync(n_sorted_dev, H + h_elems - 1, 4, hipMemcpyDeviceToDevice, s));
+    if (n_sorted_dev) *n_sorted_dev = H + h_elems - 1;  // grand total == number of valid points
     const size_t lds3 = ((size_t)p.F + 4) * sizeof(unsigned int);
     hipLaunchKernelGGL(k_cs_scatter, dim3(p.G), dim3(CS_T), 0, s, n, p.F, p.slice, key_rank, H, tmp_kv);
     if (refs)

@@ -42,7 +42,7 @@ unsigned int grid_nc_cap(size_t n) {
 // 385 us step at 1M points.
 __global__ void __launch_bounds__(256)
 k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap,
-              GridDev* __restrict__ out) {
+              GridDev* __restrict__ out, GridDev* __restrict__ host_mirror) {
     __shared__ float red[4][8];
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -115,6 +115,7 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
     for (int a = 0; a < 3; ++a) far = fmaxf(far, fmaxf(fabsf(g.org[a]), fabsf(g.org[a] + g.dim[a] * g.h)));
     d.slack = 4e-6f * far + 1e-6f * g.h;
     *out = d;
+    *host_mirror = d;  // pinned host memory: a separate 5 us D2H copy on the stream is avoided
 }
 
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
@@ -122,9 +123,8 @@ int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
     PCC_TRY(ix->d_grid.reserve(sizeof(GridDev)));
     ix->nc_cap = grid_nc_cap(ix->n_orig);
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
-                       ppc, ix->nc_cap, ix->d_grid.as<GridDev>());
+                       ppc, ix->nc_cap, ix->d_grid.as<GridDev>(), ix->h_grid);
     PCC_HIP(hipGetLastError());
-    PCC_HIP(hipMemcpyAsync(ix->h_grid, ix->d_grid.p, sizeof(GridDev), hipMemcpyDeviceToHost, ix->stream));
     ix->info_pending = true;
     return PCC_OK;
 }
@@ -287,6 +287,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     if (resolved) {
         out[qi] = best;
     } else {
+        out[qi] = ~0ull;  // the exhaustive pass merges into it with atomicMin
         unsigned int slot = atomicAdd(fb_count, 1u);
         fb_list[slot] = qi;
     }
@@ -296,11 +297,11 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
                       unsigned int** n_sorted_dev) {
     const unsigned int n = (unsigned int)nq;
-    unsigned int* n_sorted = ix->small.as<unsigned int>() + 36;
+    unsigned int* n_sorted = nullptr;  // points at the sort's grand total (stays valid until the next sort)
     ev_mark(ix, EV_SORT0);
     PCC_TRY(ix->scratch_g.reserve((size_t)n * sizeof(unsigned int) + 256));
     unsigned int* ord = ix->scratch_g.as<unsigned int>();
-    PCC_TRY(cell_sort(ix, q, nq, false, nullptr, ord, nullptr, n_sorted));
+    PCC_TRY(cell_sort(ix, q, nq, false, nullptr, ord, nullptr, &n_sorted));
     ev_mark(ix, EV_SORT1);
     *order_dev = ord;
     *n_sorted_dev = n_sorted;
@@ -312,8 +313,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     const unsigned int n = (unsigned int)nq;
     PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
     unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
-    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
-    PCC_HIP(hipMemsetAsync(fb_count, 0, 4, s));
+    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;  // zeroed by the query pack kernel
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
@@ -333,8 +333,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     ev_mark(ix, EV_FB0);
     PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_orig, q, n, out, fb_list, fb_count, n));
     ev_mark(ix, EV_FB1);
-    // counters for pcc_index_stats (read lazily): queries sent to the exhaustive fallback, sorted queries
-    PCC_HIP(hipMemcpyAsync(static_cast<unsigned int*>(ix->pinned) + 40, fb_count, 4, hipMemcpyDeviceToHost, s));
+    // pcc_index_stats reads the fallback count lazily (k_unpack mirrors it to pinned memory)
     ix->stats_pending = true;
     ix->last_nq = nq;
     return PCC_OK;

@@ -121,14 +121,15 @@ inline void ev_next(pcc_index* ix) {
 // [0] bits(invalid count), [1..3] min xyz, [4..6] max xyz of its valid points; *n_blocks rows.
 constexpr int PACK_MAX_BLOCKS = 1024;
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                float* blk_stats, int* n_blocks);
+                float* blk_stats, int* n_blocks, unsigned int* zero_word = nullptr);
 // exclusive scan of uint32 data[n] in place; data[n] receives the total when
 // write_total.  tmp is grown as needed.
 int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
 // packed u64 keys (d2 bits << 32 | packed position) -> original idx, d2; n keys; q (nullable,
 // one per key) flags invalid queries (w < 0) which get -1/+inf, as do empty keys (~0)
+// mirror (nullable): device word copied to *mirror_host (pinned) by the kernel -- fallback counter for stats
 int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
-                  int32_t* idx, float* d2);
+                  int32_t* idx, float* d2, const unsigned int* mirror_dev = nullptr, unsigned int* mirror_host = nullptr);
 int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[16],
                      const void* src, size_t n, size_t sstride, void* dst, size_t dstride);
 // dst[i].w = src[i].w (validity flags of packed points)
@@ -159,7 +160,7 @@ int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** 
 float grid_slack(const GridParams& g);
 // ---- cellsort.hip: LDS-based two-level counting sort by cell ---------------------------------------
 int cell_sort(pcc_index* ix, const float4* pts, size_t n, bool refs, float4* out_pts, unsigned int* out_order,
-              unsigned int* cell_start, unsigned int* n_sorted_dev);
+              unsigned int* cell_start, unsigned int** n_sorted_dev);
 // ---- knn.hip: k-NN, radius search (GRID engine) ----------------------------------------
 // keys[nq][K] (pre-set to ~0) receive the K smallest (d2, position) keys ascending
 int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys);
