@@ -151,7 +151,7 @@ static inline int grid1d(size_t n) {
 // cell-sort the references (asynchronous; launch sizes come from n_orig and nc_cap)
 int grid_build(pcc_index* ix) {
     const size_t n = ix->n_orig;
-    size_t cs_bytes = ((size_t)ix->nc_cap + 1 + 3) / 4 * 4 * sizeof(unsigned int);
+    size_t cs_bytes = ((size_t)ix->nc_cap + 1 + 3 + 4) / 4 * 4 * sizeof(unsigned int);  // + pad for 16-byte bound loads
     PCC_TRY(ix->cell_start.reserve(cs_bytes));
     PCC_TRY(ix->cell_refs.reserve(n * sizeof(float4) + 64));
     PCC_TRY(cell_sort(ix, ix->refs.as<float4>(), n, true, ix->cell_refs.as<float4>(), nullptr,
@@ -169,21 +169,22 @@ __device__ __forceinline__ unsigned long long fold(unsigned long long best, floa
     return key < best ? key : best;
 }
 
-// scan the contiguous span [s, e) of cell-sorted references.  Four independent 16-byte loads
-// are in flight per lane (the loop is latency-bound otherwise); the tail re-reads the last
-// point of the span, which cannot change the minimum.
+// scan the contiguous span [s, e) of cell-sorted references, U independent 16-byte loads in
+// flight per lane.  The kernel is bound by the L1/TA gather rate (a wave64 dwordx4 gather costs
+// ~16 clk whatever it fetches), so tail slots are PREDICATED OFF rather than clamped to a
+// duplicate address: an inactive lane costs the texture-address unit nothing.
 template <int U>
 __device__ __forceinline__ unsigned long long scan_span(const float4* __restrict__ cell_refs, unsigned int s,
                                                         unsigned int e, float qx, float qy, float qz,
                                                         unsigned long long best) {
-    if (s >= e) return best;
-    const unsigned int last = e - 1;
     for (unsigned int p = s; p < e; p += U) {
         float4 r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = cell_refs[min(p + u, last)];
+        for (int u = 0; u < U; ++u)
+            if (u == 0 || p + u < e) r[u] = cell_refs[p + u];
 #pragma unroll
-        for (int u = 0; u < U; ++u) best = fold(best, qx, qy, qz, r[u]);
+        for (int u = 0; u < U; ++u)
+            if (u == 0 || p + u < e) best = fold(best, qx, qy, qz, r[u]);
     }
     return best;
 }
@@ -212,7 +213,7 @@ __device__ __forceinline__ unsigned long long scan_box(const float4* __restrict_
     return best;
 }
 
-template <int U>
+template <int U, bool SEED_ROW>
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
            const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
@@ -233,9 +234,17 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
+    // ---- phase 0 (SEED_ROW): only the query's own row segment [cx-1, cx+1].  In dense regions it
+    // almost always yields a close candidate, and the ball around it (phase 2) then touches 1-4
+    // short rows instead of the nine rows of the full 3x3x3 cube: ~4x fewer distance evaluations.
+    if (SEED_ROW) {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        const unsigned int row = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0];
+        best = scan_span<U>(cell_refs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best);
+    }
     // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (18 independent loads, one
     // latency), then the rows are streamed.
-    {
+    if (!SEED_ROW || best == ~0ull) {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
         unsigned int rs[9], re[9];
 #pragma unroll
@@ -243,8 +252,13 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
             const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
             const bool ok = z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
             const unsigned int row = ((unsigned int)(ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
-            rs[i] = ok ? cell_start[row + x0] : 0u;
-            re[i] = ok ? cell_start[row + x1 + 1] : 0u;
+            // both bounds with ONE gather: x1 + 1 - x0 <= 3, so they sit in one (unaligned) 16-byte load
+            // (cell_start is padded by 4 entries); halves the bound-fetch instructions of sparse queries
+            uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) b4 = *reinterpret_cast<const uint4*>(cell_start + row + x0);
+            const int w = x1 + 1 - x0;
+            rs[i] = b4.x;
+            re[i] = w == 3 ? b4.w : (w == 2 ? b4.z : b4.y);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) best = scan_span<U>(cell_refs, rs[i], re[i], qx, qy, qz, best);
@@ -319,10 +333,18 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     ev_mark(ix, EV_MAIN0);
     static const int U = getenv("PCC_GRID_UNROLL") ? atoi(getenv("PCC_GRID_UNROLL")) : 4;
     const int BS = 256;
+    // row seeding (phase 0) measured slower than going straight to the cube once tail loads are
+    // predicated (151 vs 142 us at 1M x 1M); kept selectable for experiments
+    static const bool seed_row = getenv("PCC_GRID_SEED") && !strcmp(getenv("PCC_GRID_SEED"), "row");
 #define PCC_LAUNCH_NN1(UU)                                                                                       \
-    hipLaunchKernelGGL((k_grid_nn1<UU>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),     \
+    do { if (seed_row)                                                                                           \
+    hipLaunchKernelGGL((k_grid_nn1<UU, true>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(), \
                        ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,   \
-                       fb_list, fb_count)
+                       fb_list, fb_count);                                                                        \
+    else                                                                                                         \
+    hipLaunchKernelGGL((k_grid_nn1<UU, false>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(), \
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,   \
+                       fb_list, fb_count); } while (0)
     if (U == 1) PCC_LAUNCH_NN1(1);
     else if (U == 2) PCC_LAUNCH_NN1(2);
     else if (U == 8) PCC_LAUNCH_NN1(8);
