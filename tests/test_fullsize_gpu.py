@@ -1,0 +1,121 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties: engine-vs-engine
+bit identity, self-query idempotence, a CPU-oracle check on a fixed sample of the queries,
+shard-concatenation identity, and the known-by-construction cluster partition."""
+import numpy as np
+import pytest
+
+import oracle
+from pointcloudcomparator_amd import capi, sharding, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+def _sample_check(ref, qry, idx, d2, n_sample=20000, seed=123):
+    """fixed sample of the queries against the CPU kd-tree restatement (bit-exact)"""
+    rng = np.random.default_rng(seed)
+    sel = np.sort(rng.choice(len(qry), size=min(n_sample, len(qry)), replace=False))
+    tree = oracle.KdTree(ref)
+    oi, od = tree.nn1_batch(np.ascontiguousarray(qry[sel]))
+    assert (_bits(d2[sel]) == _bits(od)).all()
+    diff = np.nonzero(idx[sel] != oi)[0]
+    for j in diff:  # an index may differ only between exact-distance ties, lowest index on the GPU side
+        assert idx[sel][j] < oi[j]
+        assert _bits(oracle.nn1_exhaustive(ref[oi[j]:oi[j] + 1], qry[sel][j:j + 1])[1])[0] == _bits(od)[j]
+
+
+def test_c2_1m_x_1m_grid_vs_brute_vs_oracle_sample(gpu):
+    a = synth.corridor_cloud(1_000_000, synth.SEED_A)
+    b = synth.corridor_cloud(1_000_000, synth.SEED_B)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with capi.Index(ta, engine=capi.ENGINE_GRID) as ix:
+        gi, gd = ix.nn1(tb)
+        ix.sync()
+        assert ix.stats()[1] == 0 or ix.stats()[1] < 1000  # the cell walk resolves (almost) everything
+        ix.set_engine(capi.ENGINE_BRUTE)
+        bi, bd = ix.nn1(tb)
+        ix.sync()
+    assert bool((gi == bi).all()) and bool((gd.view(torch.int32) == bd.view(torch.int32)).all())
+    _sample_check(a, b, gi.cpu().numpy(), gd.cpu().numpy())
+
+
+def test_self_query_is_identity(gpu):
+    a = synth.corridor_cloud(2_000_000, synth.SEED_A)
+    ta = torch.from_numpy(a).cuda()
+    with capi.Index(ta) as ix:
+        idx, d2 = ix.nn1(ta)
+        ix.sync()
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    assert (d2 == 0).all()
+    # a point's NN in its own cloud is itself unless an exact duplicate with a lower index exists
+    moved = np.nonzero(idx != np.arange(len(a)))[0]
+    assert (idx[moved] < moved).all() and (a[idx[moved]] == a[moved]).all()
+
+
+def test_c3_10m_xyzrgb_stride_sampled(gpu):
+    a = synth.with_rgb_stride(synth.corridor_cloud(10_000_000, synth.SEED_A))
+    b = synth.with_rgb_stride(synth.corridor_cloud(10_000_000, synth.SEED_B))
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with capi.Index(ta) as ix:
+        idx, d2 = ix.nn1(tb)
+        ix.sync()
+    _sample_check(a, b, idx.cpu().numpy(), d2.cpu().numpy(), n_sample=10000)
+
+
+def test_c3_object_layer_clusters_known_partition(gpu):
+    # 5M points of the object layer: the 256 balls are the clusters by construction
+    pts = synth.corridor_cloud(5_000_000, synth.SEED_A, layer="objects")
+    with capi.Index(torch.from_numpy(pts).cuda()) as ix:
+        labels, ncl, sizes = ix.euclidean_clusters(0.05, 100, 250000)
+    assert ncl == synth.N_BALLS and sizes.sum() == len(pts) and (np.diff(sizes) <= 0).all()
+    centres = synth.ball_centres()
+    # every cluster's points lie within one ball, and distinct clusters sit in distinct balls
+    first = np.array([np.argmax(labels == k) for k in range(0, ncl, 17)])
+    owner = np.linalg.norm(pts[first][:, None, :] - centres[None], axis=2).argmin(1)
+    assert len(set(owner)) == len(owner)
+    sub = np.arange(0, len(pts), 997)
+    ball_of = np.linalg.norm(pts[sub][:, None, :] - centres[None], axis=2).argmin(1)
+    lab = labels[sub]
+    for bidx in np.unique(ball_of)[:40]:
+        assert len(np.unique(lab[ball_of == bidx])) == 1
+
+
+def test_c5_shards_concatenate_to_the_unsharded_result(gpu):
+    a = synth.corridor_cloud(2_000_000, synth.SEED_A)
+    b = synth.corridor_cloud(1_000_003, synth.SEED_B)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with capi.Index(ta) as ix:
+        fi, fd = ix.nn1(tb)
+        ix.sync()
+        parts = []
+        for r in range(8):
+            s, c = sharding.shard_range(len(b), r, 8)
+            i_, d_ = ix.nn1(tb[s:s + c])
+            ix.sync()
+            parts.append((i_.clone(), d_.clone()))
+    ci = torch.cat([p[0] for p in parts])
+    cd = torch.cat([p[1] for p in parts])
+    assert bool((ci == fi).all()) and bool((cd.view(torch.int32) == fd.view(torch.int32)).all())
+
+
+def test_c4_icp_fixed_iterations_consistent_with_stepwise(gpu):
+    tgt = synth.corridor_cloud(500_000, synth.SEED_A)
+    src = synth.rigid_offset(synth.corridor_cloud(200_000, synth.SEED_B), rot_deg=0.3, t=(0.01, -0.01, 0.005))
+    tt, ts = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
+    with capi.Index(tt) as ix:
+        T, fit, it, conv = ix.icp_align(ts, max_iter=10, fixed=True)
+        # replay the same loop through the step API: identical correspondences => identical transform
+        cur = ts.clone()
+        Tacc = np.eye(4, dtype=np.float32)
+        for _ in range(10):
+            _, _, sums = ix.icp_step(cur, want_corr=False)
+            rc, Ti = oracle.umeyama_from_sums(sums)
+            assert rc == 0
+            cur = ix.transform(Ti, cur)
+            Tacc = (Ti @ Tacc).astype(np.float32)
+    assert it == 10 and conv
+    assert np.allclose(T, Tacc, atol=5e-5)
