@@ -11,12 +11,13 @@ LIBDIR     := pointcloudcomparator_amd/lib
 HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip)
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 
-all: lib oracle hosttest
+all: lib oracle hosttest cli
 
 lib: $(LIBDIR)/libpcc_nn.so
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu
 hosttest: build/test_host_mirror
+cli: build/comparator build/ply_dump
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp include/pcc_nn.h
 	@mkdir -p build
@@ -38,7 +39,15 @@ build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.h
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -Iinclude $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
+build/comparator: pointcloudcomparator_amd/host/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+build/ply_dump: tests/cpp/ply_dump.cpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc/point_types.hpp
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Ipointcloudcomparator_amd/host $< -o $@
+
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/_build
 
-.PHONY: all lib oracle ubench hosttest clean
+.PHONY: all lib oracle ubench hosttest cli clean
