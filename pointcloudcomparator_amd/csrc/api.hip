@@ -86,6 +86,7 @@ static int check_points(const void* pts, size_t n, size_t stride, int mem) {
 static int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem) {
     PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
     // the pack kernel also zeroes the GRID engine's fallback counter (small + 32)
+    ix->fb_zeroed = true;
     return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>(), nullptr, nullptr,
                         ix->small.as<unsigned int>() + 32);
 }
@@ -171,7 +172,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->d_grid};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->d_grid, &ix->seeds};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -207,6 +208,7 @@ int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem,
     if ((st = ix->blk_stats.reserve(PACK_MAX_BLOCKS * 8 * sizeof(float))) != PCC_OK) return fail(st);
     ix->engine_requested = engine;
     ix->engine = engine;
+    memset(ix->pinned, 0, PACK_MAX_BLOCKS * 8 * sizeof(float) + 4096);
     if (hipHostMalloc((void**)&ix->h_grid, sizeof(GridDev), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
     memset(ix->h_grid, 0, sizeof(GridDev));
     if ((st = set_input(ix, pts, n, stride, mem)) != PCC_OK) return fail(st);
@@ -527,7 +529,9 @@ static int icp_reduce(pcc_index* ix, size_t n, double sums[17]) {
     PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
     int nb = 0;
     PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
-                            ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb));
+                            ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
+                            ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
+                            static_cast<unsigned int*>(ix->pinned) + 40));
     std::vector<double> h((size_t)nb * 17);
     PCC_HIP(hipMemcpyAsync(h.data(), ix->scratch_a.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
     PCC_HIP(hipStreamSynchronize(ix->stream));

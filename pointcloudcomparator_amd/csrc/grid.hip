@@ -148,6 +148,18 @@ static inline int grid1d(size_t n) {
     return (int)b;
 }
 
+constexpr int SEED_STRIDE = 64;
+constexpr int FAR_SPAN = 1024;
+
+__global__ void __launch_bounds__(256)
+k_make_seeds(const float4* __restrict__ refs, unsigned int n, float4* __restrict__ seeds, unsigned int n_seeds) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_seeds; i += gridDim.x * blockDim.x) {
+        float4 v = refs[min(i * SEED_STRIDE, n - 1)];
+        if (__float_as_int(v.w) >= 0) v.w = __int_as_float((int)min(i * SEED_STRIDE, n - 1));
+        seeds[i] = v;  // a non-finite reference stays flagged (w < 0) and is skipped by the scan
+    }
+}
+
 // cell-sort the references (asynchronous; launch sizes come from n_orig and nc_cap)
 int grid_build(pcc_index* ix) {
     const size_t n = ix->n_orig;
@@ -156,6 +168,11 @@ int grid_build(pcc_index* ix) {
     PCC_TRY(ix->cell_refs.reserve(n * sizeof(float4) + 64));
     PCC_TRY(cell_sort(ix, ix->refs.as<float4>(), n, true, ix->cell_refs.as<float4>(), nullptr,
                       ix->cell_start.as<unsigned int>(), nullptr));
+    const unsigned int n_seeds = (unsigned int)((n + SEED_STRIDE - 1) / SEED_STRIDE);
+    PCC_TRY(ix->seeds.reserve((size_t)n_seeds * sizeof(float4)));
+    hipLaunchKernelGGL(k_make_seeds, dim3(grid1d(n_seeds)), dim3(256), 0, ix->stream, ix->refs.as<float4>(), (unsigned int)n,
+                       ix->seeds.as<float4>(), n_seeds);
+    PCC_HIP(hipGetLastError());
     ix->has_grid = true;
     return PCC_OK;
 }
@@ -307,6 +324,94 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
+// ---- far queries -------------------------------------------------------------------------------
+// A query whose neighbourhood is empty for KMAX cells, or whose nearest point lies further than
+// KMAX cells (a source cloud that is still misaligned in ICP, points outside the reference's
+// bounding box), used to go straight to the exhaustive kernel: 11k such queries out of 2M cost
+// 3.4 ms against 0.34 ms for the other 1.99M.  Now they take three steps:
+//   1. exhaustive scan of the SEEDS only (every 64th reference): an upper bound on the NN distance
+//   2. k_grid_far: walk the cells the ball of that radius touches, pruning whole rows by their
+//      y/z distance and clipping every row's x-range to the chord of the (shrinking) ball
+//   3. only if the ball spans more than FAR_SPAN cells per axis: the exhaustive kernel
+// distance from coordinate v to the interval of cell c along one axis (0 inside), shrunk by slack
+__device__ __forceinline__ float axis_gap(float v, int c, float org, float h, float slack) {
+    const float lo = org + c * h, hi = org + (c + 1) * h;
+    return fmaxf(fmaxf(lo - v, v - hi) - slack, 0.f);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int lo = __shfl_xor((unsigned int)v, off, 64);
+        const unsigned int hi = __shfl_xor((unsigned int)(v >> 32), off, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// One WAVE per far query.  Rows of cells are visited ring by ring around the query's (clamped)
+// row, one row per lane; after every ring the lanes share their best key, so the ball -- and with
+// it each row's x-chord and the number of rings still needed -- shrinks as fast as points are
+// found.  Ring rho is skipped entirely once (rho-1) cell edges exceed the current best distance.
+template <int U>
+__global__ void __launch_bounds__(256)
+k_grid_far(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+           const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ list,
+           const unsigned int* __restrict__ count, unsigned long long* __restrict__ out,
+           unsigned int* __restrict__ list2, unsigned int* __restrict__ count2) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    const unsigned int cnt = *count;
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned int t = wave; t < cnt; t += nwaves) {  // wave-uniform loop
+        const unsigned int qi = list[t];
+        const float4 qv = q[qi];
+        const float qx = qv.x, qy = qv.y, qz = qv.z;
+        unsigned long long best = out[qi];  // from the seed scan: a real point, hence a valid upper bound
+        bool exhaustive = best == ~0ull;
+        const float rb0 = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
+        if (!exhaustive && !(rb0 * g.inv_h < (float)FAR_SPAN)) exhaustive = true;  // ball too large for a cell walk
+        if (!exhaustive) {
+            const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+            const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+            const int rho_max = max(max(cy, g.dim[1] - 1 - cy), max(cz, g.dim[2] - 1 - cz));
+            for (int rho = 0; rho <= rho_max; ++rho) {
+                const float bd = __uint_as_float((unsigned int)(best >> 32));
+                if (rho >= 1) {
+                    const float reach = fmaxf((float)(rho - 1) * g.h - slack, 0.f);
+                    if (reach * reach >= bd * 1.00002f) break;  // every remaining ring is farther than the best
+                }
+                const int nring = rho == 0 ? 1 : 8 * rho;
+                for (int r = (int)lane; r < nring; r += 64) {
+                    int dy, dz;
+                    if (rho == 0) { dy = 0; dz = 0; }
+                    else if (r < 2 * rho + 1) { dz = -rho; dy = r - rho; }
+                    else if (r < 2 * (2 * rho + 1)) { dz = rho; dy = r - (2 * rho + 1) - rho; }
+                    else if (r < 2 * (2 * rho + 1) + (2 * rho - 1)) { dy = -rho; dz = r - 2 * (2 * rho + 1) - rho + 1; }
+                    else { dy = rho; dz = r - 2 * (2 * rho + 1) - (2 * rho - 1) - rho + 1; }
+                    const int y = cy + dy, z = cz + dz;
+                    if (y < 0 || y >= g.dim[1] || z < 0 || z >= g.dim[2]) continue;
+                    const float gy = axis_gap(qy, y, g.org[1], g.h, slack), gz = axis_gap(qz, z, g.org[2], g.h, slack);
+                    const float lbd = __uint_as_float((unsigned int)(best >> 32));
+                    const float rem = lbd * 1.00002f - (gz * gz + gy * gy);
+                    if (!(rem > 0.f)) continue;  // the whole row is at least as far as the current best
+                    int rx0, rx1;
+                    cell_range(qx, sqrtf(rem) + slack, g.org[0], g.inv_h, g.dim[0], rx0, rx1);
+                    const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                    best = scan_span<U>(cell_refs, cell_start[row + rx0], cell_start[row + rx1 + 1], qx, qy, qz, best);
+                }
+                best = wave_min_u64(best);
+            }
+            if (lane == 0) out[qi] = best;
+        } else if (lane == 0) {
+            out[qi] = ~0ull;
+            list2[atomicAdd(count2, 1u)] = qi;
+        }
+    }
+}
+
 // sort the queries by reference-grid cell so neighbouring lanes walk the same rows
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
                       unsigned int** n_sorted_dev) {
@@ -325,9 +430,13 @@ int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** 
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)nq;
-    PCC_TRY(ix->scratch_d.reserve((size_t)n * sizeof(unsigned int) + 256));
+    PCC_TRY(ix->scratch_d.reserve(((size_t)n * 2 + 128) * sizeof(unsigned int) + 256));
     unsigned int* fb_list = ix->scratch_d.as<unsigned int>();
-    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;  // zeroed by the query pack kernel
+    unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
+    // zeroed by the query pack kernel of this call; searches that re-use packed queries (the ICP
+    // loop transforms them in place) have no pack and zero it here
+    if (!ix->fb_zeroed) PCC_HIP(hipMemsetAsync(fb_count, 0, 4, s));
+    ix->fb_zeroed = false;
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
@@ -351,9 +460,31 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     else PCC_LAUNCH_NN1(4);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
-    // queries the cell walk could not resolve: exhaustive scan over the original-order references
+    // queries the cell walk could not resolve.  When an earlier search on this index had such
+    // queries (count mirrored to pinned memory by k_unpack; read here WITHOUT waiting, it only
+    // steers the choice), take the seed + ball-walk route; otherwise go straight to the exhaustive
+    // kernel, which costs one launch when the list is empty
     ev_mark(ix, EV_FB0);
-    PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_orig, q, n, out, fb_list, fb_count, n));
+    const unsigned int seen = static_cast<volatile unsigned int*>(ix->pinned)[40];
+    if (seen > ix->last_fallback_seen) ix->last_fallback_seen = seen;
+    static const int far_mode = getenv("PCC_GRID_FAR") ? atoi(getenv("PCC_GRID_FAR")) : -1;  // -1 auto, 0 off, 1 on
+    const bool far = far_mode == 1 || (far_mode == -1 && ix->last_fallback_seen >= 64);
+    if (far) {
+        unsigned int* fb2_list = fb_list + n + 64;
+        unsigned int* fb2_count = ix->small.as<unsigned int>() + 33;
+        PCC_HIP(hipMemsetAsync(fb2_count, 0, 4, s));
+        const size_t n_seeds = (ix->n_orig + SEED_STRIDE - 1) / SEED_STRIDE;
+        PCC_TRY(launch_nn1_brute(s, ix->seeds.as<float4>(), n_seeds, q, n, out, fb_list, fb_count, n, true));
+        unsigned int gfar = (n + 3) / 4;  // one wave per listed query, 4 waves per workgroup
+        if (gfar > 2048) gfar = 2048;
+        hipLaunchKernelGGL((k_grid_far<4>), dim3(gfar), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, fb_list, fb_count, out,
+                           fb2_list, fb2_count);
+        PCC_HIP(hipGetLastError());
+        PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_orig, q, n, out, fb2_list, fb2_count, n));
+    } else {
+        PCC_TRY(launch_nn1_brute(s, ix->refs.as<float4>(), ix->n_orig, q, n, out, fb_list, fb_count, n));
+    }
     ev_mark(ix, EV_FB1);
     // pcc_index_stats reads the fallback count lazily (k_unpack mirrors it to pinned memory)
     ix->stats_pending = true;

@@ -13,7 +13,9 @@ namespace pcc {
 
 __global__ void __launch_bounds__(256)
 k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long long* __restrict__ keys,
-           const float4* __restrict__ refs, double* __restrict__ partials) {
+           const float4* __restrict__ refs, double* __restrict__ partials, const unsigned int* __restrict__ mirror_dev,
+           unsigned int* __restrict__ mirror_host) {
+    if (mirror_dev && blockIdx.x == 0 && threadIdx.x == 0) *mirror_host = *mirror_dev;  // fallback count for the far-query heuristic
     double acc[17];
 #pragma unroll
     for (int k = 0; k < 17; ++k) acc[k] = 0.0;
@@ -45,12 +47,13 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
 }
 
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
-                    const float4* refs, double* partials, int* n_blocks) {
+                    const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev,
+                    unsigned int* mirror_host) {
     size_t b = (n + 256 * 8 - 1) / (256 * 8);
     if (b < 1) b = 1;
     if (b > ICP_MAX_BLOCKS) b = ICP_MAX_BLOCKS;
     *n_blocks = (int)b;
-    hipLaunchKernelGGL(k_icp_sums, dim3((unsigned)b), dim3(256), 0, s, src, (unsigned int)n, keys, refs, partials);
+    hipLaunchKernelGGL(k_icp_sums, dim3((unsigned)b), dim3(256), 0, s, src, (unsigned int)n, keys, refs, partials, mirror_dev, mirror_host);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

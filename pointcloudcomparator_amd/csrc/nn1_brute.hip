@@ -50,7 +50,7 @@ template <int Q>
 __global__ void __launch_bounds__(BR_T)
 k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_split, unsigned int splits,
             const float4* __restrict__ q, unsigned int n, unsigned long long* __restrict__ out,
-            const unsigned int* __restrict__ qlist, const unsigned int* __restrict__ qcount_dev) {
+            const unsigned int* __restrict__ qlist, const unsigned int* __restrict__ qcount_dev, int idx_from_w) {
     __shared__ __attribute__((aligned(16))) float tile[2][3][BR_TILE];  // SoA: x[], y[], z[]
     const unsigned int nq = qlist ? min(*qcount_dev, n) : n;
     const unsigned int nqb = (nq + BR_T * Q - 1) / (BR_T * Q);
@@ -146,7 +146,7 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
         if (bchunk[k] < 0) {
             // every distance overflowed to +inf: the oracle keeps the first valid reference
             for (unsigned int p = rbeg; p < rend; ++p)
-                if (__float_as_int(refs[p].w) >= 0) { widx = p; break; }
+                if (__float_as_int(refs[p].w) >= 0) { widx = idx_from_w ? (unsigned int)__float_as_int(refs[p].w) : p; break; }
             if (widx == 0xffffffffu) continue;  // no valid reference in this split
         } else {
             unsigned int base = rbeg + (unsigned int)bchunk[k] * BR_CH;
@@ -155,7 +155,7 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
                 if (p >= rend) break;
                 float4 r = refs[p];
                 if (__float_as_int(r.w) >= 0 && dist2(qx[k], qy[k], qz[k], r) == best[k]) {
-                    widx = p;  // packed position; positions ascend with the original index
+                    widx = idx_from_w ? (unsigned int)__float_as_int(r.w) : p;  // position == original index
                     break;
                 }
             }
@@ -169,7 +169,7 @@ k_nn1_brute(const float4* __restrict__ refs, unsigned int m, unsigned int per_sp
 template <int Q>
 static int launch_q(hipStream_t s, const float4* refs, size_t m, const float4* q, size_t n,
                     unsigned long long* out, const unsigned int* qlist,
-                    const unsigned int* qcount_dev, unsigned int splits, unsigned int max_grid) {
+                    const unsigned int* qcount_dev, unsigned int splits, unsigned int max_grid, int idx_from_w = 0) {
     unsigned int qblocks = (unsigned int)((n + (size_t)BR_T * Q - 1) / ((size_t)BR_T * Q));
     unsigned int per_split = (unsigned int)((m + splits - 1) / splits);
     per_split = (per_split + BR_TILE - 1) / BR_TILE * BR_TILE;
@@ -177,14 +177,14 @@ static int launch_q(hipStream_t s, const float4* refs, size_t m, const float4* q
     unsigned long long total = (unsigned long long)qblocks * splits;
     unsigned int grid = (unsigned int)(total < max_grid ? total : max_grid);
     hipLaunchKernelGGL(k_nn1_brute<Q>, dim3(grid), dim3(BR_T), 0, s, refs, (unsigned int)m, per_split, splits,
-                       q, (unsigned int)n, out, qlist, qcount_dev);
+                       q, (unsigned int)n, out, qlist, qcount_dev, idx_from_w);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
 
 int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* q, size_t n,
                      unsigned long long* out, const unsigned int* qlist,
-                     const unsigned int* qcount_dev, size_t qcount_max) {
+                     const unsigned int* qcount_dev, size_t qcount_max, bool idx_from_w) {
     size_t nq = qlist ? qcount_max : n;
     if (nq == 0 || m == 0) return PCC_OK;
     if (m >= (1ull << 31) || n >= (1ull << 32)) { set_error("cloud too large for 32-bit indices"); return PCC_ERR_UNSUPPORTED; }
@@ -196,7 +196,7 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
         size_t splits = m / (4 * BR_TILE);
         if (splits < 1) splits = 1;
         if (splits > 1024) splits = 1024;
-        return launch_q<2>(s, refs, m, q, qcount_max, out, qlist, qcount_dev, (unsigned)splits, 2048);
+        return launch_q<2>(s, refs, m, q, qcount_max, out, qlist, qcount_dev, (unsigned)splits, 2048, idx_from_w ? 1 : 0);
     }
     // queries per lane: as many as still leave >= 1024 workgroups (4 per CU) in flight
     int Q = 1;

@@ -86,6 +86,9 @@ struct pcc_index {
     pcc::GridParams grid{};
     pcc::DevBuf cell_refs;   // float4[n_valid], cell-sorted, .w = orig index
     pcc::DevBuf cell_start;  // uint32[ncells + 1]
+    pcc::DevBuf seeds;       // float4[ceil(n/64)]: every 64th reference (w = its position) -- upper bounds for far queries
+    bool fb_zeroed = false;  // the query pack kernel of this call already zeroed the fallback counter
+    unsigned int last_fallback_seen = 0;  // fallback count of an earlier search (heuristic only, may be stale)
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
         scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src;
@@ -144,9 +147,10 @@ int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4*
 // squared distance, lowest original index on ties, merged into out[i] with a 64-bit
 // atomicMin (out must be pre-set to ~0).  If qlist != nullptr only the queries
 // qlist[0..*qcount) are processed (GRID fallback list; count read on device).
+// idx_from_w (list mode only): report refs[p].w as the index instead of p (seed subset, see grid.hip)
 int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* q,
                      size_t n, unsigned long long* out, const unsigned int* qlist,
-                     const unsigned int* qcount_dev, size_t qcount_max);
+                     const unsigned int* qcount_dev, size_t qcount_max, bool idx_from_w = false);
 
 // ---- grid.hip --------------------------------------------------------------------------
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks);  // async: d_grid + pinned mirror
@@ -173,7 +177,8 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
 // ---- icp.hip -----------------------------------------------------------------------------
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
-                    const float4* refs, double* partials, int* n_blocks);
+                    const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev = nullptr,
+                    unsigned int* mirror_host = nullptr);
 constexpr int ICP_MAX_BLOCKS = 512;
 
 }  // namespace pcc

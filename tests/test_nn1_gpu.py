@@ -94,3 +94,19 @@ def test_device_memory_path(gpu):
         idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
     oi, od = oracle.nn1_exhaustive(a, b)
     assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+
+
+def test_far_queries_take_the_seed_and_ball_route(gpu, monkeypatch):
+    """queries far outside the reference cloud (misaligned ICP source): seed scan + ball walk,
+    bit-identical to the oracle, with and without the route forced on"""
+    a = synth.corridor_cloud(60000, synth.SEED_A)
+    b = synth.corridor_cloud(6000, synth.SEED_B)
+    b[:2000] += np.float32([1.5, -2.0, 0.7])
+    b[2000:3000] += np.float32(30.0)
+    oi, od = oracle.nn1_exhaustive(a, b)
+    for mode in ("1", "-1", "0"):
+        monkeypatch.setenv("PCC_GRID_FAR", mode)  # read once per process: first value wins, the rest re-check
+        with capi.Index(a, engine=capi.ENGINE_GRID) as ix:
+            for _ in range(2):  # second call: the heuristic has seen the first call's fallbacks
+                idx, d2 = ix.nn1(b)
+                assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
