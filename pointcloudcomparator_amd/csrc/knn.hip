@@ -14,6 +14,7 @@
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
 #include <cmath>
+#include <cstring>
 
 namespace pcc {
 
@@ -97,6 +98,170 @@ k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
+// ---- wave-cooperative k-NN (K <= 128) ---------------------------------------------------------
+// One WAVE per query.  The 64 lanes read a row's candidates with ONE coalesced load, turn them
+// into (d2, position) keys, drop everything not below the current K-th key (tau), and compact
+// the survivors into a small LDS staging buffer (ballot + prefix count).  Whenever 64 survivors
+// have gathered they are bitonic-sorted across the lanes and merged into the running top list
+// (64*KR keys, one/two registers per lane, ascending across lanes) with the classic
+// min(L[i], B[63-i]) half-cleaner followed by a 6-stage bitonic merge; tau tightens and after the
+// first few batches almost every candidate dies at the compare.  The per-lane list kernel below
+// did O(K) global-memory traffic per insertion: 90 ms for 1M points at k = 51.
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned int lo = __shfl_xor((unsigned int)v, m, 64);
+    const unsigned int hi = __shfl_xor((unsigned int)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    const unsigned int lo = __shfl((unsigned int)v, src, 64);
+    const unsigned int hi = __shfl((unsigned int)(v >> 32), src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long cmpx(unsigned long long v, int m, bool take_min) {
+    const unsigned long long o = shfl_xor_u64(v, m);
+    const bool o_less = o < v;
+    return (o_less == take_min) ? o : v;
+}
+__device__ __forceinline__ unsigned long long bitonic_sort64(unsigned long long v, unsigned int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const bool up = (lane & k2) == 0, lower = (lane & j) == 0;
+            v = cmpx(v, j, lower == up);
+        }
+    return v;  // ascending over the lanes
+}
+__device__ __forceinline__ unsigned long long bitonic_merge64(unsigned long long v, unsigned int lane) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) v = cmpx(v, j, (lane & j) == 0);
+    return v;  // bitonic in -> ascending out
+}
+
+template <int KR>
+__device__ __forceinline__ void topk_merge(unsigned long long (&top)[KR], unsigned long long batch, unsigned int lane) {
+    batch = bitonic_sort64(batch, lane);
+    unsigned long long rev = shfl_u64(batch, 63 - (int)lane);
+    unsigned long long lo = rev < top[0] ? rev : top[0];
+    unsigned long long hi = rev < top[0] ? top[0] : rev;
+    top[0] = bitonic_merge64(lo, lane);
+    if (KR > 1) {
+        hi = bitonic_merge64(hi, lane);
+        rev = shfl_u64(hi, 63 - (int)lane);
+        lo = rev < top[KR - 1] ? rev : top[KR - 1];
+        top[KR - 1] = bitonic_merge64(lo, lane);
+    }
+}
+
+template <int KR>
+__global__ void __launch_bounds__(256)
+k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+                const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+                const unsigned int* __restrict__ n_sorted_ptr, int K, unsigned long long* __restrict__ keys) {
+    static_assert(KR == 1 || KR == 2, "top list lives in one or two registers per lane");
+    __shared__ unsigned long long stage_all[4][128];
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    const unsigned int n_valid = gd->n_valid;
+    const unsigned int ns = *n_sorted_ptr;
+    if (n_valid == 0) return;
+    const unsigned int lane = threadIdx.x & 63;
+    unsigned long long* stage = stage_all[threadIdx.x >> 6];
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
+        const unsigned int qi = order[t];
+        const float4 qv = q[qi];
+        const float qx = qv.x, qy = qv.y, qz = qv.z;
+        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+        // smallest cube whose inscribed ball should already hold `want` points at the local density
+        int k = 1;
+        for (;; ++k) {
+            const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+            const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+            const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+            unsigned int cnt = 0;
+            for (int r = (int)lane; r < nrow; r += 64) {
+                const unsigned int row = ((unsigned int)(z0 + r / ny) * g.dim[1] + (y0 + r % ny)) * g.dim[0];
+                cnt += cell_start[row + x1 + 1] - cell_start[row + x0];
+            }
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            const float kk = (float)k, side = 2.f * kk + 1.f;
+            if ((float)cnt * (4.18879f * kk * kk * kk) >= (float)want * side * side * side || k >= GRID_KMAX) break;
+        }
+        unsigned long long top[KR];
+        for (;;) {
+            const bool whole = k > GRID_KMAX;  // past KMAX: scan the whole grid (exact, slow, rare)
+            const int x0 = whole ? 0 : max(cx - k, 0), x1 = whole ? g.dim[0] - 1 : min(cx + k, g.dim[0] - 1);
+            const int y0 = whole ? 0 : max(cy - k, 0), y1 = whole ? g.dim[1] - 1 : min(cy + k, g.dim[1] - 1);
+            const int z0 = whole ? 0 : max(cz - k, 0), z1 = whole ? g.dim[2] - 1 : min(cz + k, g.dim[2] - 1);
+#pragma unroll
+            for (int r = 0; r < KR; ++r) top[r] = ~0ull;
+            unsigned long long tau = ~0ull;
+            unsigned int scnt = 0;  // wave-uniform
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                    const unsigned int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                    for (unsigned int p = s; p < e; p += 64) {
+                        const unsigned int pp = p + lane;
+                        unsigned long long key = ~0ull;
+                        if (pp < e) {
+                            const float4 r4 = cell_refs[pp];
+                            key = make_key(dist2(qx, qy, qz, r4), r4);
+                        }
+                        const bool pass = key < tau;
+                        const unsigned long long mask = __ballot(pass);
+                        if (mask == 0) continue;
+                        if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+                        scnt += (unsigned int)__popcll(mask);
+                        __builtin_amdgcn_wave_barrier();
+                        if (scnt >= 64) {
+                            const unsigned long long batch = stage[lane];
+                            const unsigned int rest = scnt - 64;
+                            const unsigned long long carry = lane < rest ? stage[64 + lane] : ~0ull;
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < rest) stage[lane] = carry;
+                            scnt = rest;
+                            topk_merge<KR>(top, batch, lane);
+                            tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+            if (scnt) {
+                const unsigned long long batch = lane < scnt ? stage[lane] : ~0ull;
+                __builtin_amdgcn_wave_barrier();
+                topk_merge<KR>(top, batch, lane);
+                tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
+            }
+            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+            if (lb2 == __builtin_inff()) break;  // whole grid scanned
+            if (tau != ~0ull && __uint_as_float((unsigned int)(tau >> 32)) < lb2) break;
+            // grow and rescan from scratch (a rescan must not insert a point twice)
+            int kn = k + 1;
+            if (tau != ~0ull) {
+                const float need = sqrtf(__uint_as_float((unsigned int)(tau >> 32))) * g.inv_h;
+                kn = need < (float)GRID_KMAX ? max((int)need + 1, k + 1) : GRID_KMAX + 1;
+            } else if (k >= 2) {
+                kn = 2 * k;
+            }
+            k = kn;
+        }
+        unsigned long long* list = keys + (size_t)qi * K;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = r * 64 + (int)lane;
+            if (e < K) list[e] = top[r];
+        }
+    }
+}
+
 int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)nq;
@@ -104,6 +269,17 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
+    static const bool lane_knn = getenv("PCC_KNN") && !strcmp(getenv("PCC_KNN"), "lane");
+    if (K <= 128 && !lane_knn) {
+        unsigned int gw = (n + 3) / 4;  // one wave per query, 4 waves per workgroup, waves loop
+        if (gw > 8192) gw = 8192;
+        if (K <= 64)
+            hipLaunchKernelGGL((k_grid_knn_wave<1>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                               ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, keys);
+        else
+            hipLaunchKernelGGL((k_grid_knn_wave<2>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                               ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, keys);
+    } else
     hipLaunchKernelGGL(k_grid_knn, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                        ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, K, keys);
     PCC_HIP(hipGetLastError());
