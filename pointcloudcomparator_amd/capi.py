@@ -238,6 +238,7 @@ class Index:
         cnt = self.radius_count(queries, radius)
         if _is_torch(cnt):
             import torch
+            self.sync()  # device results are written on the library's stream, torch works on its own
             offs = torch.zeros(n + 1, dtype=torch.int64, device=cnt.device)
             offs[1:] = torch.cumsum(cnt.to(torch.int64), 0)
             total = int(offs[-1].item())
