@@ -205,7 +205,7 @@ def main():
                 "kernel": "k_grid_nn1", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": load_pmc_traffic("k_grid_nn1", wl_key),
                 "kernel_ms": tm[0], "algorithmic_bytes": alg_bytes,
-                "note": "pruned exact search: latency/L2-gather bound, far below the HBM roof by construction (DESIGN.md)",
+                "note": "pruned exact search: bound by the per-lane 16-byte gather rate of the L1/texture-address path (DESIGN.md 4.2), far below the HBM roof by construction",
             }
         else:
             pairs = float(M) * N
