@@ -22,9 +22,9 @@ namespace pcc {
 
 constexpr int CS_T = 256;
 constexpr unsigned int CS_SLICE = 4096;    // points per workgroup in passes 1 and 2
-constexpr unsigned int CS_MAX_G = 1024;    // workgroups (slices grow beyond 4M points)
+constexpr unsigned int CS_MAX_G = 512;     // workgroups (slices grow beyond 2M points; measured best at 10M)
 constexpr unsigned int CS_BUCKETS = 2048;  // coarse buckets aimed for
-constexpr unsigned int CS_MAX_F = 12288;   // cells per bucket: 48 KiB of LDS counters
+constexpr unsigned int CS_MAX_F = 24576;   // cells per bucket: up to 96 KiB of LDS counters (10M+ points)
 
 struct CsPlan {
     unsigned int F, B, G, slice;
@@ -32,12 +32,14 @@ struct CsPlan {
 static CsPlan cs_plan(unsigned int ncells, unsigned int n) {
     CsPlan p;
     static const unsigned int buckets = getenv("PCC_CS_BUCKETS") ? (unsigned int)atoi(getenv("PCC_CS_BUCKETS")) : CS_BUCKETS;
+    static const unsigned int max_f = getenv("PCC_CS_MAXF") ? (unsigned int)atoi(getenv("PCC_CS_MAXF")) : CS_MAX_F;
+    static const unsigned int max_g = getenv("PCC_CS_MAXG") ? (unsigned int)atoi(getenv("PCC_CS_MAXG")) : CS_MAX_G;
     p.F = (ncells + buckets - 1) / buckets;
     if (p.F < 64) p.F = 64;
-    if (p.F > CS_MAX_F) p.F = CS_MAX_F;
+    if (p.F > max_f) p.F = max_f;
     p.B = (ncells + p.F - 1) / p.F;
     p.G = (n + CS_SLICE - 1) / CS_SLICE;
-    if (p.G > CS_MAX_G) p.G = CS_MAX_G;
+    if (p.G > max_g) p.G = max_g;
     if (p.G < 1) p.G = 1;
     p.slice = (n + p.G - 1) / p.G;
     return p;
