@@ -26,7 +26,11 @@ typedef Histogram<32> RIFT32;  // reference src/comparator.cpp:9
 inline std::vector<int> matchRIFTFeaturesKnn(const PointCloud<RIFT32>::Ptr& descriptors1,
                                              const PointCloud<RIFT32>::Ptr& descriptors2) {
     std::vector<int> correspondence(1);
-    KdTreeFLANN<RIFT32> matching;  // `= new KdTreeFLANN<RIFT32>(false)` in the reference: sorted == true
+    // `= new KdTreeFLANN<RIFT32>(false)` in the reference: sorted == true, and one (leaked) tree per
+    // call.  Here one tree per thread is re-pointed at each descriptor cloud: the reference calls this
+    // up to three times per cluster (:1322) and a fresh device handle per call would cost ~1 ms of
+    // allocations for microseconds of work.
+    static thread_local KdTreeFLANN<RIFT32> matching;
     matching.setInputCloud(descriptors1);
     if (!matching.handle() || !descriptors2 || descriptors2->empty()) return correspondence;
     std::vector<int> out(descriptors2->size() + 1);

@@ -40,21 +40,32 @@ public:
     KdTree& operator=(const KdTree&) = delete;
 
     // PCL prints "Cannot create a KDTree with an empty input cloud" and returns; so do we.
+    // A tree object can be pointed at a new cloud any number of times (PCL: cleanup() + rebuild);
+    // the device handle, its stream and its buffers are kept and only the index is rebuilt, so a
+    // long-lived tree (see matchRIFTFeaturesKnn) costs no allocation per call.
     void setInputCloud(const CloudConstPtr& cloud) {
         input_ = cloud;
-        if (index_) { pcc_index_destroy(index_); index_ = nullptr; }
+        valid_ = false;
         if (!cloud || cloud->empty()) return;
-        int st = pcc_index_create(cloud->points.data(), cloud->size(), sizeof(PointT), 3, PCC_MEM_HOST, device_,
-                                  engine_, &index_);
-        if (st == PCC_ERR_EMPTY) { index_ = nullptr; return; }
-        check(st);
+        if (!index_) {
+            int st = pcc_index_create(cloud->points.data(), cloud->size(), sizeof(PointT), 3, PCC_MEM_HOST, device_,
+                                      engine_, &index_);
+            if (st == PCC_ERR_EMPTY) { index_ = nullptr; return; }
+            check(st);
+            valid_ = true;
+            return;
+        }
+        check(pcc_index_set_input(index_, cloud->points.data(), cloud->size(), sizeof(PointT), 3, PCC_MEM_HOST));
+        size_t n_valid = 0;
+        check(pcc_index_size(index_, &n_valid));  // waits for the build; 0 == PCL's "empty input cloud"
+        valid_ = n_valid > 0;
     }
     CloudConstPtr getInputCloud() const { return input_; }
     bool getSortedResults() const { return sorted_; }
-    pcc_index* handle() const { return index_; }
+    pcc_index* handle() const { return valid_ ? index_ : nullptr; }
 
     int nearestKSearch(const PointT& p, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const {
-        if (!index_ || !isFinite(p)) { k_indices.clear(); k_sqr_distances.clear(); return 0; }  // PCL asserts here
+        if (!handle() || !isFinite(p)) { k_indices.clear(); k_sqr_distances.clear(); return 0; }  // PCL asserts here
         size_t total = 0;
         check(pcc_index_size(index_, &total));
         if ((size_t)k > total) k = (int)total;
@@ -72,7 +83,7 @@ public:
                      unsigned int max_nn = 0) const {
         k_indices.clear();
         k_sqr_distances.clear();
-        if (!index_ || !isFinite(p)) return 0;
+        if (!handle() || !isFinite(p)) return 0;
         int32_t cnt = 0;
         check(pcc_radius_count(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, &cnt));
         if (cnt == 0) return 0;
@@ -90,13 +101,13 @@ public:
     void nearestKSearchBatch(const PointCloud<PointT>& queries, std::vector<int>& idx, std::vector<float>& d2) const {
         idx.assign(queries.size(), -1);
         d2.assign(queries.size(), 0.f);
-        if (!index_ || queries.empty()) return;
+        if (!handle() || queries.empty()) return;
         check(pcc_nn1(index_, queries.points.data(), queries.size(), sizeof(PointT), PCC_MEM_HOST, idx.data(), d2.data()));
     }
     void nearestKSearchBatch(const PointCloud<PointT>& queries, int k, std::vector<int>& idx, std::vector<float>& d2) const {
         idx.assign(queries.size() * (size_t)k, -1);
         d2.assign(queries.size() * (size_t)k, 0.f);
-        if (!index_ || queries.empty()) return;
+        if (!handle() || queries.empty()) return;
         check(pcc_knn(index_, queries.points.data(), queries.size(), sizeof(PointT), PCC_MEM_HOST, k, idx.data(), d2.data()));
     }
 
@@ -105,6 +116,7 @@ private:
     int device_, engine_;
     CloudConstPtr input_;
     pcc_index* index_ = nullptr;
+    bool valid_ = false;  // index_ holds at least one finite point of input_
 };
 
 }  // namespace search
