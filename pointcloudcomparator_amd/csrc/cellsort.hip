@@ -54,11 +54,21 @@ k_cs_hist(const float4* __restrict__ pts, unsigned int n, const GridDev* __restr
     for (unsigned int b = threadIdx.x; b < B; b += CS_T) lds[b] = 0;
     __syncthreads();
     const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
-    for (unsigned int i = beg + threadIdx.x; i < end; i += CS_T) {
-        const float4 v = pts[i];
-        if (__float_as_int(v.w) < 0) { key_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // non-finite point: not indexed
-        const unsigned int c = cell_id(v, g);
-        key_rank[i] = make_uint2(c, atomicAdd(&lds[c / F], 1u));
+    // four independent loads in flight per thread: the loop is latency-bound otherwise (each
+    // iteration is load -> LDS atomic -> store)
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * CS_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * CS_T < end) v[u] = pts[i0 + u * CS_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int i = i0 + u * CS_T;
+            if (i >= end) break;
+            if (__float_as_int(v[u].w) < 0) { key_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // non-finite point: not indexed
+            const unsigned int c = cell_id(v[u], g);
+            key_rank[i] = make_uint2(c, atomicAdd(&lds[c / F], 1u));
+        }
     }
     __syncthreads();
     for (unsigned int b = threadIdx.x; b < B; b += CS_T) H[(size_t)b * gridDim.x + blockIdx.x] = lds[b];
@@ -72,11 +82,17 @@ __global__ void __launch_bounds__(CS_T)
 k_cs_scatter(unsigned int n, unsigned int F, unsigned int slice, const uint2* __restrict__ key_rank,
              const unsigned int* __restrict__ H, uint2* __restrict__ tmp_kv) {
     const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
-    for (unsigned int i = beg + threadIdx.x; i < end; i += CS_T) {
-        const uint2 kr = key_rank[i];
-        if (kr.x == 0xffffffffu) continue;
-        const unsigned int dst = H[(size_t)(kr.x / F) * gridDim.x + blockIdx.x] + kr.y;
-        tmp_kv[dst] = make_uint2(kr.x, i);
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * CS_T) {
+        uint2 kr[4];
+        unsigned int base[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kr[u] = (i0 + u * CS_T < end) ? key_rank[i0 + u * CS_T] : make_uint2(0xffffffffu, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            base[u] = kr[u].x != 0xffffffffu ? H[(size_t)(kr[u].x / F) * gridDim.x + blockIdx.x] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (kr[u].x != 0xffffffffu) tmp_kv[base[u] + kr[u].y] = make_uint2(kr[u].x, i0 + u * CS_T);
     }
 }
 
@@ -112,7 +128,14 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
     const unsigned int cell0 = b * F;
     for (unsigned int f = threadIdx.x; f < F; f += CS_T) cnt[f] = 0;
     __syncthreads();
-    for (unsigned int j = beg + threadIdx.x; j < end; j += CS_T) atomicAdd(&cnt[tmp_kv[j].x - cell0], 1u);
+    for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * CS_T) {
+        unsigned int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = (j0 + u * CS_T < end) ? tmp_kv[j0 + u * CS_T].x : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c[u] != 0xffffffffu) atomicAdd(&cnt[c[u] - cell0], 1u);
+    }
     __syncthreads();
     // exclusive scan of the F counters: thread t owns a contiguous chunk
     const unsigned int per = (F + CS_T - 1) / CS_T;
@@ -127,15 +150,26 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
         run += c;                                                      // [ncells] receives the total
     }
     __syncthreads();
-    for (unsigned int j = beg + threadIdx.x; j < end; j += CS_T) {
-        const uint2 kv = tmp_kv[j];
-        const unsigned int pos = atomicAdd(&cnt[kv.x - cell0], 1u);
+    for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * CS_T) {
+        uint2 kv[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kv[u] = (j0 + u * CS_T < end) ? tmp_kv[j0 + u * CS_T] : make_uint2(0xffffffffu, 0u);
         if (REFS) {
-            float4 v = pts[kv.y];                 // gather from the original-order array
-            v.w = __int_as_float((int)kv.y);      // cell-sorted copies carry the packed position
-            out_pts[pos] = v;
-        } else {
-            out_order[pos] = kv.y;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (kv[u].x != 0xffffffffu) v[u] = pts[kv[u].y];  // gather from the original-order array
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (kv[u].x == 0xffffffffu) continue;
+            const unsigned int pos = atomicAdd(&cnt[kv[u].x - cell0], 1u);
+            if (REFS) {
+                v[u].w = __int_as_float((int)kv[u].y);  // cell-sorted copies carry the packed position
+                out_pts[pos] = v[u];
+            } else {
+                out_order[pos] = kv[u].y;
+            }
         }
     }
 }
