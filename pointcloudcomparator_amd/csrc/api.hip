@@ -64,14 +64,14 @@ struct DeviceGuard {
 // host: one H2D copy of the raw AoS, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
                         DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr,
-                        unsigned int* zero_word = nullptr) {
+                        unsigned int* zero_word = nullptr, float4* seeds = nullptr) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word);
+    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds);
 }
 
 static int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -140,7 +140,9 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     ev_mark(ix, EV_BUILD0);
     PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
     int nblk = 0;
-    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk));
+    PCC_TRY(ix->seeds.reserve(((n + 63) / 64) * sizeof(float4)));  // the pack kernel also emits the seed subset
+    PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk,
+                         nullptr, ix->seeds.as<float4>()));
     PCC_TRY(grid_params(ix, ix->blk_stats.as<float>(), nblk));
     ix->engine = resolve_engine(ix->engine_requested, n);
     if (ix->engine == PCC_ENGINE_GRID) PCC_TRY(grid_build(ix));

@@ -151,15 +151,6 @@ static inline int grid1d(size_t n) {
 constexpr int SEED_STRIDE = 64;
 constexpr int FAR_SPAN = 1024;
 
-__global__ void __launch_bounds__(256)
-k_make_seeds(const float4* __restrict__ refs, unsigned int n, float4* __restrict__ seeds, unsigned int n_seeds) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_seeds; i += gridDim.x * blockDim.x) {
-        float4 v = refs[min(i * SEED_STRIDE, n - 1)];
-        if (__float_as_int(v.w) >= 0) v.w = __int_as_float((int)min(i * SEED_STRIDE, n - 1));
-        seeds[i] = v;  // a non-finite reference stays flagged (w < 0) and is skipped by the scan
-    }
-}
-
 // cell-sort the references (asynchronous; launch sizes come from n_orig and nc_cap)
 int grid_build(pcc_index* ix) {
     const size_t n = ix->n_orig;
@@ -168,12 +159,7 @@ int grid_build(pcc_index* ix) {
     PCC_TRY(ix->cell_refs.reserve(n * sizeof(float4) + 64));
     PCC_TRY(cell_sort(ix, ix->refs.as<float4>(), n, true, ix->cell_refs.as<float4>(), nullptr,
                       ix->cell_start.as<unsigned int>(), nullptr));
-    const unsigned int n_seeds = (unsigned int)((n + SEED_STRIDE - 1) / SEED_STRIDE);
-    PCC_TRY(ix->seeds.reserve((size_t)n_seeds * sizeof(float4)));
-    hipLaunchKernelGGL(k_make_seeds, dim3(grid1d(n_seeds)), dim3(256), 0, ix->stream, ix->refs.as<float4>(), (unsigned int)n,
-                       ix->seeds.as<float4>(), n_seeds);
-    PCC_HIP(hipGetLastError());
-    ix->has_grid = true;
+    ix->has_grid = true;  // (the seed subset for far queries was written by the pack kernel)
     return PCC_OK;
 }
 

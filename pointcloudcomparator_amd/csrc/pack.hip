@@ -28,7 +28,7 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 template <bool VEC16, bool STATS>
 __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
-       float* __restrict__ blk, unsigned int* __restrict__ zero_word) {
+       float* __restrict__ blk, unsigned int* __restrict__ zero_word, float4* __restrict__ seeds) {
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // saves a 5 us memset node
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -56,6 +56,7 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
             ++bad;
         }
         out[i] = o;
+        if (STATS && seeds && (i & 63) == 0) seeds[i >> 6] = o;  // every 64th reference: upper bounds for far queries
     }
     if (STATS) {
         __shared__ float red[4][8];
@@ -90,7 +91,7 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
 }
 
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                float* blk_stats, int* n_blocks, unsigned int* zero_word) {
+                float* blk_stats, int* n_blocks, unsigned int* zero_word, float4* seeds) {
     if (n_blocks) *n_blocks = 0;
     if (n == 0) return PCC_OK;
     bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
@@ -99,10 +100,10 @@ int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4*
     if (n_blocks) *n_blocks = g;
     const char* a = (const char*)aos;
     bool st = blk_stats != nullptr;
-    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word);
-    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word);
-    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word);
-    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word);
+    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
+    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
+    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
+    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
