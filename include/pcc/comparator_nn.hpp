@@ -41,6 +41,26 @@ inline std::vector<int> matchRIFTFeaturesKnn(const PointCloud<RIFT32>::Ptr& desc
     return out;
 }
 
+// ---- keypoint snap (src/comparator.cpp:696-713, inside processRIFTwithSIFT) -----------------------
+// For every keypoint the FIRST cloud point within `radius` (0.05 in the reference; float differences,
+// double-precision distance) is appended to the result, keypoints without one are skipped.
+template <class KeyPointT>
+inline PointCloud<PointXYZRGB>::Ptr snapKeypointsToCloud(const PointCloud<PointXYZRGB>::Ptr& cloud,
+                                                         const PointCloud<KeyPointT>& keypoints, double radius = 0.05,
+                                                         search::KdTree<PointXYZRGB>* tree = nullptr) {
+    PointCloud<PointXYZRGB>::Ptr out(new PointCloud<PointXYZRGB>);
+    if (!cloud || cloud->empty() || keypoints.empty()) return out;
+    search::KdTree<PointXYZRGB> local;
+    if (!tree) { local.setInputCloud(cloud); tree = &local; }
+    if (!tree->handle()) return out;
+    std::vector<int32_t> idx(keypoints.size());
+    check(pcc_first_within(tree->handle(), keypoints.points.data(), keypoints.size(), sizeof(KeyPointT), PCC_MEM_HOST,
+                           radius, idx.data()));
+    for (int32_t j : idx)
+        if (j >= 0) out->push_back(cloud->points[j]);
+    return out;
+}
+
 // ---- pcl::IterativeClosestPoint ---------------------------------------------------------------
 template <class PointSource, class PointTarget>
 class IterativeClosestPoint {

@@ -171,6 +171,15 @@ int pcc_match_knn(pcc_index *index_des1, const void *des2, size_t n2,
                   size_t stride_bytes, int mem, float threshold, int32_t *out,
                   int32_t *out_size);
 
+/* ---- first point within a radius ----------------------------------------------------------------
+ * replaces: the O(S*N) linear scan in processRIFTwithSIFT (src/comparator.cpp:696-713) that snaps
+ *   every SIFT keypoint to the FIRST cloud point j (lowest index) with
+ *   sqrt(pow(kx - px, 2) + pow(ky - py, 2) + pow(kz - pz, 2)) < radius  -- differences in float,
+ *   squares / sum / sqrt in double, strict compare against the double radius (0.05 there).
+ * idx[nq] (memory space `mem`): that lowest index, or -1 when no point qualifies. */
+int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes,
+                     int mem, double radius, int32_t *idx);
+
 /* ---- instrumentation ------------------------------------------------------------------
  * counters of the last search on this index (host):
  *  stats[0] queries resolved by the GRID engine, [1] queries sent to the BRUTE

@@ -470,6 +470,23 @@ int orc_match_rift_knn(const void *des1, size_t n1, const void *des2, size_t n2,
     return c;
 }
 
+/* ============ keypoint snap loop (src/comparator.cpp:696-713) ============== */
+
+void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry, size_t n, size_t qstride,
+                      double radius, int32_t *idx) {
+    for (size_t i = 0; i < n; ++i) {
+        const float *s = pt_at(qry, qstride, i);
+        idx[i] = -1;
+        if (!finite3(s)) continue;
+        for (size_t j = 0; j < m; ++j) {
+            const float *p = pt_at(pts, stride, j);
+            /* pow(float - float, 2): the difference is a float, pow promotes it to double */
+            float fx = s[0] - p[0], fy = s[1] - p[1], fz = s[2] - p[2];
+            if (sqrt(pow(fx, 2) + pow(fy, 2) + pow(fz, 2)) < radius) { idx[i] = (int32_t)j; break; }
+        }
+    }
+}
+
 /* ======= EuclideanClusterExtraction (src/segmentation.cpp:125-131, 9.4) ==== */
 
 typedef struct { int32_t first; int32_t size; int32_t id; } clus_t;

@@ -78,6 +78,12 @@ void orc_kdtree_nn1_batch_mt(const orc_kdtree *t, const void *qry, size_t n,
 int orc_match_rift_knn(const void *des1, size_t n1, const void *des2, size_t n2,
                        size_t stride, int32_t *out);
 
+/* the keypoint snap loop of processRIFTwithSIFT (src/comparator.cpp:696-713): for each query the FIRST
+ * j with sqrt(pow(qx-px,2)+pow(qy-py,2)+pow(qz-pz,2)) < radius (float differences, double math);
+ * -1 when none. */
+void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry, size_t n, size_t qstride,
+                      double radius, int32_t *idx);
+
 /* pcl::extractEuclideanClusters + EuclideanClusterExtraction::extract
  * (src/segmentation.cpp:125-131).  labels[i] = cluster id in the
  * returned order (size-descending, ties by lowest member index; -1 = not in

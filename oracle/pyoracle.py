@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         L.orc_kdtree_nn1_batch.restype = None
         L.orc_kdtree_nn1_batch_mt.argtypes = [vp, vp, sz, sz, vp, vp, i32]
         L.orc_kdtree_nn1_batch_mt.restype = None
+        L.orc_first_within.argtypes = [vp, sz, sz, vp, sz, sz, C.c_double, vp]
+        L.orc_first_within.restype = None
         L.orc_match_rift_knn.argtypes = [vp, sz, vp, sz, sz, vp]
         L.orc_euclidean_clusters.argtypes = [vp, sz, sz, C.c_float, C.c_uint32, C.c_uint32, vp, vp, i32]
         L.orc_sor.argtypes = [vp, sz, sz, i32, C.c_double, vp, vp, C.POINTER(C.c_double)]
@@ -176,6 +178,14 @@ class KdTree:
         sums = np.zeros(17, np.float64)
         lib().orc_icp_step_sums(self._h, tp, ts, sp, n, ss, idx.ctypes.data, d2.ctypes.data, sums.ctypes.data)
         return idx, d2, sums
+
+
+def first_within(pts, qry, radius):
+    a, ap, m, s1 = _f32(pts)
+    b, bp, n, s2 = _f32(qry)
+    idx = np.empty(n, np.int32)
+    lib().orc_first_within(ap, m, s1, bp, n, s2, float(radius), idx.ctypes.data)
+    return idx
 
 
 def match_rift_knn(des1, des2):

@@ -27,7 +27,7 @@ SYMBOLS = [
     "pcc_nn1", "pcc_knn", "pcc_radius_count", "pcc_radius_fill",
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
-    "pcc_index_timing",
+    "pcc_index_timing", "pcc_first_within",
 ]
 
 
@@ -75,6 +75,7 @@ def _load() -> C.CDLL:
     lib.pcc_nn1.argtypes = [vp, vp, sz, sz, i32, vp, vp]
     lib.pcc_knn.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp]
     lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
+    lib.pcc_first_within.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_radius_fill.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, vp]
     lib.pcc_euclidean_clusters.argtypes = [vp, C.c_double, C.c_uint32, C.c_uint32, i32, vp,
                                            C.POINTER(C.c_int32), vp, i32]
@@ -231,6 +232,13 @@ class Index:
         cnt, pc = _out(queries, (n,), np.int32)
         _check(LIB.pcc_radius_count(self._h, ptr, n, stride, mem, float(radius), pc))
         return cnt
+
+    def first_within(self, queries, radius: float):
+        """lowest index of a reference within `radius` (double-precision test), -1 if none"""
+        ptr, n, stride, mem = _points(queries)
+        idx, pi = _out(queries, (n,), np.int32)
+        _check(LIB.pcc_first_within(self._h, ptr, n, stride, mem, float(radius), pi))
+        return idx
 
     def radius_search(self, queries, radius: float, sorted: bool = True):
         """CSR (offsets, idx, d2) of all neighbours with d2 < float(radius^2)."""

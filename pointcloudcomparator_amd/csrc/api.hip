@@ -453,6 +453,27 @@ int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int 
     return PCC_OK;
 }
 
+int pcc_first_within(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int32_t* idx) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(q, nq, stride, mem));
+    if (!idx) { set_error("null idx"); return PCC_ERR_INVALID; }
+    if (!(radius >= 0)) { set_error("bad radius"); return PCC_ERR_INVALID; }
+    if (nq == 0) return PCC_OK;
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, q, nq, stride, mem));
+    int32_t* didx = idx;
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(nq * sizeof(int32_t))); didx = ix->out_idx.as<int32_t>(); }
+    PCC_TRY(grid_first_within(ix, ix->q_packed.as<float4>(), nq, radius, didx));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, didx, idx, nq, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
 int pcc_euclidean_clusters(pcc_index* ix, double tolerance, uint32_t min_size, uint32_t max_size, int mem,
                            int32_t* labels, int32_t* n_clusters, int32_t* sizes, int max_sizes) {
     PCC_ENTER(ix);

@@ -337,6 +337,55 @@ k_grid_radius(const float4* __restrict__ cell_refs, const unsigned int* __restri
     }
 }
 
+// ---- first point within a radius (reference src/comparator.cpp:696-713) -----------------------------
+// lowest position whose double-precision distance (float differences, double squares/sum/sqrt) is
+// < radius.  The cells are chosen with the float radius plus slack (a superset); the double test
+// decides.
+__global__ void __launch_bounds__(256)
+k_grid_first_within(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+                    const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+                    const unsigned int* __restrict__ n_sorted_ptr, double radius, int32_t* __restrict__ idx) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *n_sorted_ptr) return;
+    const unsigned int qi = order[t];
+    const float4 qv = q[qi];
+    int x0, x1, y0, y1, z0, z1;
+    const float rr = (float)radius * 1.000001f + slack;
+    cell_range(qv.x, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
+    cell_range(qv.y, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
+    cell_range(qv.z, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
+    unsigned int first = 0xffffffffu;
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+            const unsigned int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+            for (unsigned int p = s; p < e; ++p) {
+                const float4 rp = cell_refs[p];
+                const unsigned int pos = (unsigned int)__float_as_int(rp.w);
+                if (pos >= first) continue;
+                const double dx = (double)(qv.x - rp.x), dy = (double)(qv.y - rp.y), dz = (double)(qv.z - rp.z);
+                if (sqrt(dx * dx + dy * dy + dz * dz) < radius) first = pos;
+            }
+        }
+    idx[qi] = first == 0xffffffffu ? -1 : (int32_t)first;
+}
+
+int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, int32_t* idx) {
+    hipStream_t s = ix->stream;
+    const unsigned int n = (unsigned int)nq;
+    unsigned int *order = nullptr, *n_sorted = nullptr;
+    PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
+    PCC_HIP(hipMemsetAsync(idx, 0xff, nq * sizeof(int32_t), s));  // non-finite queries: -1
+    ev_mark(ix, EV_MAIN0);
+    hipLaunchKernelGGL(k_grid_first_within, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, radius, idx);
+    PCC_HIP(hipGetLastError());
+    ev_mark(ix, EV_MAIN1);
+    return PCC_OK;
+}
+
 int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
                 const int64_t* offsets, unsigned long long* keys, int sorted) {
     hipStream_t s = ix->stream;

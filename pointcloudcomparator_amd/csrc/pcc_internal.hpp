@@ -171,6 +171,7 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
 // counts[i] = #refs with d2 < r2; with fill != 0 also writes keys at offsets[i]..
 int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
                 const int64_t* offsets, unsigned long long* keys, int sorted);
+int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, int32_t* idx_dev);
 // ---- cluster.hip ------------------------------------------------------------------------
 int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t max_size,
                   int32_t* labels_dev /* n_orig, device */, int32_t* n_clusters, int32_t* sizes, int max_sizes);

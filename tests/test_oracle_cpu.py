@@ -178,3 +178,10 @@ def test_synth_is_deterministic_and_layered():
     d = np.linalg.norm(obj[:, None, :] - c[None], axis=2).min(1)
     assert (d <= synth.BALL_R + 1e-5).all()
     assert synth.with_rgb_stride(a1).strides == (32, 4)
+
+
+def test_first_within_is_first_not_nearest():
+    pts = np.array([[0.04, 0, 0], [0.01, 0, 0], [0.049999, 0, 0], [0.05, 0, 0]], np.float32)
+    q = np.zeros((1, 3), np.float32)
+    assert oracle.first_within(pts, q, 0.05)[0] == 0          # lowest index wins, not the closest
+    assert oracle.first_within(pts[3:], q, 0.05)[0] == -1     # float(0.05) > 0.05 in double: strict < fails

@@ -165,3 +165,17 @@ def test_match_knn_mirrors_reference_quirks(gpu):
     ref = oracle.match_rift_knn(des1, des2)
     assert out[0] == 0 and len(out) == len(ref)  # size() == matches + 1 (reference :568)
     assert (out == ref).all()
+
+
+def test_first_within_matches_linear_scan(gpu):
+    """processRIFTwithSIFT's keypoint snap (reference src/comparator.cpp:696-713)"""
+    cloud = _scene(50000)
+    rng = np.random.default_rng(9)
+    keys = cloud[rng.integers(0, len(cloud), 700)] + rng.normal(0, 0.02, (700, 3)).astype(np.float32)
+    keys[::50] += np.float32(3.0)      # no point within 0.05
+    keys[7, 1] = np.nan
+    with capi.Index(cloud) as ix:
+        idx = ix.first_within(keys, 0.05)
+    ref = oracle.first_within(cloud, keys, 0.05)
+    assert (idx == ref).all()
+    assert idx[7] == -1 and (idx[::50][1:] == -1).all() and (idx >= 0).sum() > 500
