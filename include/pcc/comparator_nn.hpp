@@ -41,6 +41,42 @@ inline std::vector<int> matchRIFTFeaturesKnn(const PointCloud<RIFT32>::Ptr& desc
     return out;
 }
 
+// ---- pcl::VoxelGrid (src/segmentation.cpp:69-74, 224-229) -------------------------------------------
+template <class PointT>
+class VoxelGrid {
+public:
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    void setLeafSize(float lx, float ly, float lz) {
+        if (lx != ly || ly != lz) throw Error(PCC_ERR_UNSUPPORTED, "anisotropic leaf sizes are not supported");
+        leaf_ = lx;
+    }
+    void filter(PointCloud<PointT>& output) {
+        PointCloud<PointT> result;
+        if (input_ && !input_->empty()) {
+            search::KdTree<PointT> ctx;  // supplies device, stream and scratch
+            ctx.setInputCloud(input_);
+            if (ctx.handle()) {
+                result.points.resize(input_->size());
+                size_t nv = 0;
+                const int has_rgb = sizeof(PointT) >= 20 ? 1 : 0;
+                int st = pcc_voxel_grid(ctx.handle(), input_->points.data(), input_->size(), sizeof(PointT), PCC_MEM_HOST,
+                                        leaf_, has_rgb, result.points.data(), sizeof(PointT), &nv);
+                if (st == PCC_ERR_UNSUPPORTED) { result = *input_; nv = result.size(); }  // PCL: "leaf size is too small", output = input
+                else check(st);
+                result.points.resize(nv);
+            }
+        }
+        result.width = (std::uint32_t)result.points.size();
+        result.height = 1;
+        result.is_dense = true;
+        output = result;
+    }
+
+private:
+    typename PointCloud<PointT>::ConstPtr input_;
+    float leaf_ = 0.f;
+};
+
 // ---- keypoint snap (src/comparator.cpp:696-713, inside processRIFTwithSIFT) -----------------------
 // For every keypoint the FIRST cloud point within `radius` (0.05 in the reference; float differences,
 // double-precision distance) is appended to the result, keypoints without one are skipped.

@@ -171,6 +171,19 @@ int pcc_match_knn(pcc_index *index_des1, const void *des2, size_t n2,
                   size_t stride_bytes, int mem, float threshold, int32_t *out,
                   int32_t *out_size);
 
+/* ---- voxel-grid down-sampling -----------------------------------------------------------------------
+ * replaces: pcl::VoxelGrid<PointXYZRGB> with setLeafSize(l, l, l) + filter, the first step of both
+ *   segmentation paths (src/segmentation.cpp:69-74 and :224-229, l = 0.025f).  Every occupied voxel
+ *   of the world-aligned leaf lattice (index floor(p/leaf) - min_b, as PCL computes it) is replaced
+ *   by the centroid of its points; with has_rgb != 0 the packed rgb word at byte offset 16 is
+ *   averaged per channel and truncated, as PCL does.  Output order: ascending voxel index.
+ *   Non-finite points are ignored.  `ctx` is any index handle (supplies device, stream, scratch).
+ * out: caller-allocated, capacity n elements of out_stride bytes (x, y, z at 0 [, rgb at 16]);
+ * *out_n (host) = number of voxels written.  Centroid coordinates are accumulated in double and
+ * rounded once (PCL: float sums in sort order), i.e. equal to PCL's within float rounding. */
+int pcc_voxel_grid(pcc_index *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
+                   float leaf, int has_rgb, void *out, size_t out_stride, size_t *out_n);
+
 /* ---- first point within a radius ----------------------------------------------------------------
  * replaces: the O(S*N) linear scan in processRIFTwithSIFT (src/comparator.cpp:696-713) that snaps
  *   every SIFT keypoint to the FIRST cloud point j (lowest index) with

@@ -487,6 +487,76 @@ void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry,
     }
 }
 
+/* ============ VoxelGrid (src/segmentation.cpp:69-74, 224-229) ============== */
+
+typedef struct { unsigned int idx; unsigned int pt; } vox_t;
+static int vox_cmp(const void *a, const void *b) {
+    const vox_t *x = (const vox_t *)a, *y = (const vox_t *)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return (x->pt > y->pt) - (x->pt < y->pt);
+}
+
+long orc_voxel_grid(const void *pts, size_t m, size_t stride, float leaf, int has_rgb, void *out, size_t out_stride) {
+    float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    size_t valid = 0;
+    for (size_t i = 0; i < m; ++i) { /* getMinMax3D over the finite points */
+        const float *p = pt_at(pts, stride, i);
+        if (!finite3(p)) continue;
+        for (int a = 0; a < 3; ++a) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+        ++valid;
+    }
+    if (!valid) return 0;
+    int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1,
+            dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) return -1;
+    int min_b[3], div_b[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = (int)floor(mn[a] * inv);
+        div_b[a] = (int)floor(mx[a] * inv) - min_b[a] + 1;
+    }
+    vox_t *v = (vox_t *)malloc(sizeof(vox_t) * valid);
+    size_t c = 0;
+    for (size_t i = 0; i < m; ++i) {
+        const float *p = pt_at(pts, stride, i);
+        if (!finite3(p)) continue;
+        int ijk0 = (int)(floor(p[0] * inv) - (float)min_b[0]);
+        int ijk1 = (int)(floor(p[1] * inv) - (float)min_b[1]);
+        int ijk2 = (int)(floor(p[2] * inv) - (float)min_b[2]);
+        v[c].idx = (unsigned int)(ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1]);
+        v[c].pt = (unsigned int)i;
+        ++c;
+    }
+    qsort(v, c, sizeof(vox_t), vox_cmp);
+    long nv = 0;
+    for (size_t s = 0; s < c;) {
+        size_t e = s;
+        float cx = 0, cy = 0, cz = 0, cr = 0, cg = 0, cb = 0;
+        while (e < c && v[e].idx == v[s].idx) {
+            const float *p = pt_at(pts, stride, v[e].pt);
+            cx += p[0]; cy += p[1]; cz += p[2];
+            if (has_rgb) {
+                uint32_t w;
+                memcpy(&w, (const char *)p + 16, 4);
+                cr += (float)((w >> 16) & 0xff); cg += (float)((w >> 8) & 0xff); cb += (float)(w & 0xff);
+            }
+            ++e;
+        }
+        float n = (float)(e - s);
+        float *o = (float *)((char *)out + (size_t)nv * out_stride);
+        o[0] = cx / n; o[1] = cy / n; o[2] = cz / n;
+        if (out_stride >= 16) o[3] = 1.0f;
+        if (has_rgb) {
+            uint32_t w = ((uint32_t)(int)(cr / n) << 16) | ((uint32_t)(int)(cg / n) << 8) | (uint32_t)(int)(cb / n);
+            memcpy((char *)o + 16, &w, 4);
+        }
+        ++nv;
+        s = e;
+    }
+    free(v);
+    return nv;
+}
+
 /* ======= EuclideanClusterExtraction (src/segmentation.cpp:125-131, 9.4) ==== */
 
 typedef struct { int32_t first; int32_t size; int32_t id; } clus_t;

@@ -84,6 +84,15 @@ int orc_match_rift_knn(const void *des1, size_t n1, const void *des2, size_t n2,
 void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry, size_t n, size_t qstride,
                       double radius, int32_t *idx);
 
+/* pcl::VoxelGrid<PointXYZRGB>::applyFilter with setLeafSize(leaf, leaf, leaf), downsample_all_data
+ * (src/segmentation.cpp:69-74, 224-229; pcl/filters/impl/voxel_grid.hpp [recalled]): voxel index
+ * floor(p*inv) - min_b on the world-aligned lattice, points grouped by index (ascending), centroid =
+ * float sum / float count; rgb (packed word at byte 16 when has_rgb) averaged per channel in float and
+ * truncated.  PCL's std::sort leaves the order inside a voxel unspecified; this restatement adds in
+ * ascending point index.  out has m*out_stride bytes; returns the number of voxels, or -1 when the
+ * lattice would overflow int32 (PCL then returns the input unchanged). */
+long orc_voxel_grid(const void *pts, size_t m, size_t stride, float leaf, int has_rgb, void *out, size_t out_stride);
+
 /* pcl::extractEuclideanClusters + EuclideanClusterExtraction::extract
  * (src/segmentation.cpp:125-131).  labels[i] = cluster id in the
  * returned order (size-descending, ties by lowest member index; -1 = not in

@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         L.orc_kdtree_nn1_batch.restype = None
         L.orc_kdtree_nn1_batch_mt.argtypes = [vp, vp, sz, sz, vp, vp, i32]
         L.orc_kdtree_nn1_batch_mt.restype = None
+        L.orc_voxel_grid.argtypes = [vp, sz, sz, C.c_float, i32, vp, sz]
+        L.orc_voxel_grid.restype = C.c_long
         L.orc_first_within.argtypes = [vp, sz, sz, vp, sz, sz, C.c_double, vp]
         L.orc_first_within.restype = None
         L.orc_match_rift_knn.argtypes = [vp, sz, vp, sz, sz, vp]
@@ -178,6 +180,13 @@ class KdTree:
         sums = np.zeros(17, np.float64)
         lib().orc_icp_step_sums(self._h, tp, ts, sp, n, ss, idx.ctypes.data, d2.ctypes.data, sums.ctypes.data)
         return idx, d2, sums
+
+
+def voxel_grid(pts, leaf, has_rgb=False):
+    a, ap, m, s1 = _f32(pts)
+    out = np.zeros_like(a)
+    nv = lib().orc_voxel_grid(ap, m, s1, np.float32(leaf), int(has_rgb), out.ctypes.data, s1)
+    return out[:max(nv, 0)], nv
 
 
 def first_within(pts, qry, radius):

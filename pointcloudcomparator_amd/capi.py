@@ -27,7 +27,7 @@ SYMBOLS = [
     "pcc_nn1", "pcc_knn", "pcc_radius_count", "pcc_radius_fill",
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
-    "pcc_index_timing", "pcc_first_within",
+    "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
 ]
 
 
@@ -76,6 +76,7 @@ def _load() -> C.CDLL:
     lib.pcc_knn.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp]
     lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_first_within.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
+    lib.pcc_voxel_grid.argtypes = [vp, vp, sz, sz, i32, C.c_float, i32, vp, sz, C.POINTER(sz)]
     lib.pcc_radius_fill.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, vp]
     lib.pcc_euclidean_clusters.argtypes = [vp, C.c_double, C.c_uint32, C.c_uint32, i32, vp,
                                            C.POINTER(C.c_int32), vp, i32]
@@ -232,6 +233,16 @@ class Index:
         cnt, pc = _out(queries, (n,), np.int32)
         _check(LIB.pcc_radius_count(self._h, ptr, n, stride, mem, float(radius), pc))
         return cnt
+
+    def voxel_grid(self, points, leaf: float, has_rgb: bool = False):
+        """pcl::VoxelGrid centroids of `points` (host array (n, >=3) float32; rgb word in column 4)."""
+        ptr, n, stride, mem = _points(points)
+        assert mem == MEM_HOST
+        out = np.zeros((n, points.shape[1]), dtype=np.float32)
+        cnt = C.c_size_t(0)
+        _check(LIB.pcc_voxel_grid(self._h, ptr, n, stride, mem, np.float32(leaf), int(has_rgb), out.ctypes.data,
+                                  out.strides[0] if n > 1 else points.shape[1] * 4, C.byref(cnt)))
+        return out[:cnt.value]
 
     def first_within(self, queries, radius: float):
         """lowest index of a reference within `radius` (double-precision test), -1 if none"""

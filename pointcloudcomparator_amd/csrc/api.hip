@@ -174,7 +174,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->d_grid, &ix->seeds};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -451,6 +451,19 @@ int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int 
         PCC_HIP(hipStreamSynchronize(ix->stream));
     }
     return PCC_OK;
+}
+
+int pcc_voxel_grid(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem, float leaf, int has_rgb,
+                   void* out, size_t out_stride, size_t* out_n) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(pts, n, stride, mem));
+    if (!out || !out_n) { set_error("null output"); return PCC_ERR_INVALID; }
+    if (out_stride < 12 || out_stride % 4) { set_error("bad output stride"); return PCC_ERR_INVALID; }
+    if (has_rgb && (stride < 20 || out_stride < 20)) { set_error("rgb needs a stride of at least 20 bytes"); return PCC_ERR_INVALID; }
+    if (!(leaf > 0.f)) { set_error("leaf size must be positive"); return PCC_ERR_INVALID; }
+    *out_n = 0;
+    if (n == 0) return PCC_OK;
+    return voxel_grid(ix, pts, n, stride, mem, leaf, has_rgb, out, out_stride, out_n);
 }
 
 int pcc_first_within(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int32_t* idx) {

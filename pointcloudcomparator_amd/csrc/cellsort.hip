@@ -51,6 +51,7 @@ k_cs_hist(const float4* __restrict__ pts, unsigned int n, const GridDev* __restr
           unsigned int slice, uint2* __restrict__ key_rank, unsigned int* __restrict__ H) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
     const GridParams g = gd->g;
+    const bool voxel = gd->voxel != 0;
     for (unsigned int b = threadIdx.x; b < B; b += CS_T) lds[b] = 0;
     __syncthreads();
     const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
@@ -66,7 +67,7 @@ k_cs_hist(const float4* __restrict__ pts, unsigned int n, const GridDev* __restr
             const unsigned int i = i0 + u * CS_T;
             if (i >= end) break;
             if (__float_as_int(v[u].w) < 0) { key_rank[i] = make_uint2(0xffffffffu, 0u); continue; }  // non-finite point: not indexed
-            const unsigned int c = cell_id(v[u], g);
+            const unsigned int c = voxel ? voxel_id(v[u], g) : cell_id(v[u], g);
             key_rank[i] = make_uint2(c, atomicAdd(&lds[c / F], 1u));
         }
     }
@@ -178,12 +179,13 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
 // Sorts pts[0..n) by cell.  refs: out_pts (float4, w = position) + cell_start[ncells+1].
 // queries: out_order[0..n_sorted) lists the valid queries cell by cell; *n_sorted_dev = device address of the count.
 int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4* out_pts, unsigned int* out_order,
-              unsigned int* cell_start, unsigned int** n_sorted_dev) {
+              unsigned int* cell_start, unsigned int** n_sorted_dev, const GridDev* gd_override,
+              unsigned int nc_cap_override) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)n_pts;
     // planned from the host-known upper bound of the cell count; buckets past the actual grid stay empty
-    const CsPlan p = cs_plan(ix->nc_cap + 1, n);
-    const GridDev* gd = ix->d_grid.as<GridDev>();
+    const CsPlan p = cs_plan((gd_override ? nc_cap_override : ix->nc_cap) + 1, n);
+    const GridDev* gd = gd_override ? gd_override : ix->d_grid.as<GridDev>();
     // scratch: key_rank[n] | tmp_kv[n] | H[B*G+1] + scan scratch
     DevBuf& kr_buf = ix->scratch_c;
     DevBuf& kv_buf = ix->scratch_e;

@@ -73,7 +73,7 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
     GridDev d;
     d.n_invalid = bad;
     d.n_valid = n - bad;
-    d.pad_ = 0;
+    d.voxel = 0;
     float ext[3], maxext = 0.f, maxabs = 0.f;
     for (int a = 0; a < 3; ++a) {
         if (d.n_valid == 0) { lo[a] = 0.f; hi[a] = 0.f; }

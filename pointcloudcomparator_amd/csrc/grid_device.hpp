@@ -19,6 +19,16 @@ __device__ __forceinline__ unsigned int cell_id(const float4& v, const GridParam
     return ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
 }
 
+// PCL VoxelGrid voxel of a point (pcl/filters/impl/voxel_grid.hpp):
+//   ijk_a = int(floor(p_a * inverse_leaf) - float(min_b_a)),  idx = ijk0 + ijk1*div0 + ijk2*div0*div1
+// here org[a] = float(min_b_a), inv_h = inverse_leaf (float), dim = div_b
+__device__ __forceinline__ unsigned int voxel_id(const float4& v, const GridParams& g) {
+    const int i0 = min(max((int)(floorf(v.x * g.inv_h) - g.org[0]), 0), g.dim[0] - 1);
+    const int i1 = min(max((int)(floorf(v.y * g.inv_h) - g.org[1]), 0), g.dim[1] - 1);
+    const int i2 = min(max((int)(floorf(v.z * g.inv_h) - g.org[2]), 0), g.dim[2] - 1);
+    return ((unsigned int)i2 * g.dim[1] + i1) * g.dim[0] + i0;
+}
+
 __device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& r) {
     float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
     float d = dx * dx;

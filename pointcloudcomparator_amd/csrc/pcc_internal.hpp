@@ -55,7 +55,7 @@ struct GridDev {
     unsigned int n_valid;   // finite points (PCL total_nr_points_)
     unsigned int n_invalid;
     float lo[3], hi[3];     // bounding box of the valid points
-    unsigned int pad_;
+    unsigned int voxel;     // 1: cells are PCL VoxelGrid voxels -- id from floor(v*inv_h) - org (org = float(min_b))
 };
 
 }  // namespace pcc
@@ -91,7 +91,7 @@ struct pcc_index {
     unsigned int last_fallback_seen = 0;  // fallback count of an earlier search (heuristic only, may be stale)
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
-        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src;
+        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, vox_a, vox_b, vox_c;
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
@@ -164,7 +164,11 @@ int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** 
 float grid_slack(const GridParams& g);
 // ---- cellsort.hip: LDS-based two-level counting sort by cell ---------------------------------------
 int cell_sort(pcc_index* ix, const float4* pts, size_t n, bool refs, float4* out_pts, unsigned int* out_order,
-              unsigned int* cell_start, unsigned int** n_sorted_dev);
+              unsigned int* cell_start, unsigned int** n_sorted_dev, const GridDev* gd_override = nullptr,
+              unsigned int nc_cap_override = 0);
+// ---- voxel.hip: pcl::VoxelGrid (leaf-lattice centroids) ---------------------------------------------
+int voxel_grid(pcc_index* ctx, const void* pts, size_t n, size_t stride, int mem, float leaf, int has_rgb,
+               void* out, size_t out_stride, size_t* out_n);
 // ---- knn.hip: k-NN, radius search (GRID engine) ----------------------------------------
 // keys[nq][K] (pre-set to ~0) receive the K smallest (d2, position) keys ascending
 int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys);

@@ -30,8 +30,15 @@ static void printUsage() {
               << "-h show this help\n" << "\n\n";
 }
 
-// src/segmentation.cpp:119-156 (the clustering part of euclidean_cluster_segmentation)
-static std::vector<PointCloud<PointXYZRGB>::Ptr> euclidean_cluster_segmentation(const PointCloud<PointXYZRGB>::Ptr& cloud_filtered) {
+// src/segmentation.cpp:64-156 euclidean_cluster_segmentation: VoxelGrid 0.025 (:69-76) -> [RANSAC plane
+// removal :79-117, not part of this build] -> KdTree + EuclideanClusterExtraction (:119-156)
+static std::vector<PointCloud<PointXYZRGB>::Ptr> euclidean_cluster_segmentation(const PointCloud<PointXYZRGB>::Ptr& point_cloud_ptr) {
+    VoxelGrid<PointXYZRGB> vg;
+    PointCloud<PointXYZRGB>::Ptr cloud_filtered(new PointCloud<PointXYZRGB>);
+    vg.setInputCloud(point_cloud_ptr);
+    vg.setLeafSize(0.025f, 0.025f, 0.025f);
+    vg.filter(*cloud_filtered);
+    std::cout << "PointCloud after filtering has: " << cloud_filtered->points.size() << " data points." << std::endl;
     search::KdTree<PointXYZRGB>::Ptr tree(new search::KdTree<PointXYZRGB>);
     tree->setInputCloud(cloud_filtered);
     std::vector<PointIndices> cluster_indices;

@@ -17,7 +17,7 @@ EXE = ROOT / "build" / "comparator"
 
 def _scene(n_per, seed):
     rng = np.random.default_rng(seed)
-    blobs = [rng.normal(c, 0.015, (n_per, 3)) for c in [(0, 0, 0), (1, 0, 0), (0, 1, 0.5), (1, 1, 1)]]
+    blobs = [rng.normal(c, 0.05, (n_per, 3)) for c in [(0, 0, 0), (1, 0, 0), (0, 1, 0.5), (1, 1, 1)]]
     stray = rng.uniform(3, 6, (40, 3))
     return np.concatenate(blobs + [stray]).astype(np.float32)
 
@@ -25,7 +25,7 @@ def _scene(n_per, seed):
 def test_cli_icp_clusters_noise(gpu, tmp_path):
     if not EXE.exists():
         subprocess.check_call(["make", "cli"], cwd=ROOT)
-    a = _scene(300, 1)
+    a = _scene(4000, 1)
     b = (a + np.float32([0.004, -0.003, 0.002]))[::-1].copy()
     b[5, 0] = np.nan  # stripped by removeNaNFromPointCloud
     fa, fb, res = tmp_path / "a.ply", tmp_path / "b.ply", tmp_path / "results.txt"
@@ -43,16 +43,20 @@ def test_cli_icp_clusters_noise(gpu, tmp_path):
         assert line in out, line
     bf = b[np.isfinite(b).all(1)]
     for cloud in (a, bf):
-        _, ncl, sizes = oracle.euclidean_clusters(cloud, 0.05, 100, 250000)
+        vox, nv = oracle.voxel_grid(np.ascontiguousarray(cloud), 0.025)  # the -e path down-samples first (:69-76)
+        assert f"PointCloud after filtering has: {nv} data points." in out
+        _, ncl, sizes = oracle.euclidean_clusters(np.ascontiguousarray(vox), 0.05, 100, 250000)
         for s in sizes:
             assert f"PointCloud representing the Cluster: {s} data points." in out
-    assert out.count("PointCloud representing the Cluster:") == 8
+    assert out.count("PointCloud representing the Cluster:") >= 8
     kept = [oracle.sor(c, 50, 1.5)[3] for c in (a, bf)]
     assert f"Noise pass removed {len(a) - kept[0]} / {len(bf) - kept[1]} points" in out
     txt = res.read_text()
     assert txt.startswith(f"Results of comparison between {fa} and {fb}\n" + "-" * 80)
     assert f"Number of points of PCL 1: {len(a)}\n" in txt and f"Number of points of PCL 2: {len(bf)}\n" in txt
-    assert "Number of clusters of PCL 1: 4\n" in txt and "Number of clusters of PCL 2: 4\n" in txt
+    n1 = oracle.euclidean_clusters(np.ascontiguousarray(oracle.voxel_grid(a, 0.025)[0]), 0.05, 100, 250000)[1]
+    n2 = oracle.euclidean_clusters(np.ascontiguousarray(oracle.voxel_grid(np.ascontiguousarray(bf), 0.025)[0]), 0.05, 100, 250000)[1]
+    assert n1 >= 4 and f"Number of clusters of PCL 1: {n1}\n" in txt and f"Number of clusters of PCL 2: {n2}\n" in txt
     assert "----------------------------------------\n Noise analysis: \n" in txt
 
 

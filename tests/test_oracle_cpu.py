@@ -185,3 +185,12 @@ def test_first_within_is_first_not_nearest():
     q = np.zeros((1, 3), np.float32)
     assert oracle.first_within(pts, q, 0.05)[0] == 0          # lowest index wins, not the closest
     assert oracle.first_within(pts[3:], q, 0.05)[0] == -1     # float(0.05) > 0.05 in double: strict < fails
+
+
+def test_voxel_grid_restatement_basics():
+    pts = np.array([[0.01, 0.01, 0.01], [0.02, 0.02, 0.02], [0.03, 0.01, 0.01], [-0.01, 0, 0], [np.nan, 0, 0]], np.float32)
+    out, nv = oracle.voxel_grid(pts, 0.025)
+    assert nv == 3  # voxels: x<0 | [0,0.025) | [0.025,0.05)
+    assert np.allclose(out[0], [-0.01, 0, 0]) and np.allclose(out[1], [0.015, 0.015, 0.015]) and np.allclose(out[2], [0.03, 0.01, 0.01])
+    big = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
+    assert oracle.voxel_grid(big, 0.001)[1] == -1  # PCL: "Leaf size is too small", output = input

@@ -179,3 +179,34 @@ def test_first_within_matches_linear_scan(gpu):
     ref = oracle.first_within(cloud, keys, 0.05)
     assert (idx == ref).all()
     assert idx[7] == -1 and (idx[::50][1:] == -1).all() and (idx >= 0).sum() > 500
+
+
+@pytest.mark.parametrize("leaf", [0.025, 0.1])
+def test_voxel_grid_matches_pcl_restatement(gpu, leaf):
+    """pcl::VoxelGrid (reference src/segmentation.cpp:69-74): same voxels, same order, same colours;
+    coordinates within float rounding of the float-accumulated centroid"""
+    pts = synth.with_rgb_stride(synth.corridor_cloud(200000, synth.SEED_A, layer="objects"))
+    pts[17, 0] = np.nan
+    with capi.Index(pts[:64]) as ctx:
+        out = ctx.voxel_grid(pts, leaf, has_rgb=True)
+    ref, nv = oracle.voxel_grid(pts, leaf, has_rgb=True)
+    assert len(out) == nv and nv < len(pts)
+    # PCL sums a voxel's points in float (error ~ count * 6e-8 * |coordinate|, larger voxels hold more
+    # points); the GPU sums in double and rounds once
+    assert np.allclose(out[:, :3], ref[:, :3], rtol=0, atol=1e-5 if leaf < 0.05 else 3e-4)
+    assert (out[:, 4].view(np.uint32) == ref[:, 4].view(np.uint32)).all()
+    # every centroid lies in its own voxel, voxels ascend like PCL's sorted index
+    inv = np.float32(1.0) / np.float32(leaf)
+    lo = np.floor(np.nanmin(pts[:, :3], axis=0) * inv)
+    ijk = (np.floor(out[:, :3] * inv) - lo).astype(np.float64)
+    dims = (np.floor(np.nanmax(pts[:, :3], axis=0) * inv) - lo + 1).astype(np.float64)
+    key = ijk[:, 0] + ijk[:, 1] * dims[0] + ijk[:, 2] * dims[0] * dims[1]
+    assert (np.diff(key) > 0).mean() > 0.999  # a centroid may round onto a voxel face
+
+
+def test_voxel_grid_refuses_absurd_leaf(gpu):
+    pts = synth.corridor_cloud(5000, synth.SEED_A)
+    with capi.Index(pts) as ctx:
+        with pytest.raises(capi.PccError) as e:
+            ctx.voxel_grid(pts, 1e-4)
+    assert e.value.status == -5
