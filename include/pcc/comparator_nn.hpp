@@ -216,4 +216,82 @@ private:
     typename PointCloud<PointT>::ConstPtr input_;
 };
 
+// ---- pcl::NormalEstimation (src/segmentation.cpp:232-241) ----------------------------------------------
+template <class PointT, class NormalT = Normal>
+class NormalEstimation {
+public:
+    void setSearchMethod(const typename search::KdTree<PointT>::Ptr& tree) { tree_ = tree; }
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    void setKSearch(int k) { k_ = k; }
+    void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; }
+    void compute(PointCloud<NormalT>& out) {
+        out.points.clear();
+        out.width = 0;
+        out.height = 1;
+        if (!input_ || input_->empty() || k_ < 1) return;
+        if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
+        if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
+        if (!tree_->handle()) return;
+        std::vector<float> nc(input_->size() * 4);
+        check(pcc_normals(tree_->handle(), k_, vp_, PCC_MEM_HOST, nc.data()));
+        out.points.resize(input_->size());
+        out.width = (std::uint32_t)input_->size();
+        out.is_dense = true;
+        for (size_t i = 0; i < out.points.size(); ++i) {
+            NormalT& q = out.points[i];
+            q.normal_x = nc[4 * i]; q.normal_y = nc[4 * i + 1]; q.normal_z = nc[4 * i + 2]; q.curvature = nc[4 * i + 3];
+            if (!std::isfinite(q.normal_x)) out.is_dense = false;  // as PCL flags NaN normals
+        }
+    }
+
+private:
+    typename search::KdTree<PointT>::Ptr tree_;
+    typename PointCloud<PointT>::ConstPtr input_;
+    int k_ = 0;
+    float vp_[3] = {0.f, 0.f, 0.f};
+};
+
+// ---- pcl::RegionGrowing (src/segmentation.cpp:259-271) -------------------------------------------------
+template <class PointT, class NormalT = Normal>
+class RegionGrowing {
+public:
+    void setMinClusterSize(int n) { min_ = n; }
+    void setMaxClusterSize(int n) { max_ = n; }
+    void setSearchMethod(const typename search::KdTree<PointT>::Ptr& tree) { tree_ = tree; }
+    void setNumberOfNeighbours(unsigned int k) { k_ = k; }
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    void setInputNormals(const typename PointCloud<NormalT>::ConstPtr& n) { normals_ = n; }
+    void setSmoothnessThreshold(float theta) { theta_ = theta; }
+    void setCurvatureThreshold(float c) { curvature_ = c; }
+    void extract(std::vector<PointIndices>& clusters) {
+        clusters.clear();
+        // PCL's prepareForSegmentation: no cloud, no normals or a size mismatch -> empty result
+        if (!input_ || input_->empty() || !normals_ || normals_->size() != input_->size() || k_ == 0) return;
+        if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
+        if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
+        if (!tree_->handle()) return;
+        const size_t n = input_->size();
+        std::vector<float> nc(n * 4);
+        for (size_t i = 0; i < n; ++i) {
+            const NormalT& q = normals_->points[i];
+            nc[4 * i] = q.normal_x; nc[4 * i + 1] = q.normal_y; nc[4 * i + 2] = q.normal_z; nc[4 * i + 3] = q.curvature;
+        }
+        std::vector<int32_t> labels(n);
+        int32_t ncl = 0;
+        check(pcc_region_growing(tree_->handle(), nc.data(), PCC_MEM_HOST, (int)k_, theta_, curvature_, (uint32_t)min_,
+                                 (uint32_t)max_, labels.data(), &ncl));
+        clusters.resize(ncl);
+        for (size_t i = 0; i < n; ++i)  // assembleRegions fills every cluster in ascending point order
+            if (labels[i] >= 0) clusters[labels[i]].indices.push_back((int)i);
+    }
+
+private:
+    int min_ = 1, max_ = 0x7fffffff;
+    unsigned int k_ = 30;
+    float theta_ = 30.0f / 180.0f * 3.14159265358979f, curvature_ = 0.05f;
+    typename search::KdTree<PointT>::Ptr tree_;
+    typename PointCloud<PointT>::ConstPtr input_;
+    typename PointCloud<NormalT>::ConstPtr normals_;
+};
+
 }  // namespace pcc

@@ -28,6 +28,13 @@ template <int N>
 struct Histogram {
     float histogram[N];
 };
+// pcl::Normal: normal[3] + pad, curvature + pad (32 bytes)
+struct alignas(16) Normal {
+    float normal_x = 0, normal_y = 0, normal_z = 0, pad_ = 0;
+    float curvature = 0;
+    float pad2_[3] = {0, 0, 0};
+};
+static_assert(sizeof(Normal) == 32, "PCL layout");
 static_assert(sizeof(PointXYZ) == 16 && sizeof(PointXYZRGB) == 32 && sizeof(Histogram<32>) == 128, "PCL layouts");
 
 struct PointIndices {

@@ -184,6 +184,31 @@ int pcc_match_knn(pcc_index *index_des1, const void *des2, size_t n2,
 int pcc_voxel_grid(pcc_index *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
                    float leaf, int has_rgb, void *out, size_t out_stride, size_t *out_n);
 
+/* ---- normals + region growing (default segmentation path) --------------------------------------
+ * pcc_normals replaces: pcl::NormalEstimation<PointXYZRGB, pcl::Normal> with setSearchMethod(tree),
+ *   setKSearch(k), compute (src/segmentation.cpp:232-241, k = 50; viewpoint left at (0,0,0)).
+ *   Per point of the index: its k nearest neighbours (itself first), PCL's single-pass float
+ *   mean/covariance in neighbour order, the smallest eigenpair in closed form (pcl::eigen33),
+ *   curvature = |lambda_0 / trace|, normal flipped towards the viewpoint.
+ * out[n][4] floats (memory space `mem`): nx, ny, nz, curvature.  NaN for non-finite points and when
+ *   fewer than 3 neighbours exist.  viewpoint may be NULL (= origin).
+ * pcc_region_growing replaces: pcl::RegionGrowing<PointXYZRGB, pcl::Normal> with setSearchMethod,
+ *   setNumberOfNeighbours(k), setSmoothnessThreshold, setCurvatureThreshold, setMin/MaxClusterSize,
+ *   setInputCloud / setInputNormals, extract (src/segmentation.cpp:259-271: 50, 1000000, k = 100,
+ *   3/180*pi, 1.0).  The k-neighbour rows of every point are searched on the GPU in one batch
+ *   (PCL: findPointNeighbours, one nearestKSearch per point); regions then grow in PCL's order --
+ *   seeds by ascending curvature, breadth first through the rows while
+ *   |n_current . n_neighbour| >= cos(smoothness); a neighbour continues the walk when its curvature
+ *   is <= curvature_threshold.
+ * normals[n][4] as pcc_normals writes them (memory space `mem`); labels[n] (memory space `mem`):
+ *   index of the kept cluster, in PCL's output order (creation order), or -1;
+ *   *n_clusters (host) = clusters.size().  Equal curvatures are taken in index order (PCL:
+ *   std::sort, unspecified). */
+int pcc_normals(pcc_index *index, int k, const float viewpoint[3], int mem, float *out);
+int pcc_region_growing(pcc_index *index, const float *normals, int mem, int k, float smoothness,
+                       float curvature_threshold, uint32_t min_size, uint32_t max_size,
+                       int32_t *labels, int32_t *n_clusters);
+
 /* ---- first point within a radius ----------------------------------------------------------------
  * replaces: the O(S*N) linear scan in processRIFTwithSIFT (src/comparator.cpp:696-713) that snaps
  *   every SIFT keypoint to the FIRST cloud point j (lowest index) with

@@ -487,6 +487,185 @@ void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry,
     }
 }
 
+/* ======== NormalEstimation (src/segmentation.cpp:232-241) [PCL 1.7, recalled] ======= */
+
+/* pcl::computeRoots2 */
+static void roots2(float b, float c, float r[3]) {
+    r[0] = 0.0f;
+    float d = b * b - 4.0f * c;
+    if (d < 0.0f) d = 0.0f;
+    float sd = sqrtf(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+/* pcl::computeRoots: eigenvalues of a symmetric 3x3 (row-major m[9]) in increasing order */
+static void roots3(const float m[9], float r[3]) {
+    float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    float c2 = m[0] + m[4] + m[8];
+    if (fabsf(c0) < FLT_EPSILON) { roots2(c2, c1, r); return; }
+    const float s_inv3 = (float)(1.0 / 3.0), s_sqrt3 = sqrtf(3.0f);
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    float rho = sqrtf(-a_over_3);
+    float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+    float ct = cosf(theta), st = sinf(theta);
+    r[0] = c2_over_3 + 2.0f * rho * ct;
+    r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    float t;
+    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    if (r[1] >= r[2]) {
+        t = r[1]; r[1] = r[2]; r[2] = t;
+        if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    }
+    if (r[0] <= 0.0f) roots2(c2, c1, r);
+}
+static void cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* pcl::eigen33 (smallest eigenpair) + solvePlaneParameters */
+static void plane_params(const float cov[9], float n[3], float *curvature) {
+    float scale = 0.0f;
+    for (int i = 0; i < 9; ++i) if (fabsf(cov[i]) > scale) scale = fabsf(cov[i]);
+    if (scale <= FLT_MIN) scale = 1.0f;
+    float sm[9], ev[3];
+    for (int i = 0; i < 9; ++i) sm[i] = cov[i] / scale;
+    roots3(sm, ev);
+    float eigenvalue = ev[0] * scale;
+    sm[0] -= ev[0]; sm[4] -= ev[0]; sm[8] -= ev[0];
+    float v1[3], v2[3], v3[3];
+    cross3(sm + 0, sm + 3, v1);
+    cross3(sm + 0, sm + 6, v2);
+    cross3(sm + 3, sm + 6, v3);
+    float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+    float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+    float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+    const float *v; float l;
+    if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
+    else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
+    else { v = v3; l = l3; }
+    float s = sqrtf(l);
+    n[0] = v[0] / s; n[1] = v[1] / s; n[2] = v[2] / s;
+    float eig_sum = cov[0] + cov[4] + cov[8];
+    *curvature = eig_sum != 0.0f ? fabsf(eigenvalue / eig_sum) : 0.0f;
+}
+
+static void normal_of(const void *pts, size_t stride, const int32_t *nbr, int cnt, const float *p, const float vp[3], float *o) {
+    if (cnt < 3) { o[0] = o[1] = o[2] = o[3] = NAN; return; }
+    /* computeMeanAndCovarianceMatrix: single pass, float accumulators */
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < cnt; ++j) {
+        const float *q = pt_at(pts, stride, (size_t)nbr[j]);
+        a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2];
+        a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
+        a[6] += q[0]; a[7] += q[1]; a[8] += q[2];
+    }
+    for (int i = 0; i < 9; ++i) a[i] /= (float)cnt;
+    float cov[9];
+    cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+    cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float n[3], curv;
+    plane_params(cov, n, &curv);
+    /* flipNormalTowardsViewpoint */
+    float vx = vp[0] - p[0], vy = vp[1] - p[1], vz = vp[2] - p[2];
+    float cos_theta = vx * n[0] + vy * n[1] + vz * n[2];
+    if (cos_theta < 0) { n[0] *= -1; n[1] *= -1; n[2] *= -1; }
+    o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = curv;
+}
+
+void orc_normals_from_neighbours(const void *pts, size_t n, size_t stride, const int32_t *nbr, int k,
+                                 const float vp[3], float *out) {
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = pt_at(pts, stride, i);
+        int cnt = 0;
+        while (cnt < k && nbr[i * k + cnt] >= 0) ++cnt;
+        if (!finite3(p)) cnt = 0;
+        normal_of(pts, stride, nbr + i * k, cnt, p, vp, out + i * 4);
+    }
+}
+
+void orc_normals(const void *pts, size_t n, size_t stride, int k, const float vp[3], float *out) {
+    orc_kdtree *t = orc_kdtree_build(pts, n, stride);
+    int32_t *ni = (int32_t *)malloc(sizeof(int32_t) * k);
+    float *nd = (float *)malloc(sizeof(float) * k);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = pt_at(pts, stride, i);
+        int cnt = (t && finite3(p)) ? orc_kdtree_knn(t, p, k, ni, nd) : 0;
+        normal_of(pts, stride, ni, cnt, p, vp, out + i * 4);
+    }
+    free(ni); free(nd);
+    orc_kdtree_free(t);
+}
+
+/* ======== RegionGrowing (src/segmentation.cpp:259-271) [PCL 1.7, recalled] ========= */
+
+typedef struct { float c; int32_t i; } resid_t;
+static int resid_cmp(const void *a, const void *b) {
+    const resid_t *x = (const resid_t *)a, *y = (const resid_t *)b;
+    int nx = x->c != x->c, ny = y->c != y->c; /* NaN curvature (no normal): last */
+    if (nx != ny) return nx - ny;
+    if (x->c < y->c) return -1;
+    if (x->c > y->c) return 1;
+    return (x->i > y->i) - (x->i < y->i); /* std::sort leaves equal curvatures unspecified; index order here */
+}
+
+int orc_region_growing(size_t n, const float *normals, const int32_t *nbr, int k, float smoothness,
+                       float curvature_threshold, int min_size, int max_size, int32_t *labels) {
+    int32_t *seg = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) seg[i] = -1;
+    resid_t *res = (resid_t *)malloc(sizeof(resid_t) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) { res[i].c = normals[i * 4 + 3]; res[i].i = (int32_t)i; }
+    qsort(res, n, sizeof(resid_t), resid_cmp);
+    int32_t *queue = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    int *seg_size = (int *)malloc(sizeof(int) * (n ? n : 1));
+    const float cosine_threshold = cosf(smoothness);
+    size_t segmented = 0, seed_counter = 0;
+    int nseg = 0;
+    int32_t seed = n ? res[0].i : 0;
+    while (segmented < n) {
+        /* growRegion */
+        size_t qh = 0, qt = 0;
+        queue[qt++] = seed;
+        seg[seed] = nseg;
+        int cnt = 1;
+        while (qh < qt) {
+            int32_t cur = queue[qh++];
+            const float *nc = normals + (size_t)cur * 4;
+            for (int j = 0; j < k; ++j) {
+                int32_t idx = nbr[(size_t)cur * k + j];
+                if (idx < 0) break;
+                if (seg[idx] != -1) continue;
+                /* validatePoint, smooth mode: angle between the CURRENT seed's normal and the neighbour's */
+                const float *nn = normals + (size_t)idx * 4;
+                float dot = fabsf(nn[0] * nc[0] + nn[1] * nc[1] + nn[2] * nc[2]);
+                if (dot < cosine_threshold) continue;
+                seg[idx] = nseg;
+                ++cnt;
+                if (!(nn[3] > curvature_threshold)) queue[qt++] = idx;
+            }
+        }
+        seg_size[nseg++] = cnt;
+        segmented += (size_t)cnt;
+        for (size_t s = seed_counter + 1; s < n; ++s)
+            if (seg[res[s].i] == -1) { seed = res[s].i; seed_counter = s; break; }
+    }
+    /* assembleRegions + size filter: kept clusters keep their creation order */
+    int32_t *remap = (int32_t *)malloc(sizeof(int32_t) * (nseg ? nseg : 1));
+    int kept = 0;
+    for (int s = 0; s < nseg; ++s) remap[s] = (seg_size[s] >= min_size && seg_size[s] <= max_size) ? kept++ : -1;
+    for (size_t i = 0; i < n; ++i) labels[i] = seg[i] >= 0 ? remap[seg[i]] : -1;
+    free(remap); free(seg_size); free(queue); free(res); free(seg);
+    return kept;
+}
+
 /* ============ VoxelGrid (src/segmentation.cpp:69-74, 224-229) ============== */
 
 typedef struct { unsigned int idx; unsigned int pt; } vox_t;

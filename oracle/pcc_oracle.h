@@ -84,6 +84,27 @@ int orc_match_rift_knn(const void *des1, size_t n1, const void *des2, size_t n2,
 void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry, size_t n, size_t qstride,
                       double radius, int32_t *idx);
 
+/* pcl::NormalEstimation<PointT, pcl::Normal> with setKSearch(k) and the default viewpoint (0,0,0)
+ * (src/segmentation.cpp:232-241, K = 50) [recalled from PCL 1.7 features/normal_3d.h, common/centroid.hpp,
+ * common/eigen.hpp]: per point the k nearest neighbours (itself included), single-pass float
+ * mean/covariance (accu[9] / n, cov = E[xx] - E[x]E[x]), smallest eigenpair by pcl::eigen33 (closed-form
+ * roots), curvature = |lambda0 / trace|, normal flipped towards the viewpoint.  out: n x 4 floats
+ * (nx, ny, nz, curvature); NaN for non-finite points or fewer than 3 neighbours. */
+void orc_normals(const void *pts, size_t n, size_t stride, int k, const float vp[3], float *out);
+/* the same arithmetic on given neighbour lists (n rows of k indices, -1 = unused) */
+void orc_normals_from_neighbours(const void *pts, size_t n, size_t stride, const int32_t *nbr, int k,
+                                 const float vp[3], float *out);
+
+/* pcl::RegionGrowing<PointT, pcl::Normal>::extract (src/segmentation.cpp:259-271: min 50, max 1e6,
+ * 100 neighbours, smoothness 3 deg, curvature threshold 1) [recalled from PCL 1.7
+ * segmentation/impl/region_growing.hpp]: points sorted by curvature, regions grown through the
+ * precomputed neighbour lists while |n_seed . n_nbr| >= cos(theta); a neighbour becomes a seed when its
+ * curvature <= the threshold.  nbr: n rows of k indices (ascending distance, itself first).
+ * labels[i] = index of the kept cluster (in PCL's output order) or -1.  Returns the cluster count. */
+int orc_region_growing(size_t n, const float *normals /* n x 4 */, const int32_t *nbr, int k,
+                       float smoothness, float curvature_threshold, int min_size, int max_size,
+                       int32_t *labels);
+
 /* pcl::VoxelGrid<PointXYZRGB>::applyFilter with setLeafSize(leaf, leaf, leaf), downsample_all_data
  * (src/segmentation.cpp:69-74, 224-229; pcl/filters/impl/voxel_grid.hpp [recalled]): voxel index
  * floor(p*inv) - min_b on the world-aligned lattice, points grouped by index (ascending), centroid =

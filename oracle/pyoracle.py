@@ -48,6 +48,11 @@ def lib() -> C.CDLL:
         L.orc_kdtree_nn1_batch.restype = None
         L.orc_kdtree_nn1_batch_mt.argtypes = [vp, vp, sz, sz, vp, vp, i32]
         L.orc_kdtree_nn1_batch_mt.restype = None
+        L.orc_normals.argtypes = [vp, sz, sz, i32, vp, vp]
+        L.orc_normals.restype = None
+        L.orc_normals_from_neighbours.argtypes = [vp, sz, sz, vp, i32, vp, vp]
+        L.orc_normals_from_neighbours.restype = None
+        L.orc_region_growing.argtypes = [sz, vp, vp, i32, C.c_float, C.c_float, i32, i32, vp]
         L.orc_voxel_grid.argtypes = [vp, sz, sz, C.c_float, i32, vp, sz]
         L.orc_voxel_grid.restype = C.c_long
         L.orc_first_within.argtypes = [vp, sz, sz, vp, sz, sz, C.c_double, vp]
@@ -180,6 +185,27 @@ class KdTree:
         sums = np.zeros(17, np.float64)
         lib().orc_icp_step_sums(self._h, tp, ts, sp, n, ss, idx.ctypes.data, d2.ctypes.data, sums.ctypes.data)
         return idx, d2, sums
+
+
+def normals(pts, k, viewpoint=(0.0, 0.0, 0.0), neighbours=None):
+    a, ap, n, s1 = _f32(pts)
+    vpt = np.asarray(viewpoint, np.float32)
+    out = np.empty((n, 4), np.float32)
+    if neighbours is None:
+        lib().orc_normals(ap, n, s1, k, vpt.ctypes.data, out.ctypes.data)
+    else:
+        nb = np.ascontiguousarray(neighbours, dtype=np.int32)
+        lib().orc_normals_from_neighbours(ap, n, s1, nb.ctypes.data, nb.shape[1], vpt.ctypes.data, out.ctypes.data)
+    return out
+
+
+def region_growing(normals4, neighbours, smoothness, curvature_threshold, min_size, max_size):
+    nm = np.ascontiguousarray(normals4, dtype=np.float32)
+    nb = np.ascontiguousarray(neighbours, dtype=np.int32)
+    labels = np.empty(len(nm), np.int32)
+    ncl = lib().orc_region_growing(len(nm), nm.ctypes.data, nb.ctypes.data, nb.shape[1], np.float32(smoothness),
+                                   np.float32(curvature_threshold), min_size, max_size, labels.ctypes.data)
+    return labels, ncl
 
 
 def voxel_grid(pts, leaf, has_rgb=False):

@@ -28,6 +28,7 @@ SYMBOLS = [
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
+    "pcc_normals", "pcc_region_growing",
 ]
 
 
@@ -76,6 +77,8 @@ def _load() -> C.CDLL:
     lib.pcc_knn.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp]
     lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_first_within.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
+    lib.pcc_normals.argtypes = [vp, i32, vp, i32, vp]
+    lib.pcc_region_growing.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
     lib.pcc_voxel_grid.argtypes = [vp, vp, sz, sz, i32, C.c_float, i32, vp, sz, C.POINTER(sz)]
     lib.pcc_radius_fill.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, vp]
     lib.pcc_euclidean_clusters.argtypes = [vp, C.c_double, C.c_uint32, C.c_uint32, i32, vp,
@@ -294,6 +297,44 @@ class Index:
         _check(LIB.pcc_sor(self._h, mean_k, float(stddev_mult), MEM_HOST, md.ctypes.data, inl.ctypes.data,
                            C.byref(thr), C.byref(kept)))
         return md, inl, thr.value, kept.value
+
+    def normals(self, k: int = 50, viewpoint=None, device=None):
+        """pcl::NormalEstimation over the index's own points: (n, 4) = nx, ny, nz, curvature.
+        device: a torch cuda device to get the result as a device tensor."""
+        vp = None
+        if viewpoint is not None:
+            vpa = np.ascontiguousarray(viewpoint, dtype=np.float32)
+            vp = vpa.ctypes.data
+        if device is not None:
+            import torch
+            out = torch.empty((self.n_original, 4), dtype=torch.float32, device=device)
+            _check(LIB.pcc_normals(self._h, k, vp, MEM_DEVICE, out.data_ptr()))
+            self.sync()
+            return out
+        out = np.empty((self.n_original, 4), dtype=np.float32)
+        _check(LIB.pcc_normals(self._h, k, vp, MEM_HOST, out.ctypes.data))
+        return out
+
+    def region_growing(self, normals, k: int = 100, smoothness: float = 3.0 / 180.0 * np.pi,
+                       curvature_threshold: float = 1.0, min_size: int = 50, max_size: int = 1000000):
+        """pcl::RegionGrowing::extract over the index's own points: (labels, n_clusters)."""
+        ncl = C.c_int32(0)
+        if _is_torch(normals) and normals.is_cuda:
+            import torch
+            assert normals.dtype == torch.float32 and normals.is_contiguous()
+            labels = torch.empty(self.n_original, dtype=torch.int32, device=normals.device)
+            torch.cuda.current_stream(normals.device).synchronize()
+            _check(LIB.pcc_region_growing(self._h, normals.data_ptr(), MEM_DEVICE, k, np.float32(smoothness),
+                                          np.float32(curvature_threshold), min_size, max_size, labels.data_ptr(),
+                                          C.byref(ncl)))
+            return labels, ncl.value
+        nm = np.ascontiguousarray(normals, dtype=np.float32)
+        assert nm.shape == (self.n_original, 4)
+        labels = np.empty(self.n_original, dtype=np.int32)
+        _check(LIB.pcc_region_growing(self._h, nm.ctypes.data, MEM_HOST, k, np.float32(smoothness),
+                                      np.float32(curvature_threshold), min_size, max_size, labels.ctypes.data,
+                                      C.byref(ncl)))
+        return labels, ncl.value
 
     def icp_step(self, src, want_corr: bool = True):
         ptr, n, stride, mem = _points(src)

@@ -466,6 +466,68 @@ int pcc_voxel_grid(pcc_index* ix, const void* pts, size_t n, size_t stride, int 
     return voxel_grid(ix, pts, n, stride, mem, leaf, has_rgb, out, out_stride, out_n);
 }
 
+int pcc_normals(pcc_index* ix, int k, const float viewpoint[3], int mem, float* out) {
+    PCC_ENTER(ix);
+    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
+    if (!out) { set_error("null output"); return PCC_ERR_INVALID; }
+    if (k < 1 || k > PCC_KNN_MAX_K) { set_error("k=%d outside [1, %d]", k, PCC_KNN_MAX_K); return PCC_ERR_UNSUPPORTED; }
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    const size_t n = ix->n_orig;
+    const float origin[3] = {0.f, 0.f, 0.f};
+    // self query on the packed references, as pcc_sor does
+    PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
+    auto* keys = ix->out_packed.as<unsigned long long>();
+    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, keys));
+    float4* dout = reinterpret_cast<float4*>(out);
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_d2.reserve(n * sizeof(float4))); dout = ix->out_d2.as<float4>(); }
+    PCC_TRY(launch_normals(ix->stream, keys, ix->refs.as<float4>(), n, k, viewpoint ? viewpoint : origin, dout));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, reinterpret_cast<const float*>(dout), out, n * 4, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+int pcc_region_growing(pcc_index* ix, const float* normals, int mem, int k, float smoothness,
+                       float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels,
+                       int32_t* n_clusters) {
+    PCC_ENTER(ix);
+    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
+    if (!normals || !labels || !n_clusters) { set_error("null argument"); return PCC_ERR_INVALID; }
+    if (k < 1 || k > PCC_KNN_MAX_K) { set_error("k=%d outside [1, %d]", k, PCC_KNN_MAX_K); return PCC_ERR_UNSUPPORTED; }
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    const size_t n = ix->n_orig;
+    // findPointNeighbours: one batched self k-NN; only the indices travel to the host
+    PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
+    auto* keys = ix->out_packed.as<unsigned long long>();
+    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, keys));
+    PCC_TRY(ix->out_idx.reserve(n * (size_t)k * sizeof(int32_t)));
+    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, n * (size_t)k, ix->out_idx.as<int32_t>(), nullptr));
+    ev_mark(ix, EV_CALL1);
+    std::vector<int32_t> nbr(n * (size_t)k), hl(n);
+    PCC_HIP(hipMemcpyAsync(nbr.data(), ix->out_idx.p, nbr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    std::vector<float> hn;
+    const float* nh = normals;
+    if (mem == PCC_MEM_DEVICE) {
+        hn.resize(n * 4);
+        PCC_HIP(hipMemcpyAsync(hn.data(), normals, hn.size() * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+        nh = hn.data();
+    }
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    PCC_TRY(region_growing_host(n, nh, nbr.data(), k, smoothness, curvature_threshold, min_size, max_size, hl.data(), n_clusters));
+    if (mem == PCC_MEM_HOST) memcpy(labels, hl.data(), n * sizeof(int32_t));
+    else {
+        PCC_HIP(hipMemcpyAsync(labels, hl.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
 int pcc_first_within(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int32_t* idx) {
     PCC_ENTER(ix);
     PCC_TRY(check_points(q, nq, stride, mem));

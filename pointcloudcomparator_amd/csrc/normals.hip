@@ -1,0 +1,191 @@
+// normals.hip -- surface normals + curvature from k-neighbourhoods, and region growing over the
+// same neighbourhoods: the default segmentation path of the reference
+// (src/segmentation.cpp:232-241 pcl::NormalEstimation setKSearch(50); :259-271 pcl::RegionGrowing
+// with 100 neighbours, 3 degrees, curvature threshold 1).
+//
+// The neighbourhoods come from the wave-cooperative self k-NN (knn.hip).  k_normals is one lane
+// per point: it walks its row of keys in ascending (d2, index) order -- the order PCL's
+// nearestKSearch hands to computeMeanAndCovarianceMatrix -- so the float accumulators round
+// exactly as PCL's do, then solves the smallest eigenpair in closed form the way pcl::eigen33
+// does.  The three transcendental calls are evaluated in double and rounded once, which matches
+// a correctly rounded libm float result.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "pcc_internal.hpp"
+
+namespace pcc {
+
+namespace {
+
+__device__ __forceinline__ void roots2(float b, float c, float r[3]) {
+    r[0] = 0.f;
+    float d = b * b - 4.f * c;
+    if (d < 0.f) d = 0.f;
+    const float sd = sqrtf(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+
+// eigenvalues of the (scaled) symmetric matrix, increasing; pcl::computeRoots
+__device__ __forceinline__ void roots3(const float m[9], float r[3]) {
+    const float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    const float c2 = m[0] + m[4] + m[8];
+    if (fabsf(c0) < 1.1920929e-07f) { roots2(c2, c1, r); return; }
+    const float s_inv3 = (float)(1.0 / 3.0);
+    const float s_sqrt3 = 1.7320508f;  // sqrtf(3.0f)
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.f) q = 0.f;
+    const float rho = sqrtf(-a_over_3);
+    const float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
+    const float ct = (float)cos((double)theta), st = (float)sin((double)theta);
+    r[0] = c2_over_3 + 2.f * rho * ct;
+    r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    float t;
+    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    if (r[1] >= r[2]) {
+        t = r[1]; r[1] = r[2]; r[2] = t;
+        if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    }
+    if (r[0] <= 0.f) roots2(c2, c1, r);
+}
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ void __launch_bounds__(256)
+k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict__ refs, size_t n, int K,
+          float vpx, float vpy, float vpz, float4* __restrict__ out) {
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long* row = keys + i * (size_t)K;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+        int cnt = 0;
+        // rows of flagged (non-finite) points were never written: first key is ~0
+        unsigned long long key = row[0];
+        while (key != ~0ull) {
+            const float4 p = refs[(unsigned int)key];
+            ++cnt;
+            key = cnt < K ? row[cnt] : ~0ull;
+            a0 += p.x * p.x; a1 += p.x * p.y; a2 += p.x * p.z;
+            a3 += p.y * p.y; a4 += p.y * p.z; a5 += p.z * p.z;
+            a6 += p.x; a7 += p.y; a8 += p.z;
+        }
+        if (cnt < 3) { out[i] = make_float4(qnan, qnan, qnan, qnan); continue; }
+        const float fc = (float)cnt;
+        a0 /= fc; a1 /= fc; a2 /= fc; a3 /= fc; a4 /= fc; a5 /= fc; a6 /= fc; a7 /= fc; a8 /= fc;
+        float cov[9];
+        cov[0] = a0 - a6 * a6; cov[1] = a1 - a6 * a7; cov[2] = a2 - a6 * a8;
+        cov[4] = a3 - a7 * a7; cov[5] = a4 - a7 * a8; cov[8] = a5 - a8 * a8;
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        // pcl::eigen33: scale, roots, eigenvector of the smallest root from the largest row cross product
+        float scale = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) scale = fmaxf(scale, fabsf(cov[j]));
+        if (scale <= 1.17549435e-38f) scale = 1.f;
+        float sm[9], ev[3];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sm[j] = cov[j] / scale;
+        roots3(sm, ev);
+        const float eigenvalue = ev[0] * scale;
+        sm[0] -= ev[0]; sm[4] -= ev[0]; sm[8] -= ev[0];
+        float v1[3], v2[3], v3[3];
+        cross3(sm + 0, sm + 3, v1);
+        cross3(sm + 0, sm + 6, v2);
+        cross3(sm + 3, sm + 6, v3);
+        const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+        const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+        const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+        float vx, vy, vz, l;
+        if (l1 >= l2 && l1 >= l3) { vx = v1[0]; vy = v1[1]; vz = v1[2]; l = l1; }
+        else if (l2 >= l1 && l2 >= l3) { vx = v2[0]; vy = v2[1]; vz = v2[2]; l = l2; }
+        else { vx = v3[0]; vy = v3[1]; vz = v3[2]; l = l3; }
+        const float s = sqrtf(l);
+        float nx = vx / s, ny = vy / s, nz = vz / s;
+        const float eig_sum = cov[0] + cov[4] + cov[8];
+        const float curv = eig_sum != 0.f ? fabsf(eigenvalue / eig_sum) : 0.f;
+        // flipNormalTowardsViewpoint
+        const float4 p = refs[i];
+        const float dx = vpx - p.x, dy = vpy - p.y, dz = vpz - p.z;
+        const float cos_theta = dx * nx + dy * ny + dz * nz;
+        if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+        out[i] = make_float4(nx, ny, nz, curv);
+    }
+}
+
+}  // namespace
+
+int launch_normals(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
+                   const float vp[3], float4* out) {
+    if (n == 0) return PCC_OK;
+    const size_t blocks = std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_normals, dim3((unsigned)blocks), dim3(256), 0, s, keys, refs, n, K, vp[0], vp[1], vp[2], out);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+// pcl::RegionGrowing::extract over precomputed neighbour rows (host side of pcc_region_growing).
+// Regions are grown in PCL's order: seeds by ascending curvature (ties: lower index), each region
+// a breadth-first walk of the neighbour rows; a neighbour joins when |n_cur . n_nbr| >= cos(theta)
+// and continues the walk when its curvature is not above the threshold.
+int region_growing_host(size_t n, const float* normals4, const int32_t* nbr, int K, float smoothness,
+                        float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels,
+                        int32_t* n_clusters) {
+    std::vector<int32_t> seg(n, -1), order(n), queue(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+    // NaN curvatures (points without a normal) go last; PCL's std::sort leaves them unspecified
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        const float ca = normals4[(size_t)a * 4 + 3], cb = normals4[(size_t)b * 4 + 3];
+        const bool na = ca != ca, nb = cb != cb;
+        if (na != nb) return nb;
+        if (!na && ca != cb) return ca < cb;
+        return a < b;
+    });
+    std::vector<uint32_t> seg_size;
+    const float cosine_threshold = cosf(smoothness);
+    size_t segmented = 0, seed_pos = 0;
+    while (segmented < n) {
+        while (seg[order[seed_pos]] != -1) ++seed_pos;
+        const int32_t id = (int32_t)seg_size.size();
+        size_t qh = 0, qt = 0;
+        queue[qt++] = order[seed_pos];
+        seg[order[seed_pos]] = id;
+        uint32_t cnt = 1;
+        while (qh < qt) {
+            const int32_t cur = queue[qh++];
+            const float* nc = normals4 + (size_t)cur * 4;
+            const int32_t* row = nbr + (size_t)cur * K;
+            for (int j = 0; j < K; ++j) {
+                const int32_t t = row[j];
+                if (t < 0) break;
+                if (seg[t] != -1) continue;
+                const float* nn = normals4 + (size_t)t * 4;
+                const float dot = fabsf(nn[0] * nc[0] + nn[1] * nc[1] + nn[2] * nc[2]);
+                if (dot < cosine_threshold) continue;
+                seg[t] = id;
+                ++cnt;
+                if (!(nn[3] > curvature_threshold)) queue[qt++] = t;
+            }
+        }
+        seg_size.push_back(cnt);
+        segmented += cnt;
+    }
+    std::vector<int32_t> remap(seg_size.size());
+    int32_t kept = 0;
+    for (size_t s = 0; s < seg_size.size(); ++s) remap[s] = (seg_size[s] >= min_size && seg_size[s] <= max_size) ? kept++ : -1;
+    for (size_t i = 0; i < n; ++i) labels[i] = remap[seg[i]];
+    *n_clusters = kept;
+    return PCC_OK;
+}
+
+}  // namespace pcc

@@ -6,8 +6,10 @@
 //   cluster counts (:1199-1205) -> [-n] noise pass (:1520-1568) -> results file.
 // Same flags, banner lines, section strings and exit code (always 1, :1704).  NOT part of this build
 // (out of scope): descriptor pipelines (SIFT/RIFT) and the per-cluster matching /
-// scoring that needs them, region growing (the non -e default), the VoxelGrid + RANSAC prelude of the -e
-// path (clusters are extracted from the cloud as given) and the viewer (-v is accepted and ignored).
+// scoring that needs them, the RANSAC plane removal of the -e path (:79-117) and the viewer (-v is accepted
+// and ignored).  Both segmentation paths run: region growing (default, src/segmentation.cpp:218-327) and
+// Euclidean clustering (-e, :64-156), each behind the VoxelGrid the reference applies first.
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -62,6 +64,46 @@ static std::vector<PointCloud<PointXYZRGB>::Ptr> euclidean_cluster_segmentation(
     return clusters_pcl;
 }
 
+// src/segmentation.cpp:218-327 region_growing_segmentation: VoxelGrid 0.025 -> NormalEstimation K = 50 ->
+// RegionGrowing (50..1000000 points, 100 neighbours, 3 degrees, curvature 1)
+static std::vector<PointCloud<PointXYZRGB>::Ptr> region_growing_segmentation(const PointCloud<PointXYZRGB>::Ptr& point_cloud_ptr) {
+    VoxelGrid<PointXYZRGB> vg;
+    PointCloud<PointXYZRGB>::Ptr cloud_filtered(new PointCloud<PointXYZRGB>);
+    vg.setInputCloud(point_cloud_ptr);
+    vg.setLeafSize(0.025f, 0.025f, 0.025f);
+    vg.filter(*cloud_filtered);
+    std::cout << "PointCloud after filtering has: " << cloud_filtered->points.size() << " data points." << std::endl;
+    search::KdTree<PointXYZRGB>::Ptr tree(new search::KdTree<PointXYZRGB>);
+    PointCloud<Normal>::Ptr normals(new PointCloud<Normal>);
+    NormalEstimation<PointXYZRGB, Normal> normal_estimator;
+    normal_estimator.setSearchMethod(tree);
+    normal_estimator.setInputCloud(cloud_filtered);
+    normal_estimator.setKSearch(50);
+    normal_estimator.compute(*normals);
+    RegionGrowing<PointXYZRGB, Normal> reg;
+    reg.setMinClusterSize(50);
+    reg.setMaxClusterSize(1000000);
+    reg.setSearchMethod(tree);
+    reg.setNumberOfNeighbours(100);
+    reg.setInputCloud(cloud_filtered);
+    reg.setInputNormals(normals);
+    reg.setSmoothnessThreshold(3.0 / 180.0 * M_PI);
+    reg.setCurvatureThreshold(1);
+    std::vector<PointIndices> clusters;
+    reg.extract(clusters);
+    std::cout << "Number of clusters is equal to " << clusters.size() << std::endl;
+    std::vector<PointCloud<PointXYZRGB>::Ptr> clusters_pcl;
+    for (const PointIndices& c : clusters) {
+        PointCloud<PointXYZRGB>::Ptr cloud_cluster(new PointCloud<PointXYZRGB>);
+        for (int j : c.indices) cloud_cluster->points.push_back(cloud_filtered->points[j]);
+        cloud_cluster->width = (std::uint32_t)cloud_cluster->points.size();
+        cloud_cluster->height = 1;
+        cloud_cluster->is_dense = true;
+        clusters_pcl.push_back(cloud_cluster);
+    }
+    return clusters_pcl;
+}
+
 static double computeSimilarity(const std::string& file1, const std::string& file2, const std::string& results_path) {
     PointCloud<PointXYZRGB>::Ptr point_cloud1_ptr(new PointCloud<PointXYZRGB>), point_cloud2_ptr(new PointCloud<PointXYZRGB>);
     if (io::loadPLYFile(file1, *point_cloud1_ptr) == -1) {
@@ -108,7 +150,8 @@ static double computeSimilarity(const std::string& file1, const std::string& fil
         clusters_pcl_1 = euclidean_cluster_segmentation(point_cloud1_ptr);
         clusters_pcl_2 = euclidean_cluster_segmentation(point_cloud2_ptr);
     } else {
-        std::cout << "(region growing segmentation is not part of this build: run with -e)" << std::endl;
+        clusters_pcl_1 = region_growing_segmentation(point_cloud1_ptr);
+        clusters_pcl_2 = region_growing_segmentation(point_cloud2_ptr);
     }
     myfile << "Number of points of PCL 1: " << point_cloud1_ptr->points.size() << "\n";
     myfile << "Number of points of PCL 2: " << point_cloud2_ptr->points.size() << "\n";

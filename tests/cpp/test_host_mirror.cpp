@@ -2,6 +2,8 @@
 // reference's call sites use PCL: matchRIFTFeaturesKnn, performICP, SOR, EuclideanClusterExtraction,
 // per-point KdTree calls.  Checks are self-consistency properties (the bit-level parity against the
 // oracle lives in the Python GPU tests, through the same C-ABI).  Exit code 0 = pass, 77 = no GPU.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -81,6 +83,36 @@ int main() {
     }
     PointCloud<RIFT32>::Ptr empty(new PointCloud<RIFT32>);
     REQUIRE(matchRIFTFeaturesKnn(empty, dd).size() == 1);  // empty tree: only the dummy element
+
+    // NormalEstimation + RegionGrowing (src/segmentation.cpp:232-271): two perpendicular plates
+    PointCloud<PointXYZRGB>::Ptr plates(new PointCloud<PointXYZRGB>);
+    for (int i = 0; i < 3000; ++i) { PointXYZRGB p; p.x = 1 + U(rng); p.y = 1 + U(rng); p.z = 1 + 0.0005f * U(rng); plates->push_back(p); }
+    for (int i = 0; i < 3000; ++i) { PointXYZRGB p; p.x = 1 + U(rng); p.y = 3 + 0.0005f * U(rng); p.z = 1.2f + U(rng); plates->push_back(p); }
+    search::KdTree<PointXYZRGB>::Ptr ptree(new search::KdTree<PointXYZRGB>);
+    PointCloud<Normal>::Ptr normals(new PointCloud<Normal>);
+    NormalEstimation<PointXYZRGB, Normal> ne;
+    ne.setSearchMethod(ptree); ne.setInputCloud(plates); ne.setKSearch(50);
+    ne.compute(*normals);
+    REQUIRE(normals->size() == plates->size() && normals->is_dense);
+    for (int i = 0; i < 6000; ++i) {
+        const Normal& q = normals->points[i];
+        // flipped towards the origin: the z plate looks down, the y plate looks towards -y
+        if (i < 3000) REQUIRE(q.normal_z < -0.99f); else REQUIRE(q.normal_y < -0.99f);
+        REQUIRE(q.curvature >= 0.f && q.curvature < 0.01f);
+    }
+    RegionGrowing<PointXYZRGB, Normal> reg;
+    reg.setMinClusterSize(50); reg.setMaxClusterSize(1000000); reg.setSearchMethod(ptree);
+    reg.setNumberOfNeighbours(100); reg.setInputCloud(plates); reg.setInputNormals(normals);
+    reg.setSmoothnessThreshold(3.0 / 180.0 * M_PI); reg.setCurvatureThreshold(1);
+    std::vector<PointIndices> regions;
+    reg.extract(regions);
+    REQUIRE(regions.size() == 2);
+    for (auto& c : regions) { REQUIRE(c.indices.size() == 3000); REQUIRE(std::is_sorted(c.indices.begin(), c.indices.end())); }
+    REQUIRE((regions[0].indices[0] < 3000) != (regions[1].indices[0] < 3000));
+    RegionGrowing<PointXYZRGB, Normal> reg0;  // no normals set: PCL returns no clusters
+    reg0.setInputCloud(plates);
+    reg0.extract(regions);
+    REQUIRE(regions.empty());
     std::printf("host mirror ok\n");
     return 0;
 }

@@ -60,6 +60,44 @@ def test_cli_icp_clusters_noise(gpu, tmp_path):
     assert "----------------------------------------\n Noise analysis: \n" in txt
 
 
+def _walls(n_per, seed):
+    rng = np.random.default_rng(seed)
+    u, v = rng.random((2, n_per)) * 0.8
+    floor = np.stack([u, v, np.zeros_like(u)], 1)
+    u, v = rng.random((2, n_per)) * 0.8
+    wall1 = np.stack([u, np.full_like(u, 1.0), v + 0.2], 1)
+    u, v = rng.random((2, n_per)) * 0.8
+    wall2 = np.stack([np.full_like(u, 1.0), u, v + 0.2], 1)
+    pts = np.concatenate([floor, wall1, wall2]) + rng.normal(0, 0.001, (3 * n_per, 3)) + 1.0
+    return np.ascontiguousarray(pts[rng.permutation(len(pts))].astype(np.float32))
+
+
+def test_cli_region_growing_default(gpu, tmp_path):
+    """no -e: VoxelGrid 0.025 -> normals K=50 -> RegionGrowing (src/segmentation.cpp:218-327)"""
+    import re
+    a, b = _walls(8000, 3), _walls(6000, 4)
+    fa, fb, res = tmp_path / "a.ply", tmp_path / "b.ply", tmp_path / "results.txt"
+    write_ply(fa, a, fmt="binary")
+    write_ply(fb, b, fmt="binary")
+    r = subprocess.run([str(EXE), str(fa), str(fb), "--results", str(res)], capture_output=True, text=True, timeout=300)
+    out = r.stdout
+    assert r.returncode == 1
+    assert "Region growing segmentation was selected (default) as main segmentation algorithm." in out
+    got = [int(x) for x in re.findall(r"Number of clusters is equal to (\d+)", out)]
+    assert len(got) == 2
+    txt = res.read_text()
+    for i, cloud in enumerate((a, b)):
+        vox, nv = oracle.voxel_grid(cloud, 0.025)
+        assert f"PointCloud after filtering has: {nv} data points." in out
+        vox = np.ascontiguousarray(vox[:, :3])
+        nrm = oracle.normals(vox, 50)
+        nbr, _ = oracle.knn_exhaustive(vox, vox, 100)
+        lab, ncl = oracle.region_growing(nrm, nbr, 3.0 / 180.0 * np.pi, 1.0, 50, 1000000)
+        # centroids and root solver agree to float rounding, so a borderline 3-degree edge may differ
+        assert ncl >= 3 and abs(got[i] - ncl) <= max(2, ncl // 10), (got[i], ncl)
+        assert f"Number of clusters of PCL {i + 1}: {got[i]}\n" in txt
+
+
 def test_cli_missing_file_and_usage(gpu, tmp_path):
     r = subprocess.run([str(EXE), "-e", str(tmp_path / "x.ply"), str(tmp_path / "y.ply")], capture_output=True, text=True)
     assert "Was not able to open file" in r.stderr and r.returncode == 1

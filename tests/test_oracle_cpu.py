@@ -194,3 +194,57 @@ def test_voxel_grid_restatement_basics():
     assert np.allclose(out[0], [-0.01, 0, 0]) and np.allclose(out[1], [0.015, 0.015, 0.015]) and np.allclose(out[2], [0.03, 0.01, 0.01])
     big = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
     assert oracle.voxel_grid(big, 0.001)[1] == -1  # PCL: "Leaf size is too small", output = input
+
+
+def test_normals_restatement_on_analytic_surfaces():
+    """PCL's closed-form plane fit: exact normal and zero curvature on a plane, eigen-analysis on a sphere,
+    independent check against numpy's symmetric eigensolver in double."""
+    rng = np.random.default_rng(2)
+    n = 1500
+    uv = rng.random((n, 2)) * 2
+    nrm_true = np.array([1.0, 2.0, -2.0]) / 3.0
+    e1 = np.cross(nrm_true, [0, 0, 1.0]); e1 /= np.linalg.norm(e1)
+    e2 = np.cross(nrm_true, e1)
+    plane = (uv[:, :1] * e1 + uv[:, 1:] * e2 + 0.5 * nrm_true).astype(np.float32)
+    out = oracle.normals(plane, 20)
+    assert (np.abs(out[:, :3] @ nrm_true) > 1 - 1e-4).all()
+    assert (out[:, 3] < 1e-4).all()
+    assert ((out[:, :3] * -plane).sum(1) >= 0).all()  # towards the viewpoint (origin)
+    # noisy blob: compare with the double-precision eigen decomposition of the same neighbourhoods
+    pts = rng.normal(0, 0.2, (800, 3)).astype(np.float32)
+    k = 30
+    nbr, _ = oracle.knn_exhaustive(pts, pts, k)
+    out = oracle.normals(pts, k, neighbours=nbr)
+    for i in range(0, 800, 40):
+        c = np.cov(pts[nbr[i]].astype(np.float64).T, bias=True)
+        w, v = np.linalg.eigh(c)
+        assert abs(abs(out[i, :3] @ v[:, 0]) - 1) < 1e-3
+        assert abs(out[i, 3] - w[0] / w.sum()) < 1e-3
+    # fewer than three neighbours / non-finite point -> NaN
+    assert np.isnan(oracle.normals(pts[:2], 10)).all()
+    bad = pts[:50].copy(); bad[3] = np.inf
+    o = oracle.normals(bad, 10)
+    assert np.isnan(o[3]).all() and np.isfinite(np.delete(o, 3, 0)).all()
+
+
+def test_region_growing_restatement_small_cases():
+    # two parallel strips of 4 points: neighbours inside a strip only
+    nrm = np.zeros((8, 4), np.float32)
+    nrm[:4, 2] = 1.0           # strip A: +z
+    nrm[4:, 0] = 1.0           # strip B: +x
+    nrm[:, 3] = [0.3, 0.1, 0.2, 0.4, 0.05, 0.6, 0.7, 0.8]
+    nbr = np.array([[0, 1, 4], [1, 0, 2], [2, 1, 3], [3, 2, 7], [4, 5, 0], [5, 4, 6], [6, 5, 7], [7, 6, 3]], np.int32)
+    lab, ncl = oracle.region_growing(nrm, nbr, 0.1, 1.0, 1, 100)
+    # lowest curvature (point 4) seeds the first region -> strip B is cluster 0
+    assert ncl == 2 and (lab[4:] == 0).all() and (lab[:4] == 1).all()
+    # curvature threshold stops the walk: point 5 (0.6 > 0.5) joins but does not spread
+    lab, ncl = oracle.region_growing(nrm, nbr, 0.1, 0.5, 1, 100)
+    assert lab[4] == lab[5] and lab[6] != lab[4]
+    # size filter drops small regions and renumbers the kept ones in creation order
+    lab, ncl = oracle.region_growing(nrm, nbr, 0.1, 0.5, 3, 100)
+    assert ncl == 1 and (lab[:4] == 0).all() and (lab[4:] == -1).all()
+    # smoothness: 90 degrees apart never merges even when linked
+    lab, ncl = oracle.region_growing(nrm, nbr, np.pi / 2 - 0.01, 1.0, 1, 100)
+    assert ncl == 2
+    lab, ncl = oracle.region_growing(nrm, nbr, np.pi / 2 + 0.01, 1.0, 1, 100)
+    assert ncl == 1
