@@ -196,10 +196,12 @@ int pcc_voxel_grid(pcc_index *ctx, const void *pts, size_t n, size_t stride_byte
  *   setNumberOfNeighbours(k), setSmoothnessThreshold, setCurvatureThreshold, setMin/MaxClusterSize,
  *   setInputCloud / setInputNormals, extract (src/segmentation.cpp:259-271: 50, 1000000, k = 100,
  *   3/180*pi, 1.0).  The k-neighbour rows of every point are searched on the GPU in one batch
- *   (PCL: findPointNeighbours, one nearestKSearch per point); regions then grow in PCL's order --
- *   seeds by ascending curvature, breadth first through the rows while
- *   |n_current . n_neighbour| >= cos(smoothness); a neighbour continues the walk when its curvature
- *   is <= curvature_threshold.
+ *   (PCL: findPointNeighbours, one nearestKSearch per point).  The result is PCL's: seeds by
+ *   ascending curvature, breadth first through the rows while |n_current . n_neighbour| >=
+ *   cos(smoothness), a neighbour continues the walk when its curvature is <= curvature_threshold.
+ *   When every point passes that curvature test (the reference's setting) the regions are computed
+ *   on the GPU in an equivalent order-free form (lowest-ranked ancestor over the valid-edge graph);
+ *   otherwise PCL's sequential walk runs on the host over the GPU rows.
  * normals[n][4] as pcc_normals writes them (memory space `mem`); labels[n] (memory space `mem`):
  *   index of the kept cluster, in PCL's output order (creation order), or -1;
  *   *n_clusters (host) = clusters.size().  Equal curvatures are taken in index order (PCL:

@@ -502,27 +502,23 @@ int pcc_region_growing(pcc_index* ix, const float* normals, int mem, int k, floa
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
     const size_t n = ix->n_orig;
-    // findPointNeighbours: one batched self k-NN; only the indices travel to the host
+    // findPointNeighbours: one batched self k-NN over the packed references
     PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
     auto* keys = ix->out_packed.as<unsigned long long>();
     PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, keys));
-    PCC_TRY(ix->out_idx.reserve(n * (size_t)k * sizeof(int32_t)));
-    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, n * (size_t)k, ix->out_idx.as<int32_t>(), nullptr));
-    ev_mark(ix, EV_CALL1);
-    std::vector<int32_t> nbr(n * (size_t)k), hl(n);
-    PCC_HIP(hipMemcpyAsync(nbr.data(), ix->out_idx.p, nbr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
-    std::vector<float> hn;
-    const float* nh = normals;
-    if (mem == PCC_MEM_DEVICE) {
-        hn.resize(n * 4);
-        PCC_HIP(hipMemcpyAsync(hn.data(), normals, hn.size() * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-        nh = hn.data();
+    const float4* dn = reinterpret_cast<const float4*>(normals);
+    int32_t* dl = labels;
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(ix->out_d2.reserve(n * sizeof(float4)));
+        PCC_HIP(hipMemcpyAsync(ix->out_d2.p, normals, n * sizeof(float4), hipMemcpyHostToDevice, ix->stream));
+        dn = ix->out_d2.as<float4>();
+        PCC_TRY(ix->q_raw.reserve(n * sizeof(int32_t)));
+        dl = ix->q_raw.as<int32_t>();
     }
-    PCC_HIP(hipStreamSynchronize(ix->stream));
-    PCC_TRY(region_growing_host(n, nh, nbr.data(), k, smoothness, curvature_threshold, min_size, max_size, hl.data(), n_clusters));
-    if (mem == PCC_MEM_HOST) memcpy(labels, hl.data(), n * sizeof(int32_t));
-    else {
-        PCC_HIP(hipMemcpyAsync(labels, hl.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ix->stream));
+    PCC_TRY(grid_region_growing(ix, keys, dn, k, smoothness, curvature_threshold, min_size, max_size, dl, n_clusters));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, dl, labels, n, mem));
         PCC_HIP(hipStreamSynchronize(ix->stream));
     }
     return PCC_OK;

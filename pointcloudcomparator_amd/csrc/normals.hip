@@ -1,7 +1,6 @@
-// normals.hip -- surface normals + curvature from k-neighbourhoods, and region growing over the
-// same neighbourhoods: the default segmentation path of the reference
-// (src/segmentation.cpp:232-241 pcl::NormalEstimation setKSearch(50); :259-271 pcl::RegionGrowing
-// with 100 neighbours, 3 degrees, curvature threshold 1).
+// normals.hip -- surface normals + curvature from k-neighbourhoods: the first half of the reference's
+// default segmentation path (src/segmentation.cpp:232-241 pcl::NormalEstimation setKSearch(50); the
+// region growing that consumes them is region.hip).
 //
 // The neighbourhoods come from the wave-cooperative self k-NN (knn.hip).  k_normals is one lane
 // per point: it walks its row of keys in ascending (d2, index) order -- the order PCL's
@@ -131,60 +130,6 @@ int launch_normals(hipStream_t s, const unsigned long long* keys, const float4* 
     const size_t blocks = std::min<size_t>((n + 255) / 256, 8192);
     hipLaunchKernelGGL(k_normals, dim3((unsigned)blocks), dim3(256), 0, s, keys, refs, n, K, vp[0], vp[1], vp[2], out);
     PCC_HIP(hipGetLastError());
-    return PCC_OK;
-}
-
-// pcl::RegionGrowing::extract over precomputed neighbour rows (host side of pcc_region_growing).
-// Regions are grown in PCL's order: seeds by ascending curvature (ties: lower index), each region
-// a breadth-first walk of the neighbour rows; a neighbour joins when |n_cur . n_nbr| >= cos(theta)
-// and continues the walk when its curvature is not above the threshold.
-int region_growing_host(size_t n, const float* normals4, const int32_t* nbr, int K, float smoothness,
-                        float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels,
-                        int32_t* n_clusters) {
-    std::vector<int32_t> seg(n, -1), order(n), queue(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
-    // NaN curvatures (points without a normal) go last; PCL's std::sort leaves them unspecified
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        const float ca = normals4[(size_t)a * 4 + 3], cb = normals4[(size_t)b * 4 + 3];
-        const bool na = ca != ca, nb = cb != cb;
-        if (na != nb) return nb;
-        if (!na && ca != cb) return ca < cb;
-        return a < b;
-    });
-    std::vector<uint32_t> seg_size;
-    const float cosine_threshold = cosf(smoothness);
-    size_t segmented = 0, seed_pos = 0;
-    while (segmented < n) {
-        while (seg[order[seed_pos]] != -1) ++seed_pos;
-        const int32_t id = (int32_t)seg_size.size();
-        size_t qh = 0, qt = 0;
-        queue[qt++] = order[seed_pos];
-        seg[order[seed_pos]] = id;
-        uint32_t cnt = 1;
-        while (qh < qt) {
-            const int32_t cur = queue[qh++];
-            const float* nc = normals4 + (size_t)cur * 4;
-            const int32_t* row = nbr + (size_t)cur * K;
-            for (int j = 0; j < K; ++j) {
-                const int32_t t = row[j];
-                if (t < 0) break;
-                if (seg[t] != -1) continue;
-                const float* nn = normals4 + (size_t)t * 4;
-                const float dot = fabsf(nn[0] * nc[0] + nn[1] * nc[1] + nn[2] * nc[2]);
-                if (dot < cosine_threshold) continue;
-                seg[t] = id;
-                ++cnt;
-                if (!(nn[3] > curvature_threshold)) queue[qt++] = t;
-            }
-        }
-        seg_size.push_back(cnt);
-        segmented += cnt;
-    }
-    std::vector<int32_t> remap(seg_size.size());
-    int32_t kept = 0;
-    for (size_t s = 0; s < seg_size.size(); ++s) remap[s] = (seg_size[s] >= min_size && seg_size[s] <= max_size) ? kept++ : -1;
-    for (size_t i = 0; i < n; ++i) labels[i] = remap[seg[i]];
-    *n_clusters = kept;
     return PCC_OK;
 }
 

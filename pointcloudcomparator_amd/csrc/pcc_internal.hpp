@@ -177,8 +177,8 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
                 const int64_t* offsets, unsigned long long* keys, int sorted);
 int launch_normals(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
                    const float vp[3], float4* out);
-int region_growing_host(size_t n, const float* normals4, const int32_t* nbr, int K, float smoothness,
-                        float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels,
+int grid_region_growing(pcc_index* ix, const unsigned long long* keys, const float4* normals, int K, float smoothness,
+                        float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels_dev,
                         int32_t* n_clusters);
 int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, int32_t* idx_dev);
 // ---- cluster.hip ------------------------------------------------------------------------

@@ -129,3 +129,29 @@ def test_region_growing_device_normals_and_size_filter():
     np.testing.assert_array_equal(lab_d.cpu().numpy(), lab_h)
     cnt = np.bincount(lab_h[lab_h >= 0], minlength=max(n_h, 1))
     assert n_h == 0 or ((cnt >= 100) & (cnt <= 1400)).all()
+
+
+@pytest.mark.parametrize("seed,k,theta_deg,nan_frac", [(1, 8, 25.0, 0.0), (2, 16, 35.0, 0.01), (3, 5, 50.0, 0.0),
+                                                        (4, 40, 15.0, 0.002), (5, 3, 80.0, 0.05)])
+def test_region_growing_order_free_form_equals_pcl_walk(seed, k, theta_deg, nan_frac):
+    """Adversarial graphs for the GPU formulation (label = lowest-ranked ancestor): random normals make
+    the smooth-edge graph sparse, strongly one-directional and full of small components, NaN normals
+    accept every edge, duplicated curvatures exercise the rank tie-break.  The result must equal the
+    sequential walk of the oracle, label for label."""
+    rng = np.random.default_rng(seed)
+    n = 20000
+    pts = rng.random((n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    nrm = np.zeros((n, 4), np.float32)
+    nrm[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    nrm[:, 3] = np.round(rng.random(n) * 0.3, 3)  # many equal curvatures
+    bad = rng.random(n) < nan_frac
+    nrm[bad] = np.nan
+    ix = capi.Index(pts)
+    labels, ncl = ix.region_growing(nrm, k=k, smoothness=theta_deg / 180.0 * np.pi, curvature_threshold=1.0,
+                                    min_size=1, max_size=n)
+    nbr, _ = ix.knn(pts, k)
+    want, want_n = oracle.region_growing(nrm, nbr, theta_deg / 180.0 * np.pi, 1.0, 1, n)
+    assert ncl == want_n
+    np.testing.assert_array_equal(labels, want)
+    assert ncl > 10
