@@ -83,14 +83,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # one rank per GPU.  Rehearsals on a box with fewer GPUs than ranks share devices; RCCL refuses two
+    # ranks on one device, so that case (never the driver's) falls back to gloo and says so.
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev
+    backend = os.environ.get("PCC_BENCH_BACKEND", "nccl" if world <= ndev else "gloo")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+            if rank == 0:
+                print(f"[bench] note: {world} ranks on {ndev} GPU(s): backend {backend}, devices shared", file=sys.stderr)
     else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     n_gpus = world
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -158,6 +168,7 @@ def main():
     ix.enable_timing(0)
     stats = ix.stats()
     ms_per_step = dt / K * 1e3
+    bcast_name = "RCCL" if backend == "nccl" else backend
     value = N * n_gpus / (dt / K)
 
     # query-only rate (index kept, as inside ICP where the target tree is built once)
@@ -183,7 +194,7 @@ def main():
             "references": M,
             "queries_per_gpu": N,
             "point_stride_bytes": floats * 4,
-            "parallelism": f"query-sharded x{n_gpus}, reference cloud replicated (RCCL broadcast {bcast_ms:.2f} ms, outside the timed region)",
+            "parallelism": f"query-sharded x{n_gpus}, reference cloud replicated ({bcast_name} broadcast {bcast_ms:.2f} ms, outside the timed region)",
         },
         "query_only_queries_per_sec": query_only,
         "build_ms": tm[3],
