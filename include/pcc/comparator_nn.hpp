@@ -294,4 +294,82 @@ private:
     typename PointCloud<NormalT>::ConstPtr normals_;
 };
 
+// ---- pcl::SACSegmentation, plane + RANSAC (src/segmentation.cpp:79-99) --------------------------------
+enum SacModel { SACMODEL_PLANE = 0 };
+enum SacMethod { SAC_RANSAC = 0 };
+
+template <class PointT>
+class SACSegmentation {
+public:
+    void setOptimizeCoefficients(bool b) { optimize_ = b; }
+    void setModelType(int m) { model_ = m; }
+    void setMethodType(int m) { method_ = m; }
+    void setMaxIterations(int n) { max_iterations_ = n; }
+    void setDistanceThreshold(double t) { threshold_ = t; }
+    void setProbability(double p) { probability_ = p; }
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    // inliers.indices empty + coefficients.values empty: no model (as PCL reports it)
+    void segment(PointIndices& inliers, ModelCoefficients& coefficients) {
+        inliers.indices.clear();
+        coefficients.values.clear();
+        if (!input_ || input_->empty()) return;
+        if (model_ != SACMODEL_PLANE || method_ != SAC_RANSAC) throw Error(PCC_ERR_UNSUPPORTED, "only SACMODEL_PLANE + SAC_RANSAC");
+        if (!ctx_) {
+            // any index handle supplies device, stream and scratch; a one-point index is the cheapest
+            const float one[3] = {0.f, 0.f, 0.f};
+            check(pcc_index_create(one, 1, 12, 3, PCC_MEM_HOST, 0, PCC_ENGINE_BRUTE, &ctx_));
+        }
+        std::vector<int32_t> idx(input_->size());
+        size_t m = 0;
+        float c[4];
+        check(pcc_sac_plane(ctx_, input_->points.data(), input_->size(), sizeof(PointT), PCC_MEM_HOST, max_iterations_,
+                            threshold_, probability_, optimize_ ? 1 : 0, idx.data(), &m, c, nullptr));
+        if (m == 0) return;
+        inliers.indices.assign(idx.begin(), idx.begin() + m);
+        coefficients.values.assign(c, c + 4);
+    }
+    SACSegmentation() = default;
+    SACSegmentation(const SACSegmentation&) = delete;
+    SACSegmentation& operator=(const SACSegmentation&) = delete;
+    ~SACSegmentation() { if (ctx_) pcc_index_destroy(ctx_); }
+
+private:
+    bool optimize_ = false;
+    int model_ = SACMODEL_PLANE, method_ = SAC_RANSAC, max_iterations_ = 50;
+    double threshold_ = 0.0, probability_ = 0.99;
+    typename PointCloud<PointT>::ConstPtr input_;
+    pcc_index* ctx_ = nullptr;
+};
+
+// ---- pcl::ExtractIndices (src/segmentation.cpp:103-116): index bookkeeping, host only ---------------------
+template <class PointT>
+class ExtractIndices {
+public:
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+    void setIndices(const std::shared_ptr<const PointIndices>& i) { indices_ = i; }
+    void setNegative(bool n) { negative_ = n; }
+    void filter(PointCloud<PointT>& out) {
+        std::vector<PointT> pts;
+        if (input_) {
+            const size_t n = input_->size();
+            if (!negative_) {
+                if (indices_) for (int i : indices_->indices) pts.push_back(input_->points[i]);
+            } else {
+                std::vector<char> drop(n, 0);
+                if (indices_) for (int i : indices_->indices) drop[i] = 1;
+                for (size_t i = 0; i < n; ++i) if (!drop[i]) pts.push_back(input_->points[i]);
+            }
+        }
+        out.points.swap(pts);
+        out.width = (std::uint32_t)out.points.size();
+        out.height = 1;
+        out.is_dense = true;
+    }
+
+private:
+    typename PointCloud<PointT>::ConstPtr input_;
+    std::shared_ptr<const PointIndices> indices_;
+    bool negative_ = false;
+};
+
 }  // namespace pcc

@@ -40,6 +40,9 @@ static_assert(sizeof(PointXYZ) == 16 && sizeof(PointXYZRGB) == 32 && sizeof(Hist
 struct PointIndices {
     std::vector<int> indices;
 };
+struct ModelCoefficients {
+    std::vector<float> values;
+};
 struct Correspondence {
     int index_query = 0;
     int index_match = -1;

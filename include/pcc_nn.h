@@ -184,6 +184,23 @@ int pcc_match_knn(pcc_index *index_des1, const void *des2, size_t n2,
 int pcc_voxel_grid(pcc_index *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
                    float leaf, int has_rgb, void *out, size_t out_stride, size_t *out_n);
 
+/* ---- RANSAC plane segmentation ---------------------------------------------------------------------
+ * replaces: pcl::SACSegmentation<PointXYZRGB> with setModelType(SACMODEL_PLANE), setMethodType(SAC_RANSAC),
+ *   setOptimizeCoefficients(true), setMaxIterations(100), setDistanceThreshold(0.02), segment(inliers,
+ *   coefficients) -- the plane-removal loop in front of the Euclidean clustering
+ *   (src/segmentation.cpp:79-99; the ExtractIndices steps :103-116 are index bookkeeping on the host).
+ *   PCL's RANSAC is deterministic (fixed-seed mt19937, see sac.hip): the same 3-point samples are drawn,
+ *   every candidate plane's support |a x + b y + c z + d| < threshold is counted on the GPU (32 candidates
+ *   per pass over the cloud), PCL's best-model / adaptive iteration-count logic runs on the counts, and the
+ *   inliers are selected on the GPU in ascending index order.  optimize != 0 adds PCL's least-squares
+ *   refit over the inliers and a second selection with the refined plane.
+ * inliers[] (memory space `mem`, capacity n); *n_inliers, coefficients[4] (a, b, c, d) and *iterations
+ *   (RANSAC iterations PCL would have run; may be NULL) are host values.  n_inliers == 0: no model
+ *   (PCL: "Could not estimate a planar model").  `ctx` is any index handle. */
+int pcc_sac_plane(pcc_index *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
+                  int max_iterations, double distance_threshold, double probability, int optimize,
+                  int32_t *inliers, size_t *n_inliers, float coefficients[4], int *iterations);
+
 /* ---- normals + region growing (default segmentation path) --------------------------------------
  * pcc_normals replaces: pcl::NormalEstimation<PointXYZRGB, pcl::Normal> with setSearchMethod(tree),
  *   setKSearch(k), compute (src/segmentation.cpp:232-241, k = 50; viewpoint left at (0,0,0)).

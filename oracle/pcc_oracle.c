@@ -567,7 +567,9 @@ static void normal_of(const void *pts, size_t stride, const int32_t *nbr, int cn
         a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
         a[6] += q[0]; a[7] += q[1]; a[8] += q[2];
     }
-    for (int i = 0; i < 9; ++i) a[i] /= (float)cnt;
+    /* accu /= point_count: Eigen 3.2's operator/=(scalar) multiplies by Scalar(1)/other for floats */
+    const float inv_cnt = 1.0f / (float)cnt;
+    for (int i = 0; i < 9; ++i) a[i] *= inv_cnt;
     float cov[9];
     cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
     cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
@@ -603,6 +605,148 @@ void orc_normals(const void *pts, size_t n, size_t stride, int k, const float vp
     }
     free(ni); free(nd);
     orc_kdtree_free(t);
+}
+
+/* ======== SACSegmentation, SACMODEL_PLANE + SAC_RANSAC (src/segmentation.cpp:79-117) ========
+ * [recalled from PCL 1.7 sample_consensus/{ransac,sac_model,sac_model_plane}.hpp, segmentation/sac_segmentation.hpp,
+ *  Boost.Random, Eigen 3.2 with SSE3+ (the PCL 1.7 Ubuntu packages are built with -msse4.2)]
+ * 4-float Eigen reductions (dot, squaredNorm) are one packet product + predux = (p0 + p1) + (p2 + p3). */
+
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+static void mt_seed(mt19937_t *g, uint32_t seed) {
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t *g) {
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+void orc_mt19937_raw(uint32_t seed, uint32_t *out, size_t n) { /* for the known-answer test of the generator */
+    mt19937_t g; mt_seed(&g, seed);
+    for (size_t i = 0; i < n; ++i) out[i] = mt_next(&g);
+}
+/* boost::variate_generator<mt19937&, uniform_int<>(0, INT_MAX)>: bucket size 2 -> eng() / 2, never rejected */
+static int sac_rnd(mt19937_t *g) { return (int)(mt_next(g) / 2u); }
+
+static float dot4(const float a[4], const float b[4]) {
+    return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+}
+/* SampleConsensusModelPlane::isSampleGood / the collinearity check of computeModelCoefficients:
+ * Array4f (p1-p0)/(p2-p0) on the first three lanes */
+static int plane_sample_degenerate(const float *p0, const float *p1, const float *p2) {
+    float d0 = (p1[0] - p0[0]) / (p2[0] - p0[0]);
+    float d1 = (p1[1] - p0[1]) / (p2[1] - p0[1]);
+    float d2 = (p1[2] - p0[2]) / (p2[2] - p0[2]);
+    return (d0 == d1) && (d2 == d1);
+}
+static int plane_from_sample(const float *p0, const float *p1, const float *p2, float c[4]) {
+    float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    float b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    if (plane_sample_degenerate(p0, p1, p2)) return 0;
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+    c[3] = 0.0f;
+    /* VectorXf::normalize(): *this /= norm(), i.e. *= 1/norm in Eigen 3.2 */
+    float nrm = sqrtf(dot4(c, c));
+    float inv = 1.0f / nrm;
+    c[0] *= inv; c[1] *= inv; c[2] *= inv; c[3] *= inv;
+    float p[4] = {p0[0], p0[1], p0[2], 1.0f};
+    c[3] = -1.0f * dot4(c, p);
+    return 1;
+}
+static int plane_inlier(const float c[4], const float *q, double threshold) {
+    float p[4] = {q[0], q[1], q[2], 1.0f};
+    return fabs((double)dot4(c, p)) < threshold;
+}
+
+long orc_sac_plane(const void *pts, size_t n, size_t stride, int max_iterations, double threshold, double probability,
+                   int optimize, int32_t *inliers, float coeff[4], int *iterations_out) {
+    if (iterations_out) *iterations_out = 0;
+    coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.0f;
+    if (n < 3) return 0; /* getSamples: "Can not select 3 unique points out of N" -> no model */
+    mt19937_t g; mt_seed(&g, 12345u);
+    int32_t *shuffled = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (size_t i = 0; i < n; ++i) shuffled[i] = (int32_t)i;
+    int iterations = 0, best_count = -INT32_MAX, have_model = 0;
+    double k = 1.0;
+    const double log_probability = log(1.0 - probability);
+    const double one_over_indices = 1.0 / (double)n;
+    unsigned skipped = 0;
+    const unsigned max_skip = (unsigned)max_iterations * 10u;
+    float best[4] = {0, 0, 0, 0};
+    while (iterations < k && skipped < max_skip) {
+        /* getSamples: up to 1000 draws until isSampleGood */
+        int32_t smp[3]; int got = 0;
+        for (int it = 0; it < 1000 && !got; ++it) {
+            for (unsigned i = 0; i < 3; ++i) {
+                size_t j = i + (size_t)sac_rnd(&g) % (n - i);
+                int32_t t = shuffled[i]; shuffled[i] = shuffled[j]; shuffled[j] = t;
+            }
+            smp[0] = shuffled[0]; smp[1] = shuffled[1]; smp[2] = shuffled[2];
+            got = !plane_sample_degenerate(pt_at(pts, stride, smp[0]), pt_at(pts, stride, smp[1]), pt_at(pts, stride, smp[2]));
+        }
+        if (!got) break; /* "No samples could be selected!" */
+        float c[4];
+        if (!plane_from_sample(pt_at(pts, stride, smp[0]), pt_at(pts, stride, smp[1]), pt_at(pts, stride, smp[2]), c)) {
+            ++skipped;
+            continue;
+        }
+        int cnt = 0;
+        for (size_t i = 0; i < n; ++i) cnt += plane_inlier(c, pt_at(pts, stride, i), threshold);
+        if (cnt > best_count) {
+            best_count = cnt;
+            have_model = 1;
+            memcpy(best, c, sizeof(best));
+            double w = (double)best_count * one_over_indices;
+            double p_no_outliers = 1.0 - pow(w, 3.0);
+            if (p_no_outliers < DBL_EPSILON) p_no_outliers = DBL_EPSILON;
+            if (p_no_outliers > 1.0 - DBL_EPSILON) p_no_outliers = 1.0 - DBL_EPSILON;
+            k = log_probability / log(p_no_outliers);
+        }
+        ++iterations;
+        if (iterations > max_iterations) break;
+    }
+    free(shuffled);
+    if (iterations_out) *iterations_out = iterations;
+    if (!have_model) return 0;
+    long m = 0;
+    for (size_t i = 0; i < n; ++i) if (plane_inlier(best, pt_at(pts, stride, i), threshold)) inliers[m++] = (int32_t)i;
+    memcpy(coeff, best, sizeof(best));
+    if (optimize && m >= 4) {
+        /* optimizeModelCoefficients: least-squares plane through the inliers (single-pass float sums, in order) */
+        float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (long j = 0; j < m; ++j) {
+            const float *q = pt_at(pts, stride, (size_t)inliers[j]);
+            a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2];
+            a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
+            a[6] += q[0]; a[7] += q[1]; a[8] += q[2];
+        }
+        const float inv_cnt = 1.0f / (float)m;
+        for (int i = 0; i < 9; ++i) a[i] *= inv_cnt;
+        float cov[9];
+        cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+        cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        float nrm[3], curv;
+        plane_params(cov, nrm, &curv);
+        float o[4] = {nrm[0], nrm[1], nrm[2], 0.0f};
+        float cen[4] = {a[6], a[7], a[8], 0.0f};
+        o[3] = -1.0f * dot4(o, cen);
+        memcpy(coeff, o, sizeof(o));
+        m = 0; /* refine inliers: selectWithinDistance with the refined coefficients */
+        for (size_t i = 0; i < n; ++i) if (plane_inlier(o, pt_at(pts, stride, i), threshold)) inliers[m++] = (int32_t)i;
+    }
+    return m;
 }
 
 /* ======== RegionGrowing (src/segmentation.cpp:259-271) [PCL 1.7, recalled] ========= */

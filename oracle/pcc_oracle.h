@@ -95,6 +95,16 @@ void orc_normals(const void *pts, size_t n, size_t stride, int k, const float vp
 void orc_normals_from_neighbours(const void *pts, size_t n, size_t stride, const int32_t *nbr, int k,
                                  const float vp[3], float *out);
 
+/* pcl::SACSegmentation<PointT>::segment with SACMODEL_PLANE, SAC_RANSAC, probability 0.99 default
+ * (src/segmentation.cpp:79-99: optimize on, 100 iterations, threshold 0.02).  RANSAC with PCL's fixed
+ * seed (mt19937(12345), boost uniform_int<>(0, INT_MAX) = eng()/2, partial Fisher-Yates over the persistent
+ * shuffled index array), adaptive iteration bound k = log(1-p)/log(1-w^3), inliers |c . (x,y,z,1)| <
+ * threshold in ascending index order; with optimize != 0 the least-squares refit (float mean/covariance,
+ * pcl::eigen33) and a second inlier selection.  Returns the inlier count (0: no model). */
+long orc_sac_plane(const void *pts, size_t n, size_t stride, int max_iterations, double threshold, double probability,
+                   int optimize, int32_t *inliers, float coeff[4], int *iterations_out);
+void orc_mt19937_raw(uint32_t seed, uint32_t *out, size_t n);
+
 /* pcl::RegionGrowing<PointT, pcl::Normal>::extract (src/segmentation.cpp:259-271: min 50, max 1e6,
  * 100 neighbours, smoothness 3 deg, curvature threshold 1) [recalled from PCL 1.7
  * segmentation/impl/region_growing.hpp]: points sorted by curvature, regions grown through the

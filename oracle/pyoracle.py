@@ -53,6 +53,10 @@ def lib() -> C.CDLL:
         L.orc_normals_from_neighbours.argtypes = [vp, sz, sz, vp, i32, vp, vp]
         L.orc_normals_from_neighbours.restype = None
         L.orc_region_growing.argtypes = [sz, vp, vp, i32, C.c_float, C.c_float, i32, i32, vp]
+        L.orc_sac_plane.argtypes = [vp, sz, sz, i32, C.c_double, C.c_double, i32, vp, vp, vp]
+        L.orc_sac_plane.restype = C.c_long
+        L.orc_mt19937_raw.argtypes = [C.c_uint32, vp, sz]
+        L.orc_mt19937_raw.restype = None
         L.orc_voxel_grid.argtypes = [vp, sz, sz, C.c_float, i32, vp, sz]
         L.orc_voxel_grid.restype = C.c_long
         L.orc_first_within.argtypes = [vp, sz, sz, vp, sz, sz, C.c_double, vp]
@@ -206,6 +210,25 @@ def region_growing(normals4, neighbours, smoothness, curvature_threshold, min_si
     ncl = lib().orc_region_growing(len(nm), nm.ctypes.data, nb.ctypes.data, nb.shape[1], np.float32(smoothness),
                                    np.float32(curvature_threshold), min_size, max_size, labels.ctypes.data)
     return labels, ncl
+
+
+def sac_plane(pts, max_iterations=100, threshold=0.02, probability=0.99, optimize=True):
+    """(inlier indices, coefficients[4], iterations) of SACSegmentation(PLANE, RANSAC).segment"""
+    a, ap, n, s1 = _f32(pts)
+    if n == 0:
+        return np.empty(0, np.int32), np.zeros(4, np.float32), 0
+    inl = np.empty(max(n, 1), np.int32)
+    coeff = np.zeros(4, np.float32)
+    its = C.c_int(0)
+    m = lib().orc_sac_plane(ap, n, s1, max_iterations, threshold, probability, int(optimize), inl.ctypes.data,
+                            coeff.ctypes.data, C.byref(its))
+    return inl[:m].copy(), coeff, its.value
+
+
+def mt19937_raw(seed, n):
+    out = np.empty(n, np.uint32)
+    lib().orc_mt19937_raw(seed, out.ctypes.data, n)
+    return out
 
 
 def voxel_grid(pts, leaf, has_rgb=False):

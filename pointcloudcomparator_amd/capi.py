@@ -28,7 +28,7 @@ SYMBOLS = [
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
-    "pcc_normals", "pcc_region_growing",
+    "pcc_normals", "pcc_region_growing", "pcc_sac_plane",
 ]
 
 
@@ -77,6 +77,7 @@ def _load() -> C.CDLL:
     lib.pcc_knn.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp]
     lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_first_within.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
+    lib.pcc_sac_plane.argtypes = [vp, vp, sz, sz, i32, i32, C.c_double, C.c_double, i32, vp, C.POINTER(sz), vp, vp]
     lib.pcc_normals.argtypes = [vp, i32, vp, i32, vp]
     lib.pcc_region_growing.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
     lib.pcc_voxel_grid.argtypes = [vp, vp, sz, sz, i32, C.c_float, i32, vp, sz, C.POINTER(sz)]
@@ -124,7 +125,7 @@ def _points(x):
         return x.data_ptr(), x.shape[0], x.stride(0) * 4 if x.shape[0] > 1 else x.shape[1] * 4, mem
     a = x
     assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] >= 3
-    assert a.strides[1] == 4
+    assert a.shape[0] == 0 or a.strides[1] == 4
     stride = a.strides[0] if a.shape[0] > 1 else a.shape[1] * 4
     return a.ctypes.data, a.shape[0], stride, MEM_HOST
 
@@ -297,6 +298,18 @@ class Index:
         _check(LIB.pcc_sor(self._h, mean_k, float(stddev_mult), MEM_HOST, md.ctypes.data, inl.ctypes.data,
                            C.byref(thr), C.byref(kept)))
         return md, inl, thr.value, kept.value
+
+    def sac_plane(self, points, max_iterations: int = 100, threshold: float = 0.02, probability: float = 0.99,
+                  optimize: bool = True):
+        """pcl::SACSegmentation(PLANE, RANSAC).segment on `points`: (inlier indices, coefficients[4], iterations)."""
+        ptr, n, stride, mem = _points(points)
+        inl, pi = _out(points, (max(n, 1),), np.int32)
+        cnt = C.c_size_t(0)
+        its = C.c_int(0)
+        coeff = np.zeros(4, dtype=np.float32)
+        _check(LIB.pcc_sac_plane(self._h, ptr, n, stride, mem, max_iterations, float(threshold), float(probability),
+                                 int(optimize), pi, C.byref(cnt), coeff.ctypes.data, C.byref(its)))
+        return inl[:cnt.value], coeff, its.value
 
     def normals(self, k: int = 50, viewpoint=None, device=None):
         """pcl::NormalEstimation over the index's own points: (n, 4) = nx, ny, nz, curvature.

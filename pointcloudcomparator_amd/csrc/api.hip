@@ -466,6 +466,51 @@ int pcc_voxel_grid(pcc_index* ix, const void* pts, size_t n, size_t stride, int 
     return voxel_grid(ix, pts, n, stride, mem, leaf, has_rgb, out, out_stride, out_n);
 }
 
+int pcc_sac_plane(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem, int max_iterations,
+                  double threshold, double probability, int optimize, int32_t* inliers, size_t* n_inliers,
+                  float coeff[4], int* iterations) {
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(pts, n, stride, mem));
+    if (!n_inliers || !coeff || (n && !inliers)) { set_error("null output"); return PCC_ERR_INVALID; }
+    if (max_iterations < 0 || !(threshold >= 0) || !(probability > 0 && probability < 1)) {
+        set_error("bad RANSAC parameters");
+        return PCC_ERR_INVALID;
+    }
+    *n_inliers = 0;
+    coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.f;
+    if (iterations) *iterations = 0;
+    if (n == 0) return PCC_OK;
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    PCC_TRY(stage_queries(ix, pts, n, stride, mem));
+    const float4* dp = ix->q_packed.as<float4>();
+    // the sampling and the refit read single points on the host: the caller's array, or a copy of the staged cloud
+    std::vector<float4> hp;
+    const char* host_base = static_cast<const char*>(pts);
+    size_t host_stride = stride;
+    if (mem == PCC_MEM_DEVICE) {
+        hp.resize(n);
+        PCC_HIP(hipMemcpyAsync(hp.data(), dp, n * sizeof(float4), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        const float qnan = std::nanf("");
+        for (size_t i = 0; i < n; ++i)  // the staged copy zeroes non-finite points; PCL would see them as they are
+            if (__builtin_bit_cast(int, hp[i].w) < 0) hp[i].x = hp[i].y = hp[i].z = qnan;
+        host_base = reinterpret_cast<const char*>(hp.data());
+        host_stride = sizeof(float4);
+    }
+    int32_t* di = inliers;
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(n * sizeof(int32_t))); di = ix->out_idx.as<int32_t>(); }
+    size_t m = 0;
+    PCC_TRY(sac_plane(ix, dp, n, host_base, host_stride, max_iterations, threshold, probability, optimize, di, &m, coeff, iterations));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST && m) {
+        PCC_TRY(deliver(ix, di, inliers, m, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    *n_inliers = m;
+    return PCC_OK;
+}
+
 int pcc_normals(pcc_index* ix, int k, const float viewpoint[3], int mem, float* out) {
     PCC_ENTER(ix);
     if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }

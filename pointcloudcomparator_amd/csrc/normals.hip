@@ -81,8 +81,9 @@ k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict_
             a6 += p.x; a7 += p.y; a8 += p.z;
         }
         if (cnt < 3) { out[i] = make_float4(qnan, qnan, qnan, qnan); continue; }
-        const float fc = (float)cnt;
-        a0 /= fc; a1 /= fc; a2 /= fc; a3 /= fc; a4 /= fc; a5 /= fc; a6 /= fc; a7 /= fc; a8 /= fc;
+        // accu /= point_count: Eigen 3.2's operator/=(scalar) multiplies by Scalar(1)/other
+        const float fc = 1.0f / (float)cnt;
+        a0 *= fc; a1 *= fc; a2 *= fc; a3 *= fc; a4 *= fc; a5 *= fc; a6 *= fc; a7 *= fc; a8 *= fc;
         float cov[9];
         cov[0] = a0 - a6 * a6; cov[1] = a1 - a6 * a7; cov[2] = a2 - a6 * a8;
         cov[4] = a3 - a7 * a7; cov[5] = a4 - a7 * a8; cov[8] = a5 - a8 * a8;

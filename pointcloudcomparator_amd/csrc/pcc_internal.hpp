@@ -175,6 +175,9 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
 // counts[i] = #refs with d2 < r2; with fill != 0 also writes keys at offsets[i]..
 int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
                 const int64_t* offsets, unsigned long long* keys, int sorted);
+int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n, const char* host_base, size_t host_stride,
+              int max_iterations, double threshold, double probability, int optimize, int32_t* inliers_dev,
+              size_t* n_inliers, float coeff[4], int* iterations_out);
 int launch_normals(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
                    const float vp[3], float4* out);
 int grid_region_growing(pcc_index* ix, const unsigned long long* keys, const float4* normals, int K, float smoothness,

@@ -1,0 +1,329 @@
+// sac.hip -- RANSAC plane segmentation: pcl::SACSegmentation with SACMODEL_PLANE + SAC_RANSAC, the plane
+// removal loop in front of the Euclidean clustering (reference src/segmentation.cpp:79-117:
+// optimize on, 100 iterations, distance threshold 0.02).
+//
+// PCL's RANSAC draws one 3-point sample per iteration from a fixed-seed generator, counts the points
+// within the threshold of its plane (one pass over the cloud per iteration -- the cost), keeps the best
+// and shortens the iteration bound k = log(1 - p) / log(1 - w^3) as the best inlier ratio w grows.
+// The sample sequence does not depend on the counts, only the stopping point does.  So:
+//   host   : replays PCL's sampling exactly (mt19937(12345), eng()/2, partial Fisher-Yates over the
+//            persistent shuffled index array, degenerate-sample retries) and forms the candidate planes
+//   device : k_sac_count evaluates a batch of 32 candidate planes in ONE pass over the cloud
+//            (per-lane counters, wave reduction, one atomic per wave and plane)
+//   host   : walks the counts with PCL's best/k logic; further batches only if k has not been reached
+//   device : inlier flags -> exclusive scan -> ascending index list (PCL's selectWithinDistance order)
+//   host   : optimizeModelCoefficients -- PCL's single-pass float moment sums over the inliers IN ORDER
+//            (a serial float chain, kept serial so the refit equals PCL's), pcl::eigen33, and a second
+//            device selection with the refined plane.
+// 4-float Eigen reductions are evaluated as (p0 + p1) + (p2 + p3) (packet product + hadd predux).
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pcc_internal.hpp"
+
+namespace pcc {
+
+namespace {
+
+constexpr int SAC_BATCH = 32;
+
+__device__ __forceinline__ bool plane_inlier_dev(const float4 c, const float4 p, double threshold) {
+    const float d = (c.x * p.x + c.y * p.y) + (c.z * p.z + c.w * 1.0f);
+    return (__float_as_int(p.w) >= 0) && (fabs((double)d) < threshold);
+}
+
+__global__ void __launch_bounds__(256)
+k_sac_count(const float4* __restrict__ pts, unsigned int n, const float4* __restrict__ models, double threshold,
+            unsigned int* __restrict__ counts) {
+    __shared__ float4 sm[SAC_BATCH];
+    if (threadIdx.x < SAC_BATCH) sm[threadIdx.x] = models[threadIdx.x];
+    __syncthreads();
+    unsigned int cnt[SAC_BATCH];
+#pragma unroll
+    for (int m = 0; m < SAC_BATCH; ++m) cnt[m] = 0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+#pragma unroll
+        for (int m = 0; m < SAC_BATCH; ++m) cnt[m] += plane_inlier_dev(sm[m], p, threshold) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int m = 0; m < SAC_BATCH; ++m) {
+        unsigned int v = cnt[m];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counts[m], v);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_sac_flag(const float4* __restrict__ pts, unsigned int n, float4 model, double threshold, unsigned int* __restrict__ flag) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x)
+        flag[i] = (i < n && plane_inlier_dev(model, pts[i], threshold)) ? 1u : 0u;  // flag[n] = 0: scan[n] = total
+}
+
+__global__ void __launch_bounds__(256)
+k_sac_scatter(const float4* __restrict__ pts, unsigned int n, float4 model, double threshold,
+              const unsigned int* __restrict__ pos, int32_t* __restrict__ out) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (plane_inlier_dev(model, pts[i], threshold)) out[pos[i]] = (int32_t)i;
+}
+
+// ---- host side: PCL's generator, sampling and plane arithmetic ------------------------------------------
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    explicit Mt19937(uint32_t seed) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    // boost::uniform_int<>(0, INT_MAX) over a 32-bit engine: bucket size 2, no rejection
+    int rnd() { return (int)(next() / 2u); }
+};
+
+inline float dot4(const float a[4], const float b[4]) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
+
+inline bool sample_degenerate(const float* p0, const float* p1, const float* p2) {
+    const float d0 = (p1[0] - p0[0]) / (p2[0] - p0[0]);
+    const float d1 = (p1[1] - p0[1]) / (p2[1] - p0[1]);
+    const float d2 = (p1[2] - p0[2]) / (p2[2] - p0[2]);
+    return (d0 == d1) && (d2 == d1);
+}
+
+inline bool plane_from_sample(const float* p0, const float* p1, const float* p2, float c[4]) {
+    const float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    const float b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    if (sample_degenerate(p0, p1, p2)) return false;
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+    c[3] = 0.f;
+    const float inv = 1.0f / std::sqrt(dot4(c, c));  // normalize(): Eigen 3.2 multiplies by the reciprocal
+    c[0] *= inv; c[1] *= inv; c[2] *= inv; c[3] *= inv;
+    const float p[4] = {p0[0], p0[1], p0[2], 1.0f};
+    c[3] = -1.0f * dot4(c, p);
+    return true;
+}
+
+// pcl::eigen33 (smallest eigenpair) on the host, as k_normals does it on the device
+inline void roots2_h(float b, float c, float r[3]) {
+    r[0] = 0.f;
+    float d = b * b - 4.f * c;
+    if (d < 0.f) d = 0.f;
+    const float sd = std::sqrt(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+inline void roots3_h(const float m[9], float r[3]) {
+    const float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    const float c2 = m[0] + m[4] + m[8];
+    if (std::fabs(c0) < FLT_EPSILON) { roots2_h(c2, c1, r); return; }
+    const float s_inv3 = (float)(1.0 / 3.0), s_sqrt3 = std::sqrt(3.0f);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.f) q = 0.f;
+    const float rho = std::sqrt(-a_over_3);
+    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;  // host libm, float versions, as PCL calls them
+    const float ct = cosf(theta), st = sinf(theta);
+    r[0] = c2_over_3 + 2.f * rho * ct;
+    r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    float t;
+    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    if (r[1] >= r[2]) {
+        t = r[1]; r[1] = r[2]; r[2] = t;
+        if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+    }
+    if (r[0] <= 0.f) roots2_h(c2, c1, r);
+}
+inline void cross3_h(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline void smallest_eigenvector(const float cov[9], float n[3]) {
+    float scale = 0.f;
+    for (int i = 0; i < 9; ++i) scale = std::fmax(scale, std::fabs(cov[i]));
+    if (scale <= FLT_MIN) scale = 1.f;
+    float sm[9], ev[3];
+    for (int i = 0; i < 9; ++i) sm[i] = cov[i] / scale;
+    roots3_h(sm, ev);
+    sm[0] -= ev[0]; sm[4] -= ev[0]; sm[8] -= ev[0];
+    float v1[3], v2[3], v3[3];
+    cross3_h(sm + 0, sm + 3, v1);
+    cross3_h(sm + 0, sm + 6, v2);
+    cross3_h(sm + 3, sm + 6, v3);
+    const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+    const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+    const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+    const float* v; float l;
+    if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
+    else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
+    else { v = v3; l = l3; }
+    const float s = std::sqrt(l);
+    n[0] = v[0] / s; n[1] = v[1] / s; n[2] = v[2] / s;
+}
+
+inline int g1(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+// ascending list of the points within the threshold of `model`; *m = their number
+int select_inliers(pcc_index* ix, const float4* pts, unsigned int n, const float c[4], double threshold,
+                   int32_t* out_dev, size_t* m) {
+    hipStream_t s = ix->stream;
+    PCC_TRY(ix->scratch_c.reserve(((size_t)n + 1) * 4));
+    unsigned int* pos = ix->scratch_c.as<unsigned int>();
+    const float4 model = make_float4(c[0], c[1], c[2], c[3]);
+    hipLaunchKernelGGL(k_sac_flag, dim3(g1(n + 1)), dim3(256), 0, s, pts, n, model, threshold, pos);
+    PCC_HIP(hipGetLastError());
+    PCC_TRY(launch_exclusive_scan(s, pos, (size_t)n + 1, ix->scratch_d));
+    hipLaunchKernelGGL(k_sac_scatter, dim3(g1(n)), dim3(256), 0, s, pts, n, model, threshold, pos, out_dev);
+    PCC_HIP(hipGetLastError());
+    unsigned int* h = static_cast<unsigned int*>(ix->pinned);
+    PCC_HIP(hipMemcpyAsync(h, pos + n, 4, hipMemcpyDeviceToHost, s));
+    PCC_HIP(hipStreamSynchronize(s));
+    *m = h[0];
+    return PCC_OK;
+}
+
+}  // namespace
+
+// pts_dev: the staged cloud (float4, w < 0 = non-finite).  host_xyz(i): pointer to the i-th point's three floats
+// on the host (the caller's own array, or a copy of the staged cloud).
+int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_base, size_t host_stride,
+              int max_iterations, double threshold, double probability, int optimize, int32_t* inliers_dev,
+              size_t* n_inliers, float coeff[4], int* iterations_out) {
+    hipStream_t s = ix->stream;
+    const unsigned int n = (unsigned int)n_;
+    auto P = [&](int32_t i) { return reinterpret_cast<const float*>(host_base + (size_t)i * host_stride); };
+    *n_inliers = 0;
+    coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.f;
+    if (iterations_out) *iterations_out = 0;
+    if (n < 3) return PCC_OK;  // PCL: "Can not select 3 unique points" -> no model, no inliers
+
+    PCC_TRY(ix->scratch_a.reserve(SAC_BATCH * sizeof(float4)));
+    PCC_TRY(ix->scratch_b.reserve(SAC_BATCH * sizeof(unsigned int)));
+    float4* d_models = ix->scratch_a.as<float4>();
+    unsigned int* d_counts = ix->scratch_b.as<unsigned int>();
+
+    Mt19937 gen(12345u);
+    std::vector<int32_t> shuffled(n);
+    for (unsigned int i = 0; i < n; ++i) shuffled[i] = (int32_t)i;
+    int iterations = 0, best_count = -INT32_MAX;
+    bool have_model = false, stop = false;
+    double k = 1.0;
+    const double log_probability = std::log(1.0 - probability);
+    const double one_over_indices = 1.0 / (double)n;
+    unsigned skipped = 0;
+    const unsigned max_skip = (unsigned)max_iterations * 10u;
+    float best[4] = {0, 0, 0, 0};
+    const float qnan = std::nanf("");
+    ev_mark(ix, EV_MAIN0);
+    while (!stop && iterations < k && skipped < max_skip) {
+        // the next batch of candidate planes, drawn exactly as PCL's loop would draw them
+        float models[SAC_BATCH][4];
+        int nm = 0;
+        bool sampling_failed = false;
+        unsigned skipped_batch = skipped;
+        while (nm < SAC_BATCH && iterations + nm <= max_iterations && skipped_batch < max_skip) {
+            int32_t smp[3];
+            bool got = false;
+            for (int it = 0; it < 1000 && !got; ++it) {  // max_sample_checks_
+                for (unsigned i = 0; i < 3; ++i) std::swap(shuffled[i], shuffled[i + (size_t)gen.rnd() % (n - i)]);
+                smp[0] = shuffled[0]; smp[1] = shuffled[1]; smp[2] = shuffled[2];
+                got = !sample_degenerate(P(smp[0]), P(smp[1]), P(smp[2]));
+            }
+            if (!got) { sampling_failed = true; break; }
+            if (!plane_from_sample(P(smp[0]), P(smp[1]), P(smp[2]), models[nm])) { ++skipped_batch; continue; }
+            ++nm;
+        }
+        // NOTE: the draws above run ahead of PCL's loop by at most one batch; the generator state is only
+        // consumed by draws, so running ahead never changes a plane PCL would have used.
+        for (int m = nm; m < SAC_BATCH; ++m) models[m][0] = models[m][1] = models[m][2] = models[m][3] = qnan;
+        unsigned int counts[SAC_BATCH] = {0};
+        if (nm > 0) {
+            PCC_HIP(hipMemsetAsync(d_counts, 0, SAC_BATCH * sizeof(unsigned int), s));
+            PCC_HIP(hipMemcpyAsync(d_models, models, sizeof(models), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_sac_count, dim3(g1(n)), dim3(256), 0, s, pts_dev, n, d_models, threshold, d_counts);
+            PCC_HIP(hipGetLastError());
+            PCC_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+            PCC_HIP(hipStreamSynchronize(s));
+        }
+        // PCL's loop over this batch.  Skips (degenerate samples) happened between the valid models in
+        // generation order; they only matter through the max_skip bound, which is checked per batch.
+        skipped = skipped_batch;
+        for (int m = 0; m < nm; ++m) {
+            if (!(iterations < k)) { stop = true; break; }
+            const int cnt = (int)counts[m];
+            if (cnt > best_count) {
+                best_count = cnt;
+                have_model = true;
+                std::memcpy(best, models[m], sizeof(best));
+                const double w = (double)best_count * one_over_indices;
+                double p_no_outliers = 1.0 - std::pow(w, 3.0);
+                p_no_outliers = std::fmax(DBL_EPSILON, p_no_outliers);
+                p_no_outliers = std::fmin(1.0 - DBL_EPSILON, p_no_outliers);
+                k = log_probability / std::log(p_no_outliers);
+            }
+            ++iterations;
+            if (iterations > max_iterations) { stop = true; break; }
+        }
+        if (sampling_failed || nm == 0) break;
+    }
+    if (iterations_out) *iterations_out = iterations;
+    if (!have_model) { ev_mark(ix, EV_MAIN1); return PCC_OK; }
+
+    size_t m = 0;
+    PCC_TRY(select_inliers(ix, pts_dev, n, best, threshold, inliers_dev, &m));
+    std::memcpy(coeff, best, sizeof(best));
+    if (optimize && m >= 4) {
+        // optimizeModelCoefficients: computeMeanAndCovarianceMatrix over the inliers, in index order, in float
+        std::vector<int32_t> hi(m);
+        PCC_HIP(hipMemcpyAsync(hi.data(), inliers_dev, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        PCC_HIP(hipStreamSynchronize(s));
+        float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t j = 0; j < m; ++j) {
+            const float* q = P(hi[j]);
+            a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2];
+            a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
+            a[6] += q[0]; a[7] += q[1]; a[8] += q[2];
+        }
+        const float inv_cnt = 1.0f / (float)m;
+        for (int i = 0; i < 9; ++i) a[i] *= inv_cnt;
+        float cov[9];
+        cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+        cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        float nrm[3];
+        smallest_eigenvector(cov, nrm);
+        float o[4] = {nrm[0], nrm[1], nrm[2], 0.f};
+        const float cen[4] = {a[6], a[7], a[8], 0.f};
+        o[3] = -1.0f * dot4(o, cen);
+        std::memcpy(coeff, o, sizeof(o));
+        PCC_TRY(select_inliers(ix, pts_dev, n, o, threshold, inliers_dev, &m));
+    }
+    ev_mark(ix, EV_MAIN1);
+    *n_inliers = m;
+    return PCC_OK;
+}
+
+}  // namespace pcc

@@ -6,8 +6,7 @@
 //   cluster counts (:1199-1205) -> [-n] noise pass (:1520-1568) -> results file.
 // Same flags, banner lines, section strings and exit code (always 1, :1704).  NOT part of this build
 // (out of scope): descriptor pipelines (SIFT/RIFT) and the per-cluster matching /
-// scoring that needs them, the RANSAC plane removal of the -e path (:79-117) and the viewer (-v is accepted
-// and ignored).  Both segmentation paths run: region growing (default, src/segmentation.cpp:218-327) and
+// scoring that needs them, and the viewer (-v is accepted and ignored).  Both segmentation paths run: region growing (default, src/segmentation.cpp:218-327) and
 // Euclidean clustering (-e, :64-156), each behind the VoxelGrid the reference applies first.
 #include <cmath>
 #include <cstdio>
@@ -32,8 +31,8 @@ static void printUsage() {
               << "-h show this help\n" << "\n\n";
 }
 
-// src/segmentation.cpp:64-156 euclidean_cluster_segmentation: VoxelGrid 0.025 (:69-76) -> [RANSAC plane
-// removal :79-117, not part of this build] -> KdTree + EuclideanClusterExtraction (:119-156)
+// src/segmentation.cpp:64-156 euclidean_cluster_segmentation: VoxelGrid 0.025 (:69-76) -> RANSAC plane
+// removal until <= 30 % of the points remain (:79-117) -> KdTree + EuclideanClusterExtraction (:119-156)
 static std::vector<PointCloud<PointXYZRGB>::Ptr> euclidean_cluster_segmentation(const PointCloud<PointXYZRGB>::Ptr& point_cloud_ptr) {
     VoxelGrid<PointXYZRGB> vg;
     PointCloud<PointXYZRGB>::Ptr cloud_filtered(new PointCloud<PointXYZRGB>);
@@ -41,6 +40,34 @@ static std::vector<PointCloud<PointXYZRGB>::Ptr> euclidean_cluster_segmentation(
     vg.setLeafSize(0.025f, 0.025f, 0.025f);
     vg.filter(*cloud_filtered);
     std::cout << "PointCloud after filtering has: " << cloud_filtered->points.size() << " data points." << std::endl;
+    SACSegmentation<PointXYZRGB> seg;
+    std::shared_ptr<PointIndices> inliers(new PointIndices);
+    ModelCoefficients coefficients;
+    PointCloud<PointXYZRGB>::Ptr cloud_plane(new PointCloud<PointXYZRGB>), cloud_f(new PointCloud<PointXYZRGB>);
+    seg.setOptimizeCoefficients(true);
+    seg.setModelType(SACMODEL_PLANE);
+    seg.setMethodType(SAC_RANSAC);
+    seg.setMaxIterations(100);
+    seg.setDistanceThreshold(0.02);
+    const int nr_points = (int)cloud_filtered->points.size();
+    while (cloud_filtered->points.size() > 0.3 * nr_points) {
+        seg.setInputCloud(cloud_filtered);
+        seg.segment(*inliers, coefficients);
+        if (inliers->indices.size() == 0) {
+            std::cout << "Could not estimate a planar model for the given dataset." << std::endl;
+            break;
+        }
+        ExtractIndices<PointXYZRGB> extract;
+        extract.setInputCloud(cloud_filtered);
+        extract.setIndices(inliers);
+        extract.setNegative(false);
+        extract.filter(*cloud_plane);
+        std::cout << "PointCloud representing the planar component: " << cloud_plane->points.size() << " data points." << std::endl;
+        extract.setNegative(true);
+        extract.filter(*cloud_f);
+        // the reference assigns *cloud_filtered = *cloud_f; a fresh cloud keeps the pointer-keyed caches honest
+        cloud_filtered.reset(new PointCloud<PointXYZRGB>(*cloud_f));
+    }
     search::KdTree<PointXYZRGB>::Ptr tree(new search::KdTree<PointXYZRGB>);
     tree->setInputCloud(cloud_filtered);
     std::vector<PointIndices> cluster_indices;
