@@ -113,6 +113,25 @@ int main() {
     reg0.setInputCloud(plates);
     reg0.extract(regions);
     REQUIRE(regions.empty());
+
+    // SACSegmentation + ExtractIndices (src/segmentation.cpp:79-117): the z plate is the larger plane of `plates`
+    for (int i = 0; i < 2000; ++i) { PointXYZRGB p; p.x = 1 + U(rng); p.y = 1 + U(rng); p.z = 1 + 0.0005f * U(rng); plates->push_back(p); }
+    SACSegmentation<PointXYZRGB> seg;
+    seg.setOptimizeCoefficients(true); seg.setModelType(SACMODEL_PLANE); seg.setMethodType(SAC_RANSAC);
+    seg.setMaxIterations(100); seg.setDistanceThreshold(0.02); seg.setInputCloud(plates);
+    std::shared_ptr<PointIndices> inl(new PointIndices);
+    ModelCoefficients coef;
+    seg.segment(*inl, coef);
+    REQUIRE(inl->indices.size() == 5000 && coef.values.size() == 4);
+    REQUIRE(std::fabs(std::fabs(coef.values[2]) - 1.f) < 1e-3f && std::fabs(std::fabs(coef.values[3]) - 1.f) < 2e-2f);
+    REQUIRE(std::is_sorted(inl->indices.begin(), inl->indices.end()));
+    ExtractIndices<PointXYZRGB> ex;
+    PointCloud<PointXYZRGB> plane_pts, rest;
+    ex.setInputCloud(plates); ex.setIndices(inl);
+    ex.setNegative(false); ex.filter(plane_pts);
+    ex.setNegative(true); ex.filter(rest);
+    REQUIRE(plane_pts.size() == 5000 && rest.size() == 3000);
+    for (auto& p : rest.points) REQUIRE(p.y > 2.9f);
     std::printf("host mirror ok\n");
     return 0;
 }

@@ -15,18 +15,44 @@ ROOT = Path(__file__).resolve().parent.parent
 EXE = ROOT / "build" / "comparator"
 
 
-def _scene(n_per, seed):
+def _scene(seed, shift=(0.0, 0.0, 0.0)):
+    """A floor and four boxes of points on a 0.03 lattice with +-0.002 jitter: no two points share a 0.025
+    voxel, so the VoxelGrid output is the input (centroids of single points are exact in any summation
+    order) and everything downstream -- RANSAC samples included -- can be compared exactly."""
     rng = np.random.default_rng(seed)
-    blobs = [rng.normal(c, 0.05, (n_per, 3)) for c in [(0, 0, 0), (1, 0, 0), (0, 1, 0.5), (1, 1, 1)]]
-    stray = rng.uniform(3, 6, (40, 3))
-    return np.concatenate(blobs + [stray]).astype(np.float32)
+    g = np.stack(np.meshgrid(np.arange(60), np.arange(60), indexing="ij"), -1).reshape(-1, 2) * 0.03
+    floor = np.concatenate([g, np.zeros((len(g), 1))], 1)
+    c = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(-1, 3) * 0.03
+    boxes = [c + o for o in [(0.3, 0.3, 0.3), (1.2, 0.3, 0.45), (0.3, 1.2, 0.6), (1.2, 1.2, 0.3)]]
+    pts = np.concatenate([floor] + boxes)
+    pts = pts + rng.uniform(-0.002, 0.002, pts.shape) + 0.01 + np.asarray(shift)
+    return np.ascontiguousarray(pts[rng.permutation(len(pts))].astype(np.float32))
+
+
+def _euclidean_path(cloud):
+    """the reference's -e path on the oracle: VoxelGrid -> plane removal loop -> clusters"""
+    lines = []
+    vox, nv = oracle.voxel_grid(np.ascontiguousarray(cloud), 0.025)
+    vox = np.ascontiguousarray(vox[:, :3])
+    lines.append(f"PointCloud after filtering has: {nv} data points.")
+    n0 = len(vox)
+    while len(vox) > 0.3 * n0:
+        inl, _, _ = oracle.sac_plane(vox, 100, 0.02, 0.99, True)
+        if len(inl) == 0:
+            lines.append("Could not estimate a planar model for the given dataset.")
+            break
+        lines.append(f"PointCloud representing the planar component: {len(inl)} data points.")
+        vox = np.ascontiguousarray(np.delete(vox, inl, 0))
+    _, ncl, sizes = oracle.euclidean_clusters(vox, 0.05, 100, 250000)
+    lines += [f"PointCloud representing the Cluster: {s} data points." for s in sizes]
+    return lines, ncl
 
 
 def test_cli_icp_clusters_noise(gpu, tmp_path):
     if not EXE.exists():
         subprocess.check_call(["make", "cli"], cwd=ROOT)
-    a = _scene(4000, 1)
-    b = (a + np.float32([0.004, -0.003, 0.002]))[::-1].copy()
+    a = _scene(1)
+    b = _scene(2, shift=(0.004, -0.003, 0.002))
     b[5, 0] = np.nan  # stripped by removeNaNFromPointCloud
     fa, fb, res = tmp_path / "a.ply", tmp_path / "b.ply", tmp_path / "results.txt"
     write_ply(fa, a, fmt="binary")
@@ -41,22 +67,22 @@ def test_cli_icp_clusters_noise(gpu, tmp_path):
                  "ICP has converged. Point clouds segmentation is as follows",
                  "Both pcl have the same percentage of noisy points: 0"]:
         assert line in out, line
-    bf = b[np.isfinite(b).all(1)]
+    bf = np.ascontiguousarray(b[np.isfinite(b).all(1)])
+    ncls = []
+    pos = 0
     for cloud in (a, bf):
-        vox, nv = oracle.voxel_grid(np.ascontiguousarray(cloud), 0.025)  # the -e path down-samples first (:69-76)
-        assert f"PointCloud after filtering has: {nv} data points." in out
-        _, ncl, sizes = oracle.euclidean_clusters(np.ascontiguousarray(vox), 0.05, 100, 250000)
-        for s in sizes:
-            assert f"PointCloud representing the Cluster: {s} data points." in out
-    assert out.count("PointCloud representing the Cluster:") >= 8
+        lines, ncl = _euclidean_path(cloud)
+        ncls.append(ncl)
+        for line in lines:  # same lines, same order
+            pos = out.index(line, pos) + 1
+        assert any("planar component" in l for l in lines)
+    assert out.count("PointCloud representing the Cluster:") == sum(ncls) == 8
     kept = [oracle.sor(c, 50, 1.5)[3] for c in (a, bf)]
     assert f"Noise pass removed {len(a) - kept[0]} / {len(bf) - kept[1]} points" in out
     txt = res.read_text()
     assert txt.startswith(f"Results of comparison between {fa} and {fb}\n" + "-" * 80)
     assert f"Number of points of PCL 1: {len(a)}\n" in txt and f"Number of points of PCL 2: {len(bf)}\n" in txt
-    n1 = oracle.euclidean_clusters(np.ascontiguousarray(oracle.voxel_grid(a, 0.025)[0]), 0.05, 100, 250000)[1]
-    n2 = oracle.euclidean_clusters(np.ascontiguousarray(oracle.voxel_grid(np.ascontiguousarray(bf), 0.025)[0]), 0.05, 100, 250000)[1]
-    assert n1 >= 4 and f"Number of clusters of PCL 1: {n1}\n" in txt and f"Number of clusters of PCL 2: {n2}\n" in txt
+    assert f"Number of clusters of PCL 1: {ncls[0]}\n" in txt and f"Number of clusters of PCL 2: {ncls[1]}\n" in txt
     assert "----------------------------------------\n Noise analysis: \n" in txt
 
 

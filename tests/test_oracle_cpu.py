@@ -248,3 +248,35 @@ def test_region_growing_restatement_small_cases():
     assert ncl == 2
     lab, ncl = oracle.region_growing(nrm, nbr, np.pi / 2 + 0.01, 1.0, 1, 100)
     assert ncl == 1
+
+
+def test_sac_generator_known_answers():
+    # C++11 [rand.predef]: the 10000th value of a default-constructed mt19937 (seed 5489) is 4123659995
+    assert oracle.mt19937_raw(5489, 10000)[-1] == 4123659995
+    # independent implementation: numpy's MT19937 with the same init_genrand seeding
+    bg = np.random.MT19937()
+    bg._legacy_seeding(12345)
+    assert (bg.random_raw(2000).astype(np.uint32) == oracle.mt19937_raw(12345, 2000)).all()
+
+
+def test_sac_plane_restatement():
+    rng = np.random.default_rng(0)
+    n = 6000
+    plane = np.stack([rng.random(n) * 2, rng.random(n) * 2, 0.5 + rng.normal(0, 0.004, n)], 1)
+    pts = np.concatenate([plane, rng.random((n // 2, 3)) * 2]).astype(np.float32)[rng.permutation(n + n // 2)]
+    pts = np.ascontiguousarray(pts)
+    inl, c, its = oracle.sac_plane(pts)
+    # deterministic (fixed seed), finds the plane, unit normal, inliers are exactly the points within the threshold
+    inl2, c2, its2 = oracle.sac_plane(pts)
+    assert (inl == inl2).all() and (c == c2).all() and its == its2
+    assert abs(abs(c[2]) - 1) < 1e-3 and abs(abs(c[3]) - 0.5) < 2e-3
+    assert abs(np.linalg.norm(c[:3]) - 1) < 1e-6
+    d = np.abs(((pts[:, 0] * c[0] + pts[:, 1] * c[1]) + (pts[:, 2] * c[2] + c[3])).astype(np.float32)).astype(np.float64)
+    assert (np.nonzero(d < 0.02)[0] == inl).all()
+    # adaptive stopping: w ~ 2/3 -> k = log(0.01)/log(1 - w^3) ~ 13
+    assert 5 <= its <= 40
+    # without the refit the coefficients come from three sample points: less accurate, still the plane
+    _, c3, _ = oracle.sac_plane(pts, optimize=False)
+    assert abs(abs(c3[2]) - 1) < 0.02
+    # fewer than three points -> no model
+    assert len(oracle.sac_plane(pts[:2])[0]) == 0

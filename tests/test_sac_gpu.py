@@ -13,7 +13,7 @@ def _scene(n_plane, n_clutter, seed, noise=0.005, tilt=(0.1, -0.2, 1.0), offset=
     rng = np.random.default_rng(seed)
     nrm = np.asarray(tilt, np.float64)
     nrm /= np.linalg.norm(nrm)
-    e1 = np.cross(nrm, [1.0, 0, 0]); e1 /= np.linalg.norm(e1)
+    e1 = np.cross(nrm, [1.0, 0, 0] if abs(nrm[0]) < 0.9 else [0, 1.0, 0]); e1 /= np.linalg.norm(e1)
     e2 = np.cross(nrm, e1)
     uv = rng.random((n_plane, 2)) * 3
     plane = uv[:, :1] * e1 + uv[:, 1:] * e2 + offset * nrm + rng.normal(0, noise, (n_plane, 1)) * nrm
@@ -81,11 +81,17 @@ def test_sac_plane_device_memory_and_edge_cases():
     assert len(inl) == 0 and its == 0 and (c == 0).all()
     inl, c, its = ctx.sac_plane(np.zeros((0, 3), np.float32))
     assert len(inl) == 0
-    # all points identical: every sample is degenerate -> PCL gives up ("No samples could be selected")
+    # all points identical: (p1-p0)/(p2-p0) is 0/0 = NaN on every lane, which PCL's equality test does NOT flag
+    # as collinear; the plane normalises to NaN, supports nothing, and RANSAC runs out its iterations
     same = np.ones((50, 3), np.float32)
     inl, c, its = ctx.sac_plane(same)
     w_inl, w_c, w_its = oracle.sac_plane(same)
-    assert len(inl) == len(w_inl) == 0 and its == w_its == 0
+    assert len(inl) == len(w_inl) == 0 and its == w_its == 101
+    # two distinct points repeated: differences are 0 or +-d, ratios equal on all lanes -> degenerate samples only
+    two = np.tile(np.array([[0, 0, 0], [1, 1, 1]], np.float32), (20, 1))
+    inl, c, its = ctx.sac_plane(two)
+    w_inl, w_c, w_its = oracle.sac_plane(two)
+    assert len(inl) == len(w_inl) and its == w_its
     # exactly coplanar lattice: threshold 0 keeps nothing (strict <), tiny threshold keeps all
     g = np.stack(np.meshgrid(np.arange(10.0), np.arange(10.0)), -1).reshape(-1, 2)
     flat = np.concatenate([g, np.full((100, 1), 2.0)], 1).astype(np.float32)
