@@ -180,14 +180,17 @@ template <int U>
 __device__ __forceinline__ unsigned long long scan_span(const float4* __restrict__ cell_refs, unsigned int s,
                                                         unsigned int e, float qx, float qy, float qz,
                                                         unsigned long long best) {
-    for (unsigned int p = s; p < e; p += U) {
+    // one pointer per span, advanced by U; the U loads use immediate offsets and the tail predicate is a
+    // compare of the remaining count against a constant: ~4 VALU fewer per candidate slot than indexing
+    const float4* ptr = cell_refs + s;
+    for (int rem = (int)(e - s); rem > 0; rem -= U, ptr += U) {
         float4 r[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (u == 0 || p + u < e) r[u] = cell_refs[p + u];
+            if (u == 0 || rem > u) r[u] = ptr[u];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (u == 0 || p + u < e) best = fold(best, qx, qy, qz, r[u]);
+            if (u == 0 || rem > u) best = fold(best, qx, qy, qz, r[u]);
     }
     return best;
 }

@@ -160,6 +160,11 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 const unsigned int* __restrict__ n_sorted_ptr, int K, unsigned long long* __restrict__ keys) {
     static_assert(KR == 1 || KR == 2, "top list lives in one or two registers per lane");
     __shared__ unsigned long long stage_all[4][128];
+    constexpr int ROWCAP = (2 * GRID_KMAX + 1) * (2 * GRID_KMAX + 1);  // rows of the largest cube
+    __shared__ unsigned int tab_s_all[4][ROWCAP], tab_o_all[4][ROWCAP], win_all[4][64];
+    unsigned int* tab_s = tab_s_all[threadIdx.x >> 6];
+    unsigned int* tab_o = tab_o_all[threadIdx.x >> 6];
+    unsigned int* win = win_all[threadIdx.x >> 6];
     const GridParams g = gd->g;
     const float slack = gd->slack;
     const unsigned int n_valid = gd->n_valid;
@@ -204,36 +209,100 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
             for (int r = 0; r < KR; ++r) top[r] = ~0ull;
             unsigned long long tau = ~0ull;
             unsigned int scnt = 0;  // wave-uniform
-            for (int z = z0; z <= z1; ++z)
-                for (int y = y0; y <= y1; ++y) {
-                    const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
-                    const unsigned int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-                    for (unsigned int p = s; p < e; p += 64) {
-                        const unsigned int pp = p + lane;
-                        unsigned long long key = ~0ull;
-                        if (pp < e) {
-                            const float4 r4 = cell_refs[pp];
-                            key = make_key(dist2(qx, qy, qz, r4), r4);
-                        }
-                        const bool pass = key < tau;
-                        const unsigned long long mask = __ballot(pass);
-                        if (mask == 0) continue;
-                        if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
-                        scnt += (unsigned int)__popcll(mask);
-                        __builtin_amdgcn_wave_barrier();
-                        if (scnt >= 64) {
-                            const unsigned long long batch = stage[lane];
-                            const unsigned int rest = scnt - 64;
-                            const unsigned long long carry = lane < rest ? stage[64 + lane] : ~0ull;
-                            __builtin_amdgcn_wave_barrier();
-                            if (lane < rest) stage[lane] = carry;
-                            scnt = rest;
-                            topk_merge<KR>(top, batch, lane);
-                            tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
-                            __builtin_amdgcn_wave_barrier();
+            // one batch of <= 64 candidate keys: filter by tau, stage the survivors, merge when 64 have gathered
+            auto consume = [&](unsigned long long key) {
+                const bool pass = key < tau;
+                const unsigned long long mask = __ballot(pass);
+                if (mask == 0) return;
+                if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+                scnt += (unsigned int)__popcll(mask);
+                __builtin_amdgcn_wave_barrier();
+                if (scnt >= 64) {
+                    const unsigned long long batch = stage[lane];
+                    const unsigned int rest = scnt - 64;
+                    const unsigned long long carry = lane < rest ? stage[64 + lane] : ~0ull;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) stage[lane] = carry;
+                    scnt = rest;
+                    topk_merge<KR>(top, batch, lane);
+                    tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            };
+            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+            if (!whole) {
+                // FLAT walk: the cube's non-empty rows go into an LDS table (start, running offset) -- lanes
+                // over rows, so the row bounds cost one or two wave loads instead of two dependent loads per
+                // row -- and the candidates are then taken 64 at a time across row boundaries.  In sparse
+                // regions a cube has many rows of 1-3 points: row by row that is one nearly empty wave load
+                // (and two round trips) per row.
+                unsigned int nrows_t = 0, total = 0;  // wave-uniform
+                for (int base = 0; base < nrow; base += 64) {
+                    const int r = base + (int)lane;
+                    unsigned int s0 = 0, cnt = 0;
+                    if (r < nrow) {
+                        const unsigned int row = ((unsigned int)(z0 + r / ny) * g.dim[1] + (y0 + r % ny)) * g.dim[0];
+                        s0 = cell_start[row + x0];
+                        cnt = cell_start[row + x1 + 1] - s0;
+                    }
+                    unsigned int incl = cnt;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned int tt = __shfl_up(incl, off, 64);
+                        if (lane >= (unsigned int)off) incl += tt;
+                    }
+                    const unsigned long long occ = __ballot(cnt != 0);
+                    if (cnt) {
+                        const unsigned int slot = nrows_t + (unsigned int)__popcll(occ & lt_mask);
+                        tab_s[slot] = s0;
+                        tab_o[slot] = total + incl - cnt;
+                    }
+                    nrows_t += (unsigned int)__popcll(occ);
+                    total += __shfl(incl, 63, 64);
+                }
+                __builtin_amdgcn_wave_barrier();
+                unsigned int next_row = 0, carry_row = 0;  // wave-uniform
+                for (unsigned int B = 0; B < total; B += 64) {
+                    win[lane] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned int r = next_row + lane;
+                    const bool starts = r < nrows_t && tab_o[r] < B + 64;  // offsets are strictly increasing
+                    if (starts) win[tab_o[r] - B] = r + 1;
+                    next_row += (unsigned int)__popcll(__ballot(starts));
+                    __builtin_amdgcn_wave_barrier();
+                    unsigned int v = win[lane];
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned int tt = __shfl_up(v, off, 64);
+                        if (lane >= (unsigned int)off) v = max(v, tt);
+                    }
+                    v = max(v, carry_row);
+                    carry_row = __shfl(v, 63, 64);
+                    const unsigned int c = B + lane;
+                    unsigned long long key = ~0ull;
+                    if (c < total) {
+                        const unsigned int myrow = v - 1;
+                        const float4 r4 = cell_refs[tab_s[myrow] + (c - tab_o[myrow])];
+                        key = make_key(dist2(qx, qy, qz, r4), r4);
+                    }
+                    consume(key);
+                }
+            } else {
+                for (int z = z0; z <= z1; ++z)
+                    for (int y = y0; y <= y1; ++y) {
+                        const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                        const unsigned int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                        for (unsigned int p = s; p < e; p += 64) {
+                            const unsigned int pp = p + lane;
+                            unsigned long long key = ~0ull;
+                            if (pp < e) {
+                                const float4 r4 = cell_refs[pp];
+                                key = make_key(dist2(qx, qy, qz, r4), r4);
+                            }
+                            consume(key);
                         }
                     }
-                }
+            }
             if (scnt) {
                 const unsigned long long batch = lane < scnt ? stage[lane] : ~0ull;
                 __builtin_amdgcn_wave_barrier();

@@ -49,3 +49,30 @@ def test_golden_icp_iterations(gpu):
             assert (idx == g["corr"][it]).all()       # identical inputs -> identical correspondences
             cur = ix.transform(g["T"][it], cur)       # golden transform keeps the inputs identical
         assert (_bits(cur) == _bits(g["final"])).all()
+
+
+def test_golden_segmentation_rows(gpu):
+    """the widened rows on the committed room scene: voxel grid, RANSAC plane, normals K=50,
+    region growing K=30, keypoint snap"""
+    g = np.load(G / "segmentation_6000.npz")
+    room, vox = g["room"], g["voxels"]
+    with capi.Index(room) as ix:
+        got_vox = ix.voxel_grid(room, 0.025)
+        fw = ix.first_within(vox[:200] + np.float32(0.01), 0.05)
+    assert got_vox.shape == vox.shape
+    np.testing.assert_allclose(got_vox, vox, rtol=0, atol=1e-5)  # PCL sums in float, the GPU in double (DESIGN 0)
+    assert (fw == g["first_within"]).all()
+    with capi.Index(vox) as ix:
+        inl, coeff, its = ix.sac_plane(vox, 100, 0.02, 0.99, True)
+        assert its == int(g["sac_iterations"]) and (inl == g["sac_inliers"]).all()
+        assert (_bits(coeff) == g["sac_coeff_bits"]).all()
+        nrm = ix.normals(50)
+        want = g["normals_bits"].view(np.float32)
+        same = (_bits(nrm) == g["normals_bits"]).all(axis=1)
+        assert same.mean() > 0.9                     # atan2f/cosf/sinf of libm vs the device's (DESIGN 4.6)
+        dots = np.abs((nrm[:, :3].astype(np.float64) * want[:, :3]).sum(1))
+        assert (dots > 1 - 1e-6).all()
+        np.testing.assert_allclose(nrm[:, 3], want[:, 3], rtol=0, atol=3e-7)
+        labels, ncl = ix.region_growing(want, k=30, smoothness=3.0 / 180.0 * np.pi, curvature_threshold=1.0,
+                                        min_size=50, max_size=1000000)
+    assert ncl == int(g["rg_clusters"]) and (labels == g["rg_labels"]).all()

@@ -250,6 +250,23 @@ def test_region_growing_restatement_small_cases():
     assert ncl == 1
 
 
+def test_golden_segmentation_rows():
+    """the restatements of the widened rows still produce the committed fixture (tools/gen_golden.py step 5)"""
+    g = np.load(G / "segmentation_6000.npz")
+    room, vox = g["room"], g["voxels"]
+    got, nv = oracle.voxel_grid(room, 0.025)
+    assert nv == len(vox) and (got[:, :3].view(np.uint32) == vox.view(np.uint32)).all()
+    inl, coeff, its = oracle.sac_plane(vox, 100, 0.02, 0.99, True)
+    assert its == int(g["sac_iterations"]) and (inl == g["sac_inliers"]).all()
+    assert (coeff.view(np.uint32) == g["sac_coeff_bits"]).all()
+    nbr, _ = oracle.knn_exhaustive(vox, vox, 50)
+    nrm = oracle.normals(vox, 50, neighbours=nbr)
+    assert (nrm.view(np.uint32) == g["normals_bits"]).all()
+    lab, ncl = oracle.region_growing(nrm, nbr[:, :30], 3.0 / 180.0 * np.pi, 1.0, 50, 1000000)
+    assert ncl == int(g["rg_clusters"]) and (lab == g["rg_labels"]).all()
+    assert (oracle.first_within(room, vox[:200] + np.float32(0.01), 0.05) == g["first_within"]).all()
+
+
 def test_sac_generator_known_answers():
     # C++11 [rand.predef]: the 10000th value of a default-constructed mt19937 (seed 5489) is 4123659995
     assert oracle.mt19937_raw(5489, 10000)[-1] == 4123659995

@@ -73,6 +73,30 @@ def main():
         mats.append(T)
         cur = oracle.transform(T, cur)
     np.savez_compressed(OUT / "icp_2048.npz", src=src, tgt=tgt, corr=np.stack(corr), T=np.stack(mats), final=cur)
+    # (5) segmentation rows: voxel grid, RANSAC plane, normals K=50, region growing K=30 on a
+    # 6000-point room (floor + two walls + a ball), every stage from the restatements in oracle/
+    rng = np.random.default_rng(0x5E6)
+    def wall(n, origin, e1, e2):
+        uv = rng.random((n, 2)) * 1.5
+        return np.asarray(origin) + uv[:, :1] * np.asarray(e1) + uv[:, 1:] * np.asarray(e2)
+    d = rng.normal(size=(900, 3))
+    room = np.concatenate([wall(2100, (1, 1, 1), (1, 0, 0), (0, 1, 0)), wall(1500, (1, 1, 1), (1, 0, 0), (0, 0, 1)),
+                           wall(1500, (1, 1, 1), (0, 1, 0), (0, 0, 1)),
+                           d / np.linalg.norm(d, axis=1, keepdims=True) * 0.25 + (1.8, 1.8, 1.8)])
+    room = (room + rng.normal(0, 0.0015, room.shape)).astype(np.float32)
+    room = np.ascontiguousarray(room[rng.permutation(len(room))])
+    vox, nv = oracle.voxel_grid(room, 0.025)
+    vox = np.ascontiguousarray(vox[:, :3])
+    inl, coeff, its = oracle.sac_plane(vox, 100, 0.02, 0.99, True)
+    nbr50, _ = oracle.knn_exhaustive(vox, vox, 50)
+    nrm = oracle.normals(vox, 50, neighbours=nbr50)
+    nbr30, _ = oracle.knn_exhaustive(vox, vox, 30)
+    lab, ncl = oracle.region_growing(nrm, nbr30, 3.0 / 180.0 * np.pi, 1.0, 50, 1000000)
+    assert ncl >= 3 and len(inl) > 500
+    fw = oracle.first_within(room, vox[:200] + np.float32(0.01), 0.05)
+    np.savez_compressed(OUT / "segmentation_6000.npz", room=room, voxels=vox, sac_inliers=inl, sac_coeff_bits=coeff.view(np.uint32),
+                        sac_iterations=np.int32(its), normals_bits=nrm.view(np.uint32), rg_labels=lab, rg_clusters=np.int32(ncl),
+                        first_within=fw)
     print("golden fixtures written to", OUT)
 
 
