@@ -160,8 +160,8 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 const unsigned int* __restrict__ n_sorted_ptr, int K, unsigned long long* __restrict__ keys) {
     static_assert(KR == 1 || KR == 2, "top list lives in one or two registers per lane");
     __shared__ unsigned long long stage_all[4][128];
-    constexpr int ROWCAP = (2 * GRID_KMAX + 1) * (2 * GRID_KMAX + 1);  // rows of the largest cube
-    __shared__ unsigned int tab_s_all[4][ROWCAP], tab_o_all[4][ROWCAP], win_all[4][64];
+    constexpr int ROWCAP2 = 2 * 11 * 11;  // two spans per row; boxes of up to 11 x 11 rows take the flat walk
+    __shared__ unsigned int tab_s_all[4][ROWCAP2], tab_o_all[4][ROWCAP2], win_all[4][64];
     unsigned int* tab_s = tab_s_all[threadIdx.x >> 6];
     unsigned int* tab_o = tab_o_all[threadIdx.x >> 6];
     unsigned int* win = win_all[threadIdx.x >> 6];
@@ -183,7 +183,9 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
         const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
         const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
-        // smallest cube whose inscribed ball should already hold `want` points at the local density
+        // first pass: the smallest cube that holds at least `want` points (its K-th key is then an upper
+        // bound); the second pass covers what the ball of that bound adds around the cube.  Every pass scans
+        // its box MINUS the box already scanned, so no point is seen twice and nothing is rescanned.
         int k = 1;
         for (;; ++k) {
             const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
@@ -196,54 +198,72 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 cnt += cell_start[row + x1 + 1] - cell_start[row + x0];
             }
             for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-            const float kk = (float)k, side = 2.f * kk + 1.f;
-            if ((float)cnt * (4.18879f * kk * kk * kk) >= (float)want * side * side * side || k >= GRID_KMAX) break;
+            if (cnt >= (unsigned int)want || k >= GRID_KMAX) break;
         }
         unsigned long long top[KR];
-        for (;;) {
-            const bool whole = k > GRID_KMAX;  // past KMAX: scan the whole grid (exact, slow, rare)
-            const int x0 = whole ? 0 : max(cx - k, 0), x1 = whole ? g.dim[0] - 1 : min(cx + k, g.dim[0] - 1);
-            const int y0 = whole ? 0 : max(cy - k, 0), y1 = whole ? g.dim[1] - 1 : min(cy + k, g.dim[1] - 1);
-            const int z0 = whole ? 0 : max(cz - k, 0), z1 = whole ? g.dim[2] - 1 : min(cz + k, g.dim[2] - 1);
 #pragma unroll
-            for (int r = 0; r < KR; ++r) top[r] = ~0ull;
-            unsigned long long tau = ~0ull;
-            unsigned int scnt = 0;  // wave-uniform
-            // one batch of <= 64 candidate keys: filter by tau, stage the survivors, merge when 64 have gathered
-            auto consume = [&](unsigned long long key) {
-                const bool pass = key < tau;
-                const unsigned long long mask = __ballot(pass);
-                if (mask == 0) return;
-                if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
-                scnt += (unsigned int)__popcll(mask);
+        for (int r = 0; r < KR; ++r) top[r] = ~0ull;
+        unsigned long long tau = ~0ull;
+        unsigned int scnt = 0;  // wave-uniform
+        // one batch of <= 64 candidate keys: filter by tau, stage the survivors, merge when 64 have gathered
+        auto consume = [&](unsigned long long key) {
+            const bool pass = key < tau;
+            const unsigned long long mask = __ballot(pass);
+            if (mask == 0) return;
+            if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+            scnt += (unsigned int)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (scnt >= 64) {
+                const unsigned long long batch = stage[lane];
+                const unsigned int rest = scnt - 64;
+                const unsigned long long carry = lane < rest ? stage[64 + lane] : ~0ull;
                 __builtin_amdgcn_wave_barrier();
-                if (scnt >= 64) {
-                    const unsigned long long batch = stage[lane];
-                    const unsigned int rest = scnt - 64;
-                    const unsigned long long carry = lane < rest ? stage[64 + lane] : ~0ull;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) stage[lane] = carry;
-                    scnt = rest;
-                    topk_merge<KR>(top, batch, lane);
-                    tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
-                    __builtin_amdgcn_wave_barrier();
-                }
-            };
+                if (lane < rest) stage[lane] = carry;
+                scnt = rest;
+                topk_merge<KR>(top, batch, lane);
+                tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        auto flush = [&]() {
+            if (scnt) {
+                const unsigned long long batch = lane < scnt ? stage[lane] : ~0ull;
+                __builtin_amdgcn_wave_barrier();
+                topk_merge<KR>(top, batch, lane);
+                tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
+                scnt = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        // box of this pass and box already scanned (empty at first)
+        int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+        int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+        int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+        int ix0 = 1, ix1 = 0, iy0 = 1, iy1 = 0, iz0 = 1, iz1 = 0;
+        bool ball_pass = false;  // this pass covers the ball of a valid bound: exact when it ends
+        for (;;) {
+            const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1;
             const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-            if (!whole) {
-                // FLAT walk: the cube's non-empty rows go into an LDS table (start, running offset) -- lanes
-                // over rows, so the row bounds cost one or two wave loads instead of two dependent loads per
-                // row -- and the candidates are then taken 64 at a time across row boundaries.  In sparse
-                // regions a cube has many rows of 1-3 points: row by row that is one nearly empty wave load
-                // (and two round trips) per row.
-                unsigned int nrows_t = 0, total = 0;  // wave-uniform
-                for (int base = 0; base < nrow; base += 64) {
-                    const int r = base + (int)lane;
+            if (2 * nrow <= ROWCAP2) {
+                // FLAT walk: the pass's non-empty spans go into an LDS table (start, running offset) -- lanes
+                // over rows, so the bounds cost a few wave loads instead of two dependent loads per row -- and
+                // the candidates are then taken 64 at a time across span boundaries.  A row that crosses the
+                // box already scanned contributes the part left of it and the part right of it.
+                unsigned int nspans = 0, total = 0;  // wave-uniform
+                for (int base = 0; base < 2 * nrow; base += 64) {
+                    const int v = base + (int)lane, r = v >> 1, side = v & 1;
                     unsigned int s0 = 0, cnt = 0;
                     if (r < nrow) {
-                        const unsigned int row = ((unsigned int)(z0 + r / ny) * g.dim[1] + (y0 + r % ny)) * g.dim[0];
-                        s0 = cell_start[row + x0];
-                        cnt = cell_start[row + x1 + 1] - s0;
+                        const int z = z0 + r / ny, y = y0 + r % ny;
+                        const bool crosses = y >= iy0 && y <= iy1 && z >= iz0 && z <= iz1;
+                        int a = x0, b = x1;  // cells [a, b]
+                        if (crosses) { if (side == 0) b = ix0 - 1; else a = ix1 + 1; }
+                        else if (side == 1) b = a - 1;
+                        if (a <= b) {
+                            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                            s0 = cell_start[row + a];
+                            cnt = cell_start[row + b + 1] - s0;
+                        }
                     }
                     unsigned int incl = cnt;
 #pragma unroll
@@ -253,22 +273,22 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                     }
                     const unsigned long long occ = __ballot(cnt != 0);
                     if (cnt) {
-                        const unsigned int slot = nrows_t + (unsigned int)__popcll(occ & lt_mask);
+                        const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
                         tab_s[slot] = s0;
                         tab_o[slot] = total + incl - cnt;
                     }
-                    nrows_t += (unsigned int)__popcll(occ);
+                    nspans += (unsigned int)__popcll(occ);
                     total += __shfl(incl, 63, 64);
                 }
                 __builtin_amdgcn_wave_barrier();
-                unsigned int next_row = 0, carry_row = 0;  // wave-uniform
+                unsigned int next_span = 0, carry_span = 0;  // wave-uniform
                 for (unsigned int B = 0; B < total; B += 64) {
                     win[lane] = 0u;
                     __builtin_amdgcn_wave_barrier();
-                    const unsigned int r = next_row + lane;
-                    const bool starts = r < nrows_t && tab_o[r] < B + 64;  // offsets are strictly increasing
+                    const unsigned int r = next_span + lane;
+                    const bool starts = r < nspans && tab_o[r] < B + 64;  // offsets are strictly increasing
                     if (starts) win[tab_o[r] - B] = r + 1;
-                    next_row += (unsigned int)__popcll(__ballot(starts));
+                    next_span += (unsigned int)__popcll(__ballot(starts));
                     __builtin_amdgcn_wave_barrier();
                     unsigned int v = win[lane];
 #pragma unroll
@@ -276,18 +296,24 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                         const unsigned int tt = __shfl_up(v, off, 64);
                         if (lane >= (unsigned int)off) v = max(v, tt);
                     }
-                    v = max(v, carry_row);
-                    carry_row = __shfl(v, 63, 64);
+                    v = max(v, carry_span);
+                    carry_span = __shfl(v, 63, 64);
                     const unsigned int c = B + lane;
                     unsigned long long key = ~0ull;
                     if (c < total) {
-                        const unsigned int myrow = v - 1;
-                        const float4 r4 = cell_refs[tab_s[myrow] + (c - tab_o[myrow])];
+                        const unsigned int my = v - 1;
+                        const float4 r4 = cell_refs[tab_s[my] + (c - tab_o[my])];
                         key = make_key(dist2(qx, qy, qz, r4), r4);
                     }
                     consume(key);
                 }
             } else {
+                // a box with more rows than the table holds (very sparse neighbourhoods, the whole-grid pass):
+                // row by row, from scratch
+#pragma unroll
+                for (int r = 0; r < KR; ++r) top[r] = ~0ull;
+                tau = ~0ull;
+                scnt = 0;
                 for (int z = z0; z <= z1; ++z)
                     for (int y = y0; y <= y1; ++y) {
                         const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
@@ -303,24 +329,43 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                         }
                     }
             }
-            if (scnt) {
-                const unsigned long long batch = lane < scnt ? stage[lane] : ~0ull;
-                __builtin_amdgcn_wave_barrier();
-                topk_merge<KR>(top, batch, lane);
-                tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
-            }
-            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
-            if (lb2 == __builtin_inff()) break;  // whole grid scanned
-            if (tau != ~0ull && __uint_as_float((unsigned int)(tau >> 32)) < lb2) break;
-            // grow and rescan from scratch (a rescan must not insert a point twice)
-            int kn = k + 1;
+            flush();
+            if (whole || ball_pass) break;
+            ix0 = x0; ix1 = x1; iy0 = y0; iy1 = y1; iz0 = z0; iz1 = z1;
+            bool go_whole = false;
             if (tau != ~0ull) {
-                const float need = sqrtf(__uint_as_float((unsigned int)(tau >> 32))) * g.inv_h;
-                kn = need < (float)GRID_KMAX ? max((int)need + 1, k + 1) : GRID_KMAX + 1;
-            } else if (k >= 2) {
-                kn = 2 * k;
+                const float td = __uint_as_float((unsigned int)(tau >> 32));
+                const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+                if (td < lb2) break;  // nothing outside the scanned box can beat the K-th key
+                // cover the ball of the bound (plus what is scanned already, so the subtraction stays a box)
+                const float rb = sqrtf(td) * 1.00001f + slack;
+                int a0, a1, b0, b1, c0, c1;
+                cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
+                cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
+                cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], c0, c1);
+                x0 = min(x0, a0); x1 = max(x1, a1); y0 = min(y0, b0); y1 = max(y1, b1); z0 = min(z0, c0); z1 = max(z1, c1);
+                ball_pass = rb < __builtin_inff();
+                go_whole = !ball_pass;
+            } else {
+                // fewer than `want` points so far: a bigger cube
+                k = k >= 2 ? 2 * k : k + 1;
+                if (k > GRID_KMAX) go_whole = true;
+                x0 = max(cx - k, 0); x1 = min(cx + k, g.dim[0] - 1);
+                y0 = max(cy - k, 0); y1 = min(cy + k, g.dim[1] - 1);
+                z0 = max(cz - k, 0); z1 = min(cz + k, g.dim[2] - 1);
             }
-            k = kn;
+            if (!go_whole && (x1 - x0 > 2 * GRID_KMAX + 2 || y1 - y0 > 2 * GRID_KMAX + 2 || z1 - z0 > 2 * GRID_KMAX + 2)) go_whole = true;
+            if (!go_whole && 2 * (y1 - y0 + 1) * (z1 - z0 + 1) > ROWCAP2) {
+                ix0 = iy0 = iz0 = 1; ix1 = iy1 = iz1 = 0;  // too many rows for the table: this box row by row, from scratch
+            }
+            if (go_whole) {  // from scratch over the whole grid (exact, slow, rare)
+                x0 = y0 = z0 = 0; x1 = g.dim[0] - 1; y1 = g.dim[1] - 1; z1 = g.dim[2] - 1;
+                ix0 = iy0 = iz0 = 1; ix1 = iy1 = iz1 = 0;
+                ball_pass = false;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) top[r] = ~0ull;
+                tau = ~0ull;
+            }
         }
         unsigned long long* list = keys + (size_t)qi * K;
 #pragma unroll
