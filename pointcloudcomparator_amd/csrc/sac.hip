@@ -16,6 +16,7 @@
 //            (a serial float chain, kept serial so the refit equals PCL's), pcl::eigen33, and a second
 //            device selection with the refined plane.
 // 4-float Eigen reductions are evaluated as (p0 + p1) + (p2 + p3) (packet product + hadd predux).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -48,12 +49,19 @@ k_sac_count(const float4* __restrict__ pts, unsigned int n, const float4* __rest
 #pragma unroll
         for (int m = 0; m < SAC_BATCH; ++m) cnt[m] += plane_inlier_dev(sm[m], p, threshold) ? 1u : 0u;
     }
+    // wave sums -> LDS -> ONE row of partial counts per workgroup (no same-address atomics: 16k waves adding
+    // to 32 words serialised to ~1 ms); the host adds the rows
+    __shared__ unsigned int red[4][SAC_BATCH];
 #pragma unroll
     for (int m = 0; m < SAC_BATCH; ++m) {
         unsigned int v = cnt[m];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counts[m], v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][m] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < SAC_BATCH)
+        counts[blockIdx.x * SAC_BATCH + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256)
@@ -221,7 +229,9 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_
     if (n < 3) return PCC_OK;  // PCL: "Can not select 3 unique points" -> no model, no inliers
 
     PCC_TRY(ix->scratch_a.reserve(SAC_BATCH * sizeof(float4)));
-    PCC_TRY(ix->scratch_b.reserve(SAC_BATCH * sizeof(unsigned int)));
+    const int count_blocks = std::min(g1(n), 512);  // 2 workgroups per CU, grid-stride
+    PCC_TRY(ix->scratch_b.reserve((size_t)count_blocks * SAC_BATCH * sizeof(unsigned int)));
+    std::vector<unsigned int> part((size_t)count_blocks * SAC_BATCH);
     float4* d_models = ix->scratch_a.as<float4>();
     unsigned int* d_counts = ix->scratch_b.as<unsigned int>();
 
@@ -261,12 +271,13 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_
         for (int m = nm; m < SAC_BATCH; ++m) models[m][0] = models[m][1] = models[m][2] = models[m][3] = qnan;
         unsigned int counts[SAC_BATCH] = {0};
         if (nm > 0) {
-            PCC_HIP(hipMemsetAsync(d_counts, 0, SAC_BATCH * sizeof(unsigned int), s));
             PCC_HIP(hipMemcpyAsync(d_models, models, sizeof(models), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_sac_count, dim3(g1(n)), dim3(256), 0, s, pts_dev, n, d_models, threshold, d_counts);
+            hipLaunchKernelGGL(k_sac_count, dim3(count_blocks), dim3(256), 0, s, pts_dev, n, d_models, threshold, d_counts);
             PCC_HIP(hipGetLastError());
-            PCC_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+            PCC_HIP(hipMemcpyAsync(part.data(), d_counts, part.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
             PCC_HIP(hipStreamSynchronize(s));
+            for (int b = 0; b < count_blocks; ++b)
+                for (int m = 0; m < SAC_BATCH; ++m) counts[m] += part[(size_t)b * SAC_BATCH + m];
         }
         // PCL's loop over this batch.  Skips (degenerate samples) happened between the valid models in
         // generation order; they only matter through the max_skip bound, which is checked per batch.
