@@ -13,10 +13,22 @@
 //   collect : roots whose size lies in [min, max]; the (few) survivors are ordered on the host
 //             by size descending, lowest member first among equal sizes
 //   label   : labels[original index] = cluster id or -1
+//
+// link, fast path (k_uf_link_cells): a second grid with cell edge 0.57 r.  The cell diagonal is then below r, so
+// all points of a cell are mutually connected -- they are chained to the cell's first point without a single
+// distance test -- and two cells can only be connected when their indices differ by at most 2 per axis.
+// For every occupied cell the 62 "forward" neighbour cells are split among the cell's points; a neighbour
+// cell whose first point already has the same root is skipped, otherwise its points are tested against
+// the cell's until the first pair within r is found (one union per connected cell pair).  The search
+// grid's cells (0.5 points per cell on average over the bounding box) hold tens of points each inside the
+// objects, where the per-point ball scan does 500-1000 distance tests to find ~90 neighbours; the cell
+// walk does a few tens.  Same components, hence the same clusters.
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
 #include "uf_device.hpp"
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace pcc {
@@ -51,6 +63,49 @@ k_uf_link(const float4* __restrict__ cell_refs, const unsigned int* __restrict__
                 if (opos < mypos && dist2(me.x, me.y, me.z, o) < r2) uf_union(parent, mypos, opos);
             }
         }
+}
+
+// thread t owns the t-th valid point in the order of the CLUSTERING grid (cr2 / cs2 / gd2)
+__global__ void __launch_bounds__(256)
+k_uf_link_cells(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2,
+                float r2, unsigned int* __restrict__ parent) {
+    const GridParams g = gd2->g;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= gd2->n_valid) return;
+    const float4 me = cr2[t];
+    const unsigned int mypos = (unsigned int)__float_as_int(me.w);
+    const int cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+    const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+    const unsigned int a0 = cs2[c], a1 = cs2[c + 1];
+    const unsigned int first = (unsigned int)__float_as_int(cr2[a0].w);
+    if (t != a0) uf_union(parent, mypos, first);  // same cell: within r by construction
+    // forward half of the 5 x 5 x 5 neighbourhood, 62 cells, numbered 0..61; this point takes every cnt-th
+    const unsigned int cnt = a1 - a0, j = t - a0;
+    for (unsigned int nb = j; nb < 62; nb += cnt) {
+        const int lin = (int)nb + 63;  // 62 = own cell in the 5x5x5 numbering (dz,dy,dx from -2): forward = lin > 62
+        const int dz = lin / 25 - 2, dy = (lin / 5) % 5 - 2, dx = lin % 5 - 2;
+        const int x = cx + dx, y = cy + dy, z = cz + dz;
+        if (x < 0 || x >= g.dim[0] || y < 0 || y >= g.dim[1] || z >= g.dim[2]) continue;
+        const unsigned int cb = ((unsigned int)z * g.dim[1] + y) * g.dim[0] + x;
+        const unsigned int b0 = cs2[cb], b1 = cs2[cb + 1];
+        if (b0 == b1) continue;
+        const unsigned int other = (unsigned int)__float_as_int(cr2[b0].w);
+        if (uf_find(parent, first) == uf_find(parent, other)) continue;  // linked already (through anything)
+        bool linked = false;
+        for (unsigned int pb = b0; pb < b1 && !linked; ++pb) {
+            const float4 o = cr2[pb];
+            for (unsigned int pa = a0; pa < a1; ++pa) {
+                const float4 m = cr2[pa];
+                if (dist2(m.x, m.y, m.z, o) < r2) {
+                    uf_union(parent, (unsigned int)__float_as_int(m.w), (unsigned int)__float_as_int(o.w));
+                    linked = true;
+                    break;
+                }
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -100,6 +155,37 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
                   int32_t* labels_dev, int32_t* n_clusters, int32_t* sizes, int max_sizes) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)ix->n_orig;
+    // (built first: the cell sort uses the scratch buffers the union-find arrays live in afterwards)
+    // clustering grid: cell edge 0.57 r (diagonal 0.987 r < r), over the bounding box of the valid points
+    bool cells_ok = false;
+    static const bool no_cells = getenv("PCC_EC_CELLS") && atoi(getenv("PCC_EC_CELLS")) == 0;
+    if (!no_cells && r > 0.f && n >= 4096) {
+        PCC_TRY(sync_info(ix));
+        GridDev hd;
+        memset(&hd, 0, sizeof(hd));
+        const float h = r * 0.57f;
+        double cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = (double)ix->bbox_hi[a] - (double)ix->bbox_lo[a];
+            hd.g.org[a] = ix->bbox_lo[a];
+            hd.g.dim[a] = (int)std::min(ext / h + 2.0, 2.0e9);
+            cells *= (double)hd.g.dim[a];
+        }
+        if (ix->n_valid > 0 && cells <= (double)(1u << 26)) {
+            hd.g.h = h;
+            hd.g.inv_h = 1.0f / h;
+            hd.g.ncells = hd.g.dim[0] * hd.g.dim[1] * hd.g.dim[2];
+            hd.n_valid = (unsigned int)ix->n_valid;
+            PCC_TRY(ix->vox_a.reserve((size_t)n * sizeof(float4) + 64));
+            PCC_TRY(ix->vox_b.reserve(sizeof(GridDev)));
+            PCC_TRY(ix->vox_c.reserve(((size_t)hd.g.ncells + 8) * sizeof(unsigned int)));
+            PCC_HIP(hipMemcpyAsync(ix->vox_b.p, &hd, sizeof(hd), hipMemcpyHostToDevice, s));
+            PCC_TRY(cell_sort(ix, ix->refs.as<float4>(), n, true, ix->vox_a.as<float4>(), nullptr, ix->vox_c.as<unsigned int>(),
+                              nullptr, ix->vox_b.as<GridDev>(), (unsigned int)hd.g.ncells));
+            PCC_HIP(hipStreamSynchronize(s));  // hd lives on this stack frame
+            cells_ok = true;
+        }
+    }
     // scratch: parent[n] | size[n] | id_of_root[n] | list[cap]
     const unsigned int cap = min_size > 0 ? n / min_size + 1 : n;
     PCC_TRY(ix->scratch_c.reserve((size_t)n * 4));
@@ -117,8 +203,13 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
     PCC_HIP(hipMemsetAsync(id_of_root, 0xff, (size_t)n * 4, s));
     PCC_HIP(hipMemsetAsync(d_count, 0, 4, s));
     PCC_HIP(hipMemsetAsync(labels_dev, 0xff, ix->n_orig * sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_uf_link, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), r, r2, parent);
+    if (cells_ok) {
+        hipLaunchKernelGGL(k_uf_link_cells, dim3((n + 255) / 256), dim3(256), 0, s, ix->vox_a.as<float4>(),
+                           ix->vox_c.as<unsigned int>(), ix->vox_b.as<GridDev>(), r2, parent);
+    } else {
+        hipLaunchKernelGGL(k_uf_link, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), r, r2, parent);
+    }
     hipLaunchKernelGGL(k_uf_flatten_count, dim3(g1(n)), dim3(256), 0, s, ix->refs.as<float4>(), parent, n, size);
     hipLaunchKernelGGL(k_uf_collect, dim3(g1(n)), dim3(256), 0, s, parent, size, n, min_size, max_size, list, d_count, cap);
     PCC_HIP(hipGetLastError());
