@@ -15,7 +15,7 @@ all: lib oracle hosttest cli
 
 lib: $(LIBDIR)/libpcc_nn.so
 oracle: oracle/_build/libpcc_oracle.so
-ubench: build/ubench_valu
+ubench: build/ubench_valu build/ubench_gather
 hosttest: build/test_host_mirror
 cli: build/comparator build/ply_dump
 
@@ -30,6 +30,10 @@ $(LIBDIR)/libpcc_nn.so: $(HIP_OBJS)
 oracle/_build/libpcc_oracle.so: oracle/pcc_oracle.c oracle/pcc_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread -o $@ oracle/pcc_oracle.c -lm
+
+build/ubench_gather: $(CSRC)/ubench_gather.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
 build/ubench_valu: $(CSRC)/ubench_valu.hip
 	@mkdir -p build
