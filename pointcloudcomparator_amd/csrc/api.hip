@@ -140,7 +140,7 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     ev_mark(ix, EV_BUILD0);
     PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
     int nblk = 0;
-    PCC_TRY(ix->seeds.reserve(((n + 63) / 64) * sizeof(float4)));  // the pack kernel also emits the seed subset
+    PCC_TRY(ix->seeds.reserve(((n + PCC_SEED_STRIDE - 1) / PCC_SEED_STRIDE) * sizeof(float4)));  // the pack kernel also emits the seed subset
     PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk,
                          nullptr, ix->seeds.as<float4>()));
     PCC_TRY(grid_params(ix, ix->blk_stats.as<float>(), nblk));

@@ -148,7 +148,7 @@ static inline int grid1d(size_t n) {
     return (int)b;
 }
 
-constexpr int SEED_STRIDE = 64;
+constexpr int SEED_STRIDE = PCC_SEED_STRIDE;
 constexpr int FAR_SPAN = 1024;
 
 // cell-sort the references (asynchronous; launch sizes come from n_orig and nc_cap)

@@ -56,7 +56,7 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
             ++bad;
         }
         out[i] = o;
-        if (STATS && seeds && (i & 63) == 0) seeds[i >> 6] = o;  // every 64th reference: upper bounds for far queries
+        if (STATS && seeds && (i & (PCC_SEED_STRIDE - 1)) == 0) seeds[i >> PCC_SEED_SHIFT] = o;  // upper bounds for far queries
     }
     if (STATS) {
         __shared__ float red[4][8];
