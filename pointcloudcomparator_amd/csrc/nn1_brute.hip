@@ -193,7 +193,9 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
         // GRID fallback list: the count lives on the device, usually tiny.  Fixed grid of
         // 2048 workgroups looping over (query block, split) items; many splits so that a
         // handful of queries still spreads over the whole chip.
-        size_t splits = m / (4 * BR_TILE);
+        // one tile per split: the list is usually short (the seed scan of an ICP pass: ~10k queries against
+        // 31k seeds was 154 items = 0.6 workgroups per CU with four tiles per split, 240 us)
+        size_t splits = (m + BR_TILE - 1) / BR_TILE;
         if (splits < 1) splits = 1;
         if (splits > 1024) splits = 1024;
         return launch_q<2>(s, refs, m, q, qcount_max, out, qlist, qcount_dev, (unsigned)splits, 2048, idx_from_w ? 1 : 0);
