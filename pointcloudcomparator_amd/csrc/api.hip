@@ -838,6 +838,11 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     int it = 0;
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
+    struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
+        pcc_index* ix;
+        explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; }
+        ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; }
+    } keep_order_guard(ix);
     while (it < max_iter) {
         PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
         double sums[17];

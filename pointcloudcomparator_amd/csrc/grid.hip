@@ -427,7 +427,16 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     if (!ix->fb_zeroed) PCC_HIP(hipMemsetAsync(fb_count, 0, 4, s));
     ix->fb_zeroed = false;
     unsigned int *order = nullptr, *n_sorted = nullptr;
-    PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
+    if (ix->keep_order && ix->order_valid && ix->order_nq == nq) {
+        order = ix->order_ptr;  // (any permutation of the valid queries is correct; this one is still coherent)
+        n_sorted = ix->order_nsorted;
+    } else {
+        PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
+        ix->order_valid = ix->keep_order;
+        ix->order_nq = nq;
+        ix->order_ptr = order;
+        ix->order_nsorted = n_sorted;
+    }
     ev_mark(ix, EV_MAIN0);
     static const int U = getenv("PCC_GRID_UNROLL") ? atoi(getenv("PCC_GRID_UNROLL")) : 4;
     const int BS = 256;

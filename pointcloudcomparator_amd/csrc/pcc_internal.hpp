@@ -92,6 +92,12 @@ struct pcc_index {
     pcc::DevBuf cell_start;  // uint32[ncells + 1]
     pcc::DevBuf seeds;       // float4[ceil(n / PCC_SEED_STRIDE)]: every 64th reference (w = its position; strides 32 / 128 / 256 measured 38.3 / 40.0 / 44.2 ms vs 38.0 on the ICP config) -- upper bounds for far queries
     bool fb_zeroed = false;  // the query pack kernel of this call already zeroed the fallback counter
+    // ICP moves the same source cloud rigidly from pass to pass: the lane order of its first pass keeps
+    // neighbouring lanes on neighbouring points, so later passes skip the query sort
+    bool keep_order = false, order_valid = false;
+    size_t order_nq = 0;
+    unsigned int* order_ptr = nullptr;
+    unsigned int* order_nsorted = nullptr;
     unsigned int last_fallback_seen = 0;  // fallback count of an earlier search (heuristic only, may be stale)
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
