@@ -119,3 +119,46 @@ def test_c4_icp_fixed_iterations_consistent_with_stepwise(gpu):
             Tacc = (Ti @ Tacc).astype(np.float32)
     assert it == 10 and conv
     assert np.allclose(T, Tacc, atol=5e-5)
+
+
+def test_1m_knn_normals_region_growing_against_the_sequential_walk(gpu):
+    """1M corridor points: the k-NN rows (sampled against the exhaustive oracle), the normals built on them and
+    the GPU's order-free region growing against PCL's sequential walk (oracle) over the same rows"""
+    n, k = 1_000_000, 20
+    pts = synth.corridor_cloud(n, synth.SEED_A)
+    with capi.Index(pts) as ix:
+        nbr, d2 = ix.knn(pts, k)
+        nrm = ix.normals(k)
+        labels, ncl = ix.region_growing(nrm, k=k, smoothness=8.0 / 180.0 * np.pi, curvature_threshold=1.0,
+                                        min_size=30, max_size=n)
+    # rows: sorted by (d2, idx), self first, and a sample equals the exhaustive oracle
+    assert (nbr[:, 0] == np.arange(n)).mean() > 0.9999 and (np.diff(d2.astype(np.float64), axis=1) >= 0).all()
+    sample = np.arange(0, n, 4001)
+    oi, od = oracle.knn_exhaustive(pts, pts[sample], k)
+    assert (oi == nbr[sample]).all() and (od.view(np.uint32) == d2[sample].view(np.uint32)).all()
+    # normals: same arithmetic as the oracle on the same rows (tolerance of DESIGN 4.6)
+    want = oracle.normals(pts, k, neighbours=nbr)
+    same = (nrm.view(np.uint32) == want.view(np.uint32)).all(axis=1) | (np.isnan(nrm).all(axis=1) & np.isnan(want).all(axis=1))
+    assert same.mean() > 0.9
+    ok = np.isfinite(nrm).all(axis=1) & np.isfinite(want).all(axis=1)
+    dots = np.abs((nrm[ok, :3].astype(np.float64) * want[ok, :3]).sum(1))
+    assert (dots > 1 - 1e-5).all()
+    assert (nrm[ok, 3] >= 0).all() and (nrm[ok, 3] <= 1 / 3 + 1e-6).all()
+    # region growing: label for label
+    want_labels, want_n = oracle.region_growing(nrm, nbr, 8.0 / 180.0 * np.pi, 1.0, 30, n)
+    assert ncl == want_n and (labels == want_labels).all()
+    assert ncl > 10
+
+
+def test_2m_ransac_plane_against_the_restatement(gpu):
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    plane = np.stack([rng.random(n // 2) * 20 - 5, rng.random(n // 2) * 20 - 5, 0.3 + rng.normal(0, 0.006, n // 2)], 1)
+    rest = rng.random((n - n // 2, 3)) * [20, 20, 3] - [5, 5, 0]
+    pts = np.ascontiguousarray(np.concatenate([plane, rest]).astype(np.float32)[rng.permutation(n)])
+    with capi.Index(pts[:1]) as ctx:
+        inl, coeff, its = ctx.sac_plane(pts)
+    w_inl, w_c, w_its = oracle.sac_plane(pts)
+    assert its == w_its and (coeff.view(np.uint32) == w_c.view(np.uint32)).all()
+    assert len(inl) == len(w_inl) and (inl == w_inl).all()
+    assert len(inl) > 0.49 * n
