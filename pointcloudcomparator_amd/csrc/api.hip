@@ -527,7 +527,8 @@ int pcc_normals(pcc_index* ix, int k, const float viewpoint[3], int mem, float* 
     PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, keys));
     float4* dout = reinterpret_cast<float4*>(out);
     if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_d2.reserve(n * sizeof(float4))); dout = ix->out_d2.as<float4>(); }
-    PCC_TRY(launch_normals(ix->stream, keys, ix->refs.as<float4>(), n, k, viewpoint ? viewpoint : origin, dout));
+    PCC_TRY(launch_normals(ix->stream, keys, ix->refs.as<float4>(), ix->cell_refs.as<float4>(), ix->d_grid.as<GridDev>(), n, k,
+                           viewpoint ? viewpoint : origin, dout));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, reinterpret_cast<const float*>(dout), out, n * 4, mem));
