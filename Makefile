@@ -16,10 +16,10 @@ all: lib oracle hosttest cli
 lib: $(LIBDIR)/libpcc_nn.so
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu build/ubench_gather
-hosttest: build/test_host_mirror
+hosttest: build/test_host_mirror build/test_lane_ops
 cli: build/comparator build/ply_dump
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp include/pcc_nn.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp include/pcc_nn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 
@@ -38,6 +38,10 @@ build/ubench_gather: $(CSRC)/ubench_gather.hip
 build/ubench_valu: $(CSRC)/ubench_valu.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
+build/test_lane_ops: tests/cpp/test_lane_ops.hip $(CSRC)/lane_ops.hpp
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -I$(CSRC) $< -o $@
 
 build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build

@@ -13,6 +13,7 @@
 // the list is full almost every candidate costs one compare.
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
+#include "lane_ops.hpp"
 #include <cmath>
 #include <cstring>
 
@@ -107,18 +108,14 @@ k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
 // min(L[i], B[63-i]) half-cleaner followed by a 6-stage bitonic merge; tau tightens and after the
 // first few batches almost every candidate dies at the compare.  The per-lane list kernel below
 // did O(K) global-memory traffic per insertion: 90 ms for 1M points at k = 51.
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-    const unsigned int lo = __shfl_xor((unsigned int)v, m, 64);
-    const unsigned int hi = __shfl_xor((unsigned int)(v >> 32), m, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
+// value of lane `src`; src must be wave-uniform (v_readlane_b32)
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
-    const unsigned int lo = __shfl((unsigned int)v, src, 64);
-    const unsigned int hi = __shfl((unsigned int)(v >> 32), src, 64);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), src);
     return ((unsigned long long)hi << 32) | lo;
 }
-__device__ __forceinline__ unsigned long long cmpx(unsigned long long v, int m, bool take_min) {
-    const unsigned long long o = shfl_xor_u64(v, m);
+__device__ __forceinline__ unsigned long long cmpx(unsigned long long v, int m, bool take_min, unsigned int lane) {
+    const unsigned long long o = xor_lane_u64(v, m, lane);
     const bool o_less = o < v;
     return (o_less == take_min) ? o : v;
 }
@@ -128,26 +125,26 @@ __device__ __forceinline__ unsigned long long bitonic_sort64(unsigned long long 
 #pragma unroll
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             const bool up = (lane & k2) == 0, lower = (lane & j) == 0;
-            v = cmpx(v, j, lower == up);
+            v = cmpx(v, j, lower == up, lane);
         }
     return v;  // ascending over the lanes
 }
 __device__ __forceinline__ unsigned long long bitonic_merge64(unsigned long long v, unsigned int lane) {
 #pragma unroll
-    for (int j = 32; j > 0; j >>= 1) v = cmpx(v, j, (lane & j) == 0);
+    for (int j = 32; j > 0; j >>= 1) v = cmpx(v, j, (lane & j) == 0, lane);
     return v;  // bitonic in -> ascending out
 }
 
 template <int KR>
 __device__ __forceinline__ void topk_merge(unsigned long long (&top)[KR], unsigned long long batch, unsigned int lane) {
     batch = bitonic_sort64(batch, lane);
-    unsigned long long rev = shfl_u64(batch, 63 - (int)lane);
+    unsigned long long rev = reverse_lanes_u64(batch, lane);
     unsigned long long lo = rev < top[0] ? rev : top[0];
     unsigned long long hi = rev < top[0] ? top[0] : rev;
     top[0] = bitonic_merge64(lo, lane);
     if (KR > 1) {
         hi = bitonic_merge64(hi, lane);
-        rev = shfl_u64(hi, 63 - (int)lane);
+        rev = reverse_lanes_u64(hi, lane);
         lo = rev < top[KR - 1] ? rev : top[KR - 1];
         top[KR - 1] = bitonic_merge64(lo, lane);
     }
@@ -197,7 +194,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 const unsigned int row = ((unsigned int)(z0 + r / ny) * g.dim[1] + (y0 + r % ny)) * g.dim[0];
                 cnt += cell_start[row + x1 + 1] - cell_start[row + x0];
             }
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(cnt), 63);
             if (cnt >= (unsigned int)want || k >= GRID_KMAX) break;
         }
         unsigned long long top[KR];
@@ -265,12 +262,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                             cnt = cell_start[row + b + 1] - s0;
                         }
                     }
-                    unsigned int incl = cnt;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const unsigned int tt = __shfl_up(incl, off, 64);
-                        if (lane >= (unsigned int)off) incl += tt;
-                    }
+                    const unsigned int incl = wave_incl_scan_add(cnt);
                     const unsigned long long occ = __ballot(cnt != 0);
                     if (cnt) {
                         const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
@@ -278,7 +270,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                         tab_o[slot] = total + incl - cnt;
                     }
                     nspans += (unsigned int)__popcll(occ);
-                    total += __shfl(incl, 63, 64);
+                    total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
                 }
                 __builtin_amdgcn_wave_barrier();
                 unsigned int next_span = 0, carry_span = 0;  // wave-uniform
@@ -290,14 +282,9 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                     if (starts) win[tab_o[r] - B] = r + 1;
                     next_span += (unsigned int)__popcll(__ballot(starts));
                     __builtin_amdgcn_wave_barrier();
-                    unsigned int v = win[lane];
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const unsigned int tt = __shfl_up(v, off, 64);
-                        if (lane >= (unsigned int)off) v = max(v, tt);
-                    }
+                    unsigned int v = wave_incl_scan_max(win[lane]);
                     v = max(v, carry_span);
-                    carry_span = __shfl(v, 63, 64);
+                    carry_span = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
                     const unsigned int c = B + lane;
                     unsigned long long key = ~0ull;
                     if (c < total) {
