@@ -17,6 +17,7 @@
 // resolved by the explicit (d2, position) key.
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
+#include "lane_ops.hpp"
 
 namespace pcc {
 
@@ -100,11 +101,7 @@ k_cs_scatter(unsigned int n, unsigned int F, unsigned int slice, const uint2* __
 // pass 3 ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned int block_excl_scan_256(unsigned int v, unsigned int* wsum /* 4 LDS words */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
+    const unsigned int inc = wave_incl_scan_add(v);  // DPP, no LDS crossbar
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     unsigned int base = 0;

@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "pcc_internal.hpp"
+#include "lane_ops.hpp"
 
 namespace pcc {
 
@@ -119,11 +120,7 @@ __device__ __forceinline__ unsigned int block_exclusive_scan(unsigned int v, uns
     // exclusive scan of one value per thread over a 256-thread workgroup
     __shared__ unsigned int wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
+    const unsigned int inc = wave_incl_scan_add(v);  // DPP, no LDS crossbar
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     unsigned int base = 0;
