@@ -43,6 +43,27 @@ void DevBuf::release() {
     cap = 0;
 }
 
+int HostBuf::reserve(size_t bytes) {
+    if (bytes <= cap && p) return PCC_OK;
+    if (bytes == 0) bytes = 256;
+    size_t want = bytes + bytes / 8;
+    want = (want + 4095) & ~(size_t)4095;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return PCC_ERR_NOMEM;
+    }
+    cap = want;
+    return PCC_OK;
+}
+void HostBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -179,6 +200,8 @@ int pcc_index_destroy(pcc_index* ix) {
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
             if (ix->ev[sl][k]) (void)hipEventDestroy(ix->ev[sl][k]);
+    ix->host_a.release();
+    ix->host_b.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     if (ix->h_grid) (void)hipHostFree(ix->h_grid);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
@@ -635,29 +658,31 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     PCC_HIP(hipMemsetAsync(dmean, 0, no * sizeof(float), ix->stream));
     PCC_TRY(launch_sor_mean(ix->stream, keys, ix->refs.as<float4>(), n, K, dmean));
     ev_mark(ix, EV_CALL1);
-    std::vector<float> hm(no);
-    PCC_HIP(hipMemcpyAsync(hm.data(), dmean, no * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCC_TRY(ix->host_a.reserve(no * sizeof(float)));
+    PCC_TRY(ix->host_b.reserve(no));
+    float* hm = ix->host_a.as<float>();
+    uint8_t* hin = ix->host_b.as<uint8_t>();
+    PCC_HIP(hipMemcpyAsync(hm, dmean, no * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     PCC_HIP(hipStreamSynchronize(ix->stream));
     // PCL: sum / sq_sum over ALL entries in index order (double), valid = points with a full
     // neighbourhood.  Invalid points and points without k neighbours contribute 0.
     PCC_TRY(sync_info(ix));
     size_t valid = ix->n_valid >= (size_t)K ? ix->n_valid : 0;
     double sum = 0, sq = 0;
-    for (size_t i = 0; i < no; ++i) { sum += hm[i]; sq += (double)hm[i] * hm[i]; }
+    for (size_t i = 0; i < no; ++i) { const double d = hm[i]; sum += d; sq += d * d; }
     double mean = sum / (double)valid;
     double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
     double thr = mean + stddev_mult * std::sqrt(var);
-    std::vector<uint8_t> hin(no);
     size_t k_in = 0;
     for (size_t i = 0; i < no; ++i) { hin[i] = !(hm[i] > thr); k_in += hin[i]; }
     if (threshold) *threshold = thr;
     if (kept) *kept = k_in;
     if (mem == PCC_MEM_HOST) {
-        if (mean_dist) memcpy(mean_dist, hm.data(), no * sizeof(float));
-        if (inlier) memcpy(inlier, hin.data(), no);
+        if (mean_dist) memcpy(mean_dist, hm, no * sizeof(float));
+        if (inlier) memcpy(inlier, hin, no);
     } else {
         if (mean_dist) PCC_HIP(hipMemcpyAsync(mean_dist, dmean, no * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
-        if (inlier) PCC_HIP(hipMemcpyAsync(inlier, hin.data(), no, hipMemcpyHostToDevice, ix->stream));
+        if (inlier) PCC_HIP(hipMemcpyAsync(inlier, hin, no, hipMemcpyHostToDevice, ix->stream));
         PCC_HIP(hipStreamSynchronize(ix->stream));
     }
     return PCC_OK;

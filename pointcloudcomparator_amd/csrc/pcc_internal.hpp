@@ -38,6 +38,15 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// grow-only pinned host buffer (read-backs that the host then walks: SOR mean distances, ...)
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // Uniform-grid parameters (device + host copy).  Cell of a point:
 //   c_a = clamp(int((p_a - org_a) * inv_h), 0, dim_a - 1)
 // The same expression (same rounding) is used at build and query time.
@@ -103,6 +112,7 @@ struct pcc_index {
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
         scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, vox_a, vox_b, vox_c;
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
+    pcc::HostBuf host_a, host_b;  // large pinned read-back buffers
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
     // ring of PCC_EV_SLOTS calls so a timed region of many steps is covered without syncing
