@@ -32,9 +32,7 @@ struct CsPlan {
 };
 static CsPlan cs_plan(unsigned int ncells, unsigned int n) {
     CsPlan p;
-    static const unsigned int buckets = getenv("PCC_CS_BUCKETS") ? (unsigned int)atoi(getenv("PCC_CS_BUCKETS")) : CS_BUCKETS;
-    static const unsigned int max_f = getenv("PCC_CS_MAXF") ? (unsigned int)atoi(getenv("PCC_CS_MAXF")) : CS_MAX_F;
-    static const unsigned int max_g = getenv("PCC_CS_MAXG") ? (unsigned int)atoi(getenv("PCC_CS_MAXG")) : CS_MAX_G;
+    const unsigned int buckets = CS_BUCKETS, max_f = CS_MAX_F, max_g = CS_MAX_G;
     p.F = (ncells + buckets - 1) / buckets;
     if (p.F < 64) p.F = 64;
     if (p.F > max_f) p.F = max_f;

@@ -219,7 +219,7 @@ __device__ __forceinline__ unsigned long long scan_box(const float4* __restrict_
     return best;
 }
 
-template <int U, bool SEED_ROW>
+template <int U>
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
            const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
@@ -240,17 +240,9 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
-    // ---- phase 0 (SEED_ROW): only the query's own row segment [cx-1, cx+1].  In dense regions it
-    // almost always yields a close candidate, and the ball around it (phase 2) then touches 1-4
-    // short rows instead of the nine rows of the full 3x3x3 cube: ~4x fewer distance evaluations.
-    if (SEED_ROW) {
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-        const unsigned int row = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0];
-        best = scan_span<U>(cell_refs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best);
-    }
     // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (18 independent loads, one
     // latency), then the rows are streamed.
-    if (!SEED_ROW || best == ~0ull) {
+    {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
         unsigned int rs[9], re[9];
 #pragma unroll
@@ -438,24 +430,11 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
         ix->order_nsorted = n_sorted;
     }
     ev_mark(ix, EV_MAIN0);
-    static const int U = getenv("PCC_GRID_UNROLL") ? atoi(getenv("PCC_GRID_UNROLL")) : 4;
     const int BS = 256;
-    // row seeding (phase 0) measured slower than going straight to the cube once tail loads are
-    // predicated (151 vs 142 us at 1M x 1M); kept selectable for experiments
-    static const bool seed_row = getenv("PCC_GRID_SEED") && !strcmp(getenv("PCC_GRID_SEED"), "row");
-#define PCC_LAUNCH_NN1(UU)                                                                                       \
-    do { if (seed_row)                                                                                           \
-    hipLaunchKernelGGL((k_grid_nn1<UU, true>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(), \
-                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,   \
-                       fb_list, fb_count);                                                                        \
-    else                                                                                                         \
-    hipLaunchKernelGGL((k_grid_nn1<UU, false>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(), \
-                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,   \
-                       fb_list, fb_count); } while (0)
-    if (U == 1) PCC_LAUNCH_NN1(1);
-    else if (U == 2) PCC_LAUNCH_NN1(2);
-    else if (U == 8) PCC_LAUNCH_NN1(8);
-    else PCC_LAUNCH_NN1(4);
+    // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
+    hipLaunchKernelGGL((k_grid_nn1<4>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,
+                       fb_list, fb_count);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     // queries the cell walk could not resolve.  When an earlier search on this index had such

@@ -370,8 +370,7 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
-    static const bool lane_knn = getenv("PCC_KNN") && !strcmp(getenv("PCC_KNN"), "lane");
-    if (K <= 128 && !lane_knn) {
+    if (K <= 128) {
         unsigned int gw = (n + 3) / 4;  // one wave per query, 4 waves per workgroup, waves loop
         if (gw > 8192) gw = 8192;
         if (K <= 64)

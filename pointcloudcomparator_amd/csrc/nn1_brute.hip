@@ -188,7 +188,6 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
     size_t nq = qlist ? qcount_max : n;
     if (nq == 0 || m == 0) return PCC_OK;
     if (m >= (1ull << 31) || n >= (1ull << 32)) { set_error("cloud too large for 32-bit indices"); return PCC_ERR_UNSUPPORTED; }
-    const char* env = getenv("PCC_BRUTE_Q");
     if (qlist) {
         // GRID fallback list: the count lives on the device, usually tiny.  Fixed grid of
         // 2048 workgroups looping over (query block, split) items; many splits so that a
@@ -202,8 +201,7 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
     }
     // queries per lane: as many as still leave >= 1024 workgroups (4 per CU) in flight
     int Q = 1;
-    if (env) Q = atoi(env);
-    else if (nq >= (size_t)BR_T * 8 * 1024) Q = 8;
+    if (nq >= (size_t)BR_T * 8 * 1024) Q = 8;
     else if (nq >= (size_t)BR_T * 4 * 512) Q = 4;
     else if (nq >= (size_t)BR_T * 2 * 256) Q = 2;
     size_t qblocks = (nq + (size_t)BR_T * Q - 1) / ((size_t)BR_T * Q);
