@@ -210,3 +210,29 @@ def test_voxel_grid_refuses_absurd_leaf(gpu):
         with pytest.raises(capi.PccError) as e:
             ctx.voxel_grid(pts, 1e-4)
     assert e.value.status == -5
+
+
+def test_sorted_radius_rows_of_every_length_class(gpu):
+    """rows of 1..64, 65..128, 129..256, 257..512 entries (one wave sorts them in 1, 2, 4, 8 registers per lane)
+    and longer ones (in-place fallback), with duplicated distances: order must be (d2, index) everywhere"""
+    rng = np.random.default_rng(17)
+    # blobs of very different densities around the query points
+    centres = rng.random((40, 3)).astype(np.float32) * 4
+    sizes = rng.integers(5, 900, 40)
+    pts = np.concatenate([c + rng.normal(0, 0.02, (s, 3)) for c, s in zip(centres, sizes)]).astype(np.float32)
+    pts = np.ascontiguousarray(np.round(pts, 2))  # 1 cm lattice: many equal distances, ties decided by the index
+    pts = np.ascontiguousarray(pts[rng.permutation(len(pts))])
+    q = np.ascontiguousarray(np.round(centres, 2))
+    with capi.Index(pts) as ix:
+        offs, idx, d2 = ix.radius_search(q, 0.08, sorted=True)
+    lens = np.diff(offs)
+    assert lens.max() > 512 and ((lens > 64) & (lens <= 128)).any() and ((lens > 128) & (lens <= 512)).any()
+    for i in range(len(q)):
+        s, e = offs[i], offs[i + 1]
+        dd = ((pts - q[i]) ** 2).astype(np.float32)
+        want_d2 = (dd[:, 0] + dd[:, 1]) + dd[:, 2]
+        inside = np.nonzero(want_d2 < np.float32(0.08 * 0.08))[0]
+        order = np.lexsort((inside, want_d2[inside]))
+        assert e - s == len(inside)
+        assert (idx[s:e] == inside[order]).all()
+        assert (_bits(d2[s:e]) == _bits(want_d2[inside][order])).all()
