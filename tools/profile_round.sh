@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01h
+O=gpurun_out/r01h   # remove a previous local gpurun_out/r01h first: gpurun merges, it does not replace
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1 && tail -2 $O/gpu_tests.log
 python bench.py --steps 20 --warmup 3 > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
