@@ -42,6 +42,23 @@ def test_argument_validation_needs_no_gpu():
     assert L.pcc_index_create(None, 4, 12, 3, 0, 0, 0, ctypes.byref(h)) == -1              # null points
     assert b"empty input cloud" in L.pcc_last_error() or b"null" in L.pcc_last_error()
     assert L.pcc_nn1(None, pts.ctypes.data, 4, 12, 0, None, None) == -1                     # null index
+    # every entry point refuses a null handle before touching anything else
+    out = np.zeros(64, np.float32)
+    cnt = ctypes.c_size_t(0)
+    n32 = ctypes.c_int32(0)
+    P = pts.ctypes.data
+    assert L.pcc_knn(None, P, 4, 12, 0, 1, None, None) == -1
+    assert L.pcc_radius_count(None, P, 4, 12, 0, ctypes.c_double(0.1), out.ctypes.data) == -1
+    assert L.pcc_euclidean_clusters(None, ctypes.c_double(0.1), 1, 10, 0, out.ctypes.data, ctypes.byref(n32), None, 0) == -1
+    assert L.pcc_sor(None, 5, ctypes.c_double(1.0), 0, None, None, None, None) == -1
+    assert L.pcc_first_within(None, P, 4, 12, 0, ctypes.c_double(0.1), out.ctypes.data) == -1
+    assert L.pcc_voxel_grid(None, P, 4, 12, 0, ctypes.c_float(0.1), 0, out.ctypes.data, 12, ctypes.byref(cnt)) == -1
+    assert L.pcc_normals(None, 5, None, 0, out.ctypes.data) == -1
+    assert L.pcc_region_growing(None, out.ctypes.data, 0, 5, ctypes.c_float(0.1), ctypes.c_float(1.0), 1, 10,
+                                out.ctypes.data, ctypes.byref(n32)) == -1
+    assert L.pcc_sac_plane(None, P, 4, 12, 0, 10, ctypes.c_double(0.02), ctypes.c_double(0.99), 1, out.ctypes.data,
+                           ctypes.byref(cnt), out.ctypes.data, None) == -1
+    assert L.pcc_index_destroy(None) == 0                                                    # like free(NULL)
 
 
 def test_no_cpu_fallback_without_device():

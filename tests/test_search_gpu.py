@@ -236,3 +236,41 @@ def test_sorted_radius_rows_of_every_length_class(gpu):
         assert e - s == len(inside)
         assert (idx[s:e] == inside[order]).all()
         assert (_bits(d2[s:e]) == _bits(want_d2[inside][order])).all()
+
+
+def test_bad_arguments_are_refused_with_a_message(gpu):
+    """error behaviour of the widened entry points on a live handle: PCC_ERR_INVALID (-1) / UNSUPPORTED (-5),
+    never a crash, and pcc_last_error() says why"""
+    import ctypes as C
+    pts = _scene(5000)
+    L = capi.LIB
+    with capi.Index(pts) as ix:
+        h = ix._h
+        out = np.zeros(4 * len(pts), np.float32)
+        lab = np.zeros(len(pts), np.int32)
+        n32, cnt = C.c_int32(0), C.c_size_t(0)
+        cases = [
+            (L.pcc_knn(h, pts.ctypes.data, 10, 12, 0, 0, lab.ctypes.data, out.ctypes.data), -5),              # k = 0
+            (L.pcc_knn(h, pts.ctypes.data, 10, 12, 0, 1 << 20, lab.ctypes.data, out.ctypes.data), -5),        # k too large
+            (L.pcc_knn(h, pts.ctypes.data, 10, 10, 0, 3, lab.ctypes.data, out.ctypes.data), -1),              # stride
+            (L.pcc_radius_count(h, pts.ctypes.data, 10, 12, 0, C.c_double(-1.0), lab.ctypes.data), -1),       # negative radius
+            (L.pcc_radius_count(h, pts.ctypes.data, 10, 12, 7, C.c_double(0.1), lab.ctypes.data), -1),        # memory space
+            (L.pcc_normals(h, 0, None, 0, out.ctypes.data), -5),
+            (L.pcc_normals(h, 10, None, 0, None), -1),
+            (L.pcc_region_growing(h, None, 0, 10, C.c_float(0.1), C.c_float(1.0), 1, 10, lab.ctypes.data, C.byref(n32)), -1),
+            (L.pcc_region_growing(h, out.ctypes.data, 0, 0, C.c_float(0.1), C.c_float(1.0), 1, 10, lab.ctypes.data, C.byref(n32)), -5),
+            (L.pcc_sac_plane(h, pts.ctypes.data, 100, 12, 0, 10, C.c_double(0.02), C.c_double(1.5), 1, lab.ctypes.data,
+                             C.byref(cnt), out.ctypes.data, None), -1),                                            # probability
+            (L.pcc_sac_plane(h, pts.ctypes.data, 100, 12, 0, 10, C.c_double(0.02), C.c_double(0.99), 1, None,
+                             C.byref(cnt), out.ctypes.data, None), -1),                                            # null inliers
+            (L.pcc_voxel_grid(h, pts.ctypes.data, 100, 12, 0, C.c_float(0.0), 0, out.ctypes.data, 12, C.byref(cnt)), -1),
+            (L.pcc_voxel_grid(h, pts.ctypes.data, 100, 12, 0, C.c_float(0.1), 1, out.ctypes.data, 12, C.byref(cnt)), -1),  # rgb needs 20 B
+            (L.pcc_first_within(h, pts.ctypes.data, 10, 12, 0, C.c_double(float("nan")), lab.ctypes.data), -1),
+            (L.pcc_sor(h, 0, C.c_double(1.0), 0, None, None, None, None), -5),
+        ]
+        for i, (got, want) in enumerate(cases):
+            assert got == want, (i, got, want)
+        assert len(L.pcc_last_error()) > 0
+        # the handle is still usable afterwards
+        idx, d2 = ix.nn1(pts[:10])
+        assert (idx == np.arange(10)).all() and (d2 == 0).all()
