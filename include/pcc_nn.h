@@ -216,9 +216,9 @@ int pcc_sac_plane(pcc_index *ctx, const void *pts, size_t n, size_t stride_bytes
  *   (PCL: findPointNeighbours, one nearestKSearch per point).  The result is PCL's: seeds by
  *   ascending curvature, breadth first through the rows while |n_current . n_neighbour| >=
  *   cos(smoothness), a neighbour continues the walk when its curvature is <= curvature_threshold.
- *   When every point passes that curvature test (the reference's setting) the regions are computed
- *   on the GPU in an equivalent order-free form (lowest-ranked ancestor over the valid-edge graph);
- *   otherwise PCL's sequential walk runs on the host over the GPU rows.
+ *   The regions are computed on the GPU in an equivalent order-free form: the label of a point is the
+ *   lowest-ranked (curvature, index) point that reaches it along valid edges, where a point above the
+ *   curvature threshold passes labels on only if it is a seed itself (region.hip).
  * normals[n][4] as pcc_normals writes them (memory space `mem`); labels[n] (memory space `mem`):
  *   index of the kept cluster, in PCL's output order (creation order), or -1;
  *   *n_clusters (host) = clusters.size().  Equal curvatures are taken in index order (PCL:

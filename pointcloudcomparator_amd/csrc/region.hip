@@ -24,8 +24,12 @@
 //             after the first sweep, so later sweeps are short)
 //   count / collect / label : region sizes, size filter, ids in PCL's creation order (= rank of
 //             the seed), labels
-// When some point would not spread (a curvature threshold below the data's curvatures) the growth
-// is order dependent; that case runs PCL's sequential walk on the host over the same GPU rows.
+// When some points would NOT spread (curvature above the threshold) the rule gains one condition: such a
+// point u passes its label on only if it is a seed itself (label(u) == rank(u); PCL pushes the seed of a
+// region on the queue unconditionally).  "Is a seed" depends on lower-ranked points only, so the labels are
+// still well defined; they are computed by repeating  label_new = min(own component's lowest rank, labels
+// pushed along the edges that are active under label_old)  from scratch until nothing changes (the in-place
+// minimum above would keep a label pushed by a point that turns out not to be a seed).
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -86,12 +90,13 @@ k_rg_prepare(const unsigned long long* __restrict__ keys, const float4* __restri
 __global__ void __launch_bounds__(256)
 k_rg_link(const unsigned long long* __restrict__ keys, const float4* __restrict__ normals,
           const unsigned long long* __restrict__ kth, const float4* __restrict__ cell_refs,
-          const GridDev* __restrict__ gd, int K, float cos_thr, unsigned int* __restrict__ parent) {
+          const GridDev* __restrict__ gd, int K, float cos_thr, float curv_thr, unsigned int* __restrict__ parent) {
     const unsigned int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned int lane = threadIdx.x & 63;
     if (w >= gd->n_valid) return;
     const unsigned int u = (unsigned int)__float_as_int(cell_refs[w].w);
     const float4 nu = normals[u];
+    if (nu.w > curv_thr) return;  // u does not spread: it shares nobody's label by construction
     const unsigned long long* row = keys + (size_t)u * K;
     for (int base = 0; base < K; base += 64) {
         const int j = base + (int)lane;
@@ -99,7 +104,8 @@ k_rg_link(const unsigned long long* __restrict__ keys, const float4* __restrict_
         if (key == ~0ull) continue;
         const unsigned int v = (unsigned int)key;
         if (v >= u) continue;  // every mutual pair is seen from both ends: the higher one links
-        if (!smooth_edge(nu, normals[v], cos_thr)) continue;
+        const float4 nv = normals[v];
+        if (nv.w > curv_thr || !smooth_edge(nu, nv, cos_thr)) continue;
         const unsigned long long mine = (key & 0xffffffff00000000ull) | u;  // u's key in v's ordering
         if (mine <= kth[v]) uf_union(parent, u, v);
     }
@@ -151,6 +157,53 @@ k_rg_sweep(const unsigned long long* __restrict__ keys, const float4* __restrict
     if (__ballot(moved) != 0ull && lane == 0) atomicOr(changed, 1u);
 }
 
+// general case (some points do not spread): one Jacobi step.  label_new was preset to the components' own lowest
+// ranks; every point whose edges are active under label_old pushes label_old of its component across its valid
+// edges into other components.
+template <bool FIRST>
+__global__ void __launch_bounds__(256)
+k_rg_sweep_general(const unsigned long long* __restrict__ keys, const float4* __restrict__ normals,
+                   const float4* __restrict__ cell_refs, const GridDev* __restrict__ gd, int K, float cos_thr, float curv_thr,
+                   const unsigned int* __restrict__ parent, const unsigned long long* __restrict__ label_old,
+                   unsigned long long* __restrict__ label_new, unsigned char* __restrict__ has_cross) {
+    const unsigned int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned int lane = threadIdx.x & 63;
+    if (w >= gd->n_valid) return;
+    const unsigned int u = (unsigned int)__float_as_int(cell_refs[w].w);
+    if (!FIRST && !has_cross[u]) return;
+    const float4 nu = normals[u];
+    const unsigned int ru = parent[u];
+    const unsigned long long lu = label_old[ru];
+    // a point that does not spread is a component of its own; it acts only while nobody has claimed it
+    const bool active = !(nu.w > curv_thr) || lu == rank_key(nu.w, u);
+    if (!FIRST && !active) return;
+    const unsigned long long* row = keys + (size_t)u * K;
+    bool cross = false;
+    for (int base = 0; base < K; base += 64) {
+        const int j = base + (int)lane;
+        const unsigned long long key = j < K ? row[j] : ~0ull;
+        if (key == ~0ull) continue;
+        const unsigned int v = (unsigned int)key;
+        const unsigned int rv = parent[v];
+        if (rv == ru) continue;
+        if (!smooth_edge(nu, normals[v], cos_thr)) continue;
+        cross = true;
+        if (active) atomicMin(&label_new[rv], lu);
+    }
+    if (FIRST) {
+        const bool any_cross = __ballot(cross) != 0ull;
+        if (lane == 0 && any_cross) has_cross[u] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_rg_diff(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, unsigned int n,
+          unsigned int* __restrict__ changed) {
+    bool d = false;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d |= a[i] != b[i];
+    if (__syncthreads_or(d) && threadIdx.x == 0) atomicOr(changed, 1u);
+}
+
 // parent[i] becomes the seed of i's region; sizes are counted per seed
 __global__ void __launch_bounds__(256)
 k_rg_count(const unsigned long long* __restrict__ comp_label, unsigned int n, unsigned int* __restrict__ parent,
@@ -192,61 +245,6 @@ inline int g1(size_t n) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-// pcl::RegionGrowing::extract over precomputed neighbour rows (host side of pcc_region_growing).
-// Regions are grown in PCL's order: seeds by ascending curvature (ties: lower index), each region
-// a breadth-first walk of the neighbour rows; a neighbour joins when |n_cur . n_nbr| >= cos(theta)
-// and continues the walk when its curvature is not above the threshold.
-int region_growing_host(size_t n, const float* normals4, const int32_t* nbr, int K, float smoothness,
-                        float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels,
-                        int32_t* n_clusters) {
-    std::vector<int32_t> seg(n, -1), order(n), queue(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
-    // NaN curvatures (points without a normal) go last; PCL's std::sort leaves them unspecified
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        const float ca = normals4[(size_t)a * 4 + 3], cb = normals4[(size_t)b * 4 + 3];
-        const bool na = ca != ca, nb = cb != cb;
-        if (na != nb) return nb;
-        if (!na && ca != cb) return ca < cb;
-        return a < b;
-    });
-    std::vector<uint32_t> seg_size;
-    const float cosine_threshold = cosf(smoothness);
-    size_t segmented = 0, seed_pos = 0;
-    while (segmented < n) {
-        while (seg[order[seed_pos]] != -1) ++seed_pos;
-        const int32_t id = (int32_t)seg_size.size();
-        size_t qh = 0, qt = 0;
-        queue[qt++] = order[seed_pos];
-        seg[order[seed_pos]] = id;
-        uint32_t cnt = 1;
-        while (qh < qt) {
-            const int32_t cur = queue[qh++];
-            const float* nc = normals4 + (size_t)cur * 4;
-            const int32_t* row = nbr + (size_t)cur * K;
-            for (int j = 0; j < K; ++j) {
-                const int32_t t = row[j];
-                if (t < 0) break;
-                if (seg[t] != -1) continue;
-                const float* nn = normals4 + (size_t)t * 4;
-                const float dot = fabsf(nn[0] * nc[0] + nn[1] * nc[1] + nn[2] * nc[2]);
-                if (dot < cosine_threshold) continue;
-                seg[t] = id;
-                ++cnt;
-                if (!(nn[3] > curvature_threshold)) queue[qt++] = t;
-            }
-        }
-        seg_size.push_back(cnt);
-        segmented += cnt;
-    }
-    std::vector<int32_t> remap(seg_size.size());
-    int32_t kept = 0;
-    for (size_t s = 0; s < seg_size.size(); ++s) remap[s] = (seg_size[s] >= min_size && seg_size[s] <= max_size) ? kept++ : -1;
-    for (size_t i = 0; i < n; ++i) labels[i] = remap[seg[i]];
-    *n_clusters = kept;
-    return PCC_OK;
-}
-
-
 }  // namespace
 
 // keys: the self k-NN rows of the index (n x K); normals: float4 (nx, ny, nz, curvature) on the device
@@ -280,27 +278,39 @@ int grid_region_growing(pcc_index* ix, const unsigned long long* keys, const flo
     PCC_HIP(hipGetLastError());
     PCC_HIP(hipMemcpyAsync(h, d_words, 4, hipMemcpyDeviceToHost, s));
     PCC_HIP(hipStreamSynchronize(s));
-    if (h[0] != 0) {
-        // some point would join a region without spreading: PCL's sequential walk, same rows
-        PCC_TRY(ix->out_idx.reserve((size_t)n * K * sizeof(int32_t)));
-        PCC_TRY(launch_unpack(s, keys, nullptr, (size_t)n * K, ix->out_idx.as<int32_t>(), nullptr));
-        std::vector<int32_t> nbr((size_t)n * K), hl(n);
-        std::vector<float> hn((size_t)n * 4);
-        PCC_HIP(hipMemcpyAsync(nbr.data(), ix->out_idx.p, nbr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        PCC_HIP(hipMemcpyAsync(hn.data(), normals, hn.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-        PCC_HIP(hipStreamSynchronize(s));
-        PCC_TRY(region_growing_host(n, hn.data(), nbr.data(), K, smoothness, curvature_threshold, min_size, max_size,
-                                    hl.data(), n_clusters));
-        PCC_HIP(hipMemcpyAsync(labels_dev, hl.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        PCC_HIP(hipStreamSynchronize(s));
-        ev_mark(ix, EV_MAIN1);
-        return PCC_OK;
-    }
+    const bool general = h[0] != 0;  // some point would join a region without spreading
     const unsigned int wave_blocks = (n + 3) / 4;
     hipLaunchKernelGGL(k_rg_link, dim3(wave_blocks), dim3(256), 0, s, keys, normals, kth, ix->cell_refs.as<float4>(),
-                       ix->d_grid.as<GridDev>(), K, cos_thr, parent);
+                       ix->d_grid.as<GridDev>(), K, cos_thr, curvature_threshold, parent);
     hipLaunchKernelGGL(k_rg_compmin, dim3(g1(n)), dim3(256), 0, s, normals, n, parent, comp_label);
     PCC_HIP(hipGetLastError());
+    if (general) {
+        // comp_label holds the components' own lowest ranks; label_old / label_new alternate
+        PCC_TRY(ix->vox_a.reserve((size_t)n * 16));
+        unsigned long long* lab[2] = {ix->vox_a.as<unsigned long long>(), ix->vox_a.as<unsigned long long>() + n};
+        PCC_HIP(hipMemcpyAsync(lab[0], comp_label, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        int cur = 0;
+        for (int sweep = 0;; ++sweep) {
+            if (sweep > 100000) { set_error("region growing did not settle"); return PCC_ERR_DEVICE; }
+            PCC_HIP(hipMemcpyAsync(lab[cur ^ 1], comp_label, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+            PCC_HIP(hipMemsetAsync(d_words + 1, 0, 4, s));
+            if (sweep == 0)
+                hipLaunchKernelGGL(k_rg_sweep_general<true>, dim3(wave_blocks), dim3(256), 0, s, keys, normals,
+                                   ix->cell_refs.as<float4>(), ix->d_grid.as<GridDev>(), K, cos_thr, curvature_threshold, parent,
+                                   lab[cur], lab[cur ^ 1], has_cross);
+            else
+                hipLaunchKernelGGL(k_rg_sweep_general<false>, dim3(wave_blocks), dim3(256), 0, s, keys, normals,
+                                   ix->cell_refs.as<float4>(), ix->d_grid.as<GridDev>(), K, cos_thr, curvature_threshold, parent,
+                                   lab[cur], lab[cur ^ 1], has_cross);
+            hipLaunchKernelGGL(k_rg_diff, dim3(g1(n)), dim3(256), 0, s, lab[cur], lab[cur ^ 1], n, d_words + 1);
+            PCC_HIP(hipGetLastError());
+            PCC_HIP(hipMemcpyAsync(h, d_words + 1, 4, hipMemcpyDeviceToHost, s));
+            PCC_HIP(hipStreamSynchronize(s));
+            cur ^= 1;
+            if (h[0] == 0) break;
+        }
+        PCC_HIP(hipMemcpyAsync(comp_label, lab[cur], (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    } else
     for (int sweep = 0;; ++sweep) {
         PCC_HIP(hipMemsetAsync(d_words + 1, 0, 4, s));
         if (sweep == 0)

@@ -131,9 +131,11 @@ def test_region_growing_device_normals_and_size_filter():
     assert n_h == 0 or ((cnt >= 100) & (cnt <= 1400)).all()
 
 
-@pytest.mark.parametrize("seed,k,theta_deg,nan_frac", [(1, 8, 25.0, 0.0), (2, 16, 35.0, 0.01), (3, 5, 50.0, 0.0),
-                                                        (4, 40, 15.0, 0.002), (5, 3, 80.0, 0.05)])
-def test_region_growing_order_free_form_equals_pcl_walk(seed, k, theta_deg, nan_frac):
+@pytest.mark.parametrize("seed,k,theta_deg,nan_frac,curv_thr", [
+    (1, 8, 25.0, 0.0, 1.0), (2, 16, 35.0, 0.01, 1.0), (3, 5, 50.0, 0.0, 1.0), (4, 40, 15.0, 0.002, 1.0), (5, 3, 80.0, 0.05, 1.0),
+    # points above the curvature threshold join a region without spreading -- unless they seed one themselves
+    (6, 8, 40.0, 0.0, 0.15), (7, 12, 60.0, 0.01, 0.05), (8, 4, 85.0, 0.03, 0.25), (9, 20, 30.0, 0.0, 0.0), (10, 6, 89.0, 0.02, 0.29)])
+def test_region_growing_order_free_form_equals_pcl_walk(seed, k, theta_deg, nan_frac, curv_thr):
     """Adversarial graphs for the GPU formulation (label = lowest-ranked ancestor): random normals make
     the smooth-edge graph sparse, strongly one-directional and full of small components, NaN normals
     accept every edge, duplicated curvatures exercise the rank tie-break.  The result must equal the
@@ -148,10 +150,10 @@ def test_region_growing_order_free_form_equals_pcl_walk(seed, k, theta_deg, nan_
     bad = rng.random(n) < nan_frac
     nrm[bad] = np.nan
     ix = capi.Index(pts)
-    labels, ncl = ix.region_growing(nrm, k=k, smoothness=theta_deg / 180.0 * np.pi, curvature_threshold=1.0,
+    labels, ncl = ix.region_growing(nrm, k=k, smoothness=theta_deg / 180.0 * np.pi, curvature_threshold=curv_thr,
                                     min_size=1, max_size=n)
     nbr, _ = ix.knn(pts, k)
-    want, want_n = oracle.region_growing(nrm, nbr, theta_deg / 180.0 * np.pi, 1.0, 1, n)
+    want, want_n = oracle.region_growing(nrm, nbr, theta_deg / 180.0 * np.pi, curv_thr, 1, n)
     assert ncl == want_n
     np.testing.assert_array_equal(labels, want)
     assert ncl > 10
