@@ -14,54 +14,11 @@
 
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
+#include "plane_fit.hpp"
 
 namespace pcc {
 
 namespace {
-
-__device__ __forceinline__ void roots2(float b, float c, float r[3]) {
-    r[0] = 0.f;
-    float d = b * b - 4.f * c;
-    if (d < 0.f) d = 0.f;
-    const float sd = sqrtf(d);
-    r[2] = 0.5f * (b + sd);
-    r[1] = 0.5f * (b - sd);
-}
-
-// eigenvalues of the (scaled) symmetric matrix, increasing; pcl::computeRoots
-__device__ __forceinline__ void roots3(const float m[9], float r[3]) {
-    const float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
-    const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
-    const float c2 = m[0] + m[4] + m[8];
-    if (fabsf(c0) < 1.1920929e-07f) { roots2(c2, c1, r); return; }
-    const float s_inv3 = (float)(1.0 / 3.0);
-    const float s_sqrt3 = 1.7320508f;  // sqrtf(3.0f)
-    const float c2_over_3 = c2 * s_inv3;
-    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
-    if (a_over_3 > 0.f) a_over_3 = 0.f;
-    const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
-    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
-    if (q > 0.f) q = 0.f;
-    const float rho = sqrtf(-a_over_3);
-    const float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
-    const float ct = (float)cos((double)theta), st = (float)sin((double)theta);
-    r[0] = c2_over_3 + 2.f * rho * ct;
-    r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
-    r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
-    float t;
-    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
-    if (r[1] >= r[2]) {
-        t = r[1]; r[1] = r[2]; r[2] = t;
-        if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
-    }
-    if (r[0] <= 0.f) roots2(c2, c1, r);
-}
-
-__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
 
 // NR_KC neighbour columns at a time: each wave copies the rows of its 64 points into LDS with coalesced
 // loads (lanes over columns), then every lane walks its own row from LDS.  Points are taken in CELL order,
@@ -111,39 +68,10 @@ k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict_
         }
         if (!have) continue;
         if (cnt < 3) { out[i] = make_float4(qnan, qnan, qnan, qnan); continue; }
-        // accu /= point_count: Eigen 3.2's operator/=(scalar) multiplies by Scalar(1)/other
-        const float fc = 1.0f / (float)cnt;
-        a0 *= fc; a1 *= fc; a2 *= fc; a3 *= fc; a4 *= fc; a5 *= fc; a6 *= fc; a7 *= fc; a8 *= fc;
-        float cov[9];
-        cov[0] = a0 - a6 * a6; cov[1] = a1 - a6 * a7; cov[2] = a2 - a6 * a8;
-        cov[4] = a3 - a7 * a7; cov[5] = a4 - a7 * a8; cov[8] = a5 - a8 * a8;
-        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
-        // pcl::eigen33: scale, roots, eigenvector of the smallest root from the largest row cross product
-        float scale = 0.f;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) scale = fmaxf(scale, fabsf(cov[j]));
-        if (scale <= 1.17549435e-38f) scale = 1.f;
-        float sm[9], ev[3];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) sm[j] = cov[j] / scale;
-        roots3(sm, ev);
-        const float eigenvalue = ev[0] * scale;
-        sm[0] -= ev[0]; sm[4] -= ev[0]; sm[8] -= ev[0];
-        float v1[3], v2[3], v3[3];
-        cross3(sm + 0, sm + 3, v1);
-        cross3(sm + 0, sm + 6, v2);
-        cross3(sm + 3, sm + 6, v3);
-        const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
-        const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
-        const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
-        float vx, vy, vz, l;
-        if (l1 >= l2 && l1 >= l3) { vx = v1[0]; vy = v1[1]; vz = v1[2]; l = l1; }
-        else if (l2 >= l1 && l2 >= l3) { vx = v2[0]; vy = v2[1]; vz = v2[2]; l = l2; }
-        else { vx = v3[0]; vy = v3[1]; vz = v3[2]; l = l3; }
-        const float s = sqrtf(l);
-        float nx = vx / s, ny = vy / s, nz = vz / s;
-        const float eig_sum = cov[0] + cov[4] + cov[8];
-        const float curv = eig_sum != 0.f ? fabsf(eigenvalue / eig_sum) : 0.f;
+        float acc[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8}, cov[9], nrm[3], curv;
+        covariance_from_sums(acc, (unsigned int)cnt, cov);
+        plane_from_covariance(cov, nrm, &curv);
+        float nx = nrm[0], ny = nrm[1], nz = nrm[2];
         // flipNormalTowardsViewpoint
         const float4 p = refs[i];
         const float dx = vpx - p.x, dy = vpy - p.y, dz = vpz - p.z;

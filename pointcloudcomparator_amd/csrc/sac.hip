@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "pcc_internal.hpp"
+#include "plane_fit.hpp"
 
 namespace pcc {
 
@@ -124,69 +125,6 @@ inline bool plane_from_sample(const float* p0, const float* p1, const float* p2,
     const float p[4] = {p0[0], p0[1], p0[2], 1.0f};
     c[3] = -1.0f * dot4(c, p);
     return true;
-}
-
-// pcl::eigen33 (smallest eigenpair) on the host, as k_normals does it on the device
-inline void roots2_h(float b, float c, float r[3]) {
-    r[0] = 0.f;
-    float d = b * b - 4.f * c;
-    if (d < 0.f) d = 0.f;
-    const float sd = std::sqrt(d);
-    r[2] = 0.5f * (b + sd);
-    r[1] = 0.5f * (b - sd);
-}
-inline void roots3_h(const float m[9], float r[3]) {
-    const float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
-    const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
-    const float c2 = m[0] + m[4] + m[8];
-    if (std::fabs(c0) < FLT_EPSILON) { roots2_h(c2, c1, r); return; }
-    const float s_inv3 = (float)(1.0 / 3.0), s_sqrt3 = std::sqrt(3.0f);
-    const float c2_over_3 = c2 * s_inv3;
-    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
-    if (a_over_3 > 0.f) a_over_3 = 0.f;
-    const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
-    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
-    if (q > 0.f) q = 0.f;
-    const float rho = std::sqrt(-a_over_3);
-    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;  // host libm, float versions, as PCL calls them
-    const float ct = cosf(theta), st = sinf(theta);
-    r[0] = c2_over_3 + 2.f * rho * ct;
-    r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
-    r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
-    float t;
-    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
-    if (r[1] >= r[2]) {
-        t = r[1]; r[1] = r[2]; r[2] = t;
-        if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
-    }
-    if (r[0] <= 0.f) roots2_h(c2, c1, r);
-}
-inline void cross3_h(const float* a, const float* b, float* o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-inline void smallest_eigenvector(const float cov[9], float n[3]) {
-    float scale = 0.f;
-    for (int i = 0; i < 9; ++i) scale = std::fmax(scale, std::fabs(cov[i]));
-    if (scale <= FLT_MIN) scale = 1.f;
-    float sm[9], ev[3];
-    for (int i = 0; i < 9; ++i) sm[i] = cov[i] / scale;
-    roots3_h(sm, ev);
-    sm[0] -= ev[0]; sm[4] -= ev[0]; sm[8] -= ev[0];
-    float v1[3], v2[3], v3[3];
-    cross3_h(sm + 0, sm + 3, v1);
-    cross3_h(sm + 0, sm + 6, v2);
-    cross3_h(sm + 3, sm + 6, v3);
-    const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
-    const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
-    const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
-    const float* v; float l;
-    if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
-    else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
-    else { v = v3; l = l3; }
-    const float s = std::sqrt(l);
-    n[0] = v[0] / s; n[1] = v[1] / s; n[2] = v[2] / s;
 }
 
 inline int g1(size_t n) {
@@ -318,14 +256,9 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_
             a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
             a[6] += q[0]; a[7] += q[1]; a[8] += q[2];
         }
-        const float inv_cnt = 1.0f / (float)m;
-        for (int i = 0; i < 9; ++i) a[i] *= inv_cnt;
-        float cov[9];
-        cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
-        cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
-        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
-        float nrm[3];
-        smallest_eigenvector(cov, nrm);
+        float cov[9], nrm[3], curv;
+        covariance_from_sums(a, (unsigned int)m, cov);
+        plane_from_covariance(cov, nrm, &curv);
         float o[4] = {nrm[0], nrm[1], nrm[2], 0.f};
         const float cen[4] = {a[6], a[7], a[8], 0.f};
         o[3] = -1.0f * dot4(o, cen);
