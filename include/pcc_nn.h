@@ -147,12 +147,18 @@ int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
  *   double-precision sums Umeyama needs, fused in one pass.
  *   sums[0..2]=sum p, [3..5]=sum q, [6..14]=sum q p^T (row-major, q row, p col),
  *   [15]=sum d2, [16]=count.  idx/d2 may be NULL.  sums is a HOST array.
+ * pcc_rigid_from_sums: the rigid transform (rotation + translation, no scaling; Horn's quaternion form of
+ *   the Umeyama/Kabsch solution, solved in double, returned as a row-major float 4x4) those sums determine.
+ *   Pure host arithmetic, needs no handle: a caller that shards the SOURCE cloud over several GPUs adds up the
+ *   sums of all shards (one all-reduce of 17 doubles per iteration) and gets the same transform on every rank.
+ *   Returns PCC_ERR_INVALID when fewer than 3 correspondences contributed.
  * pcc_transform: dst = T * src with PCL's transformPointCloud rounding
  *   ((m0*x + m1*y) + m2*z) + m3; T row-major 4x4 (host); dst may alias src.
  * pcc_icp_align: the whole loop on the device (source stays resident):
  *   max_iter iterations (early exit on |mse-prev| < 1e-12 unless fixed != 0),
  *   final transform T (host, row-major), *fitness = mean squared NN distance of
  *   the finally transformed source, *converged as PCL's hasConverged(). */
+int pcc_rigid_from_sums(const double sums[17], float T[16]);
 int pcc_icp_step(pcc_index *target, const void *src, size_t n, size_t stride_bytes,
                  int mem, int32_t *idx, float *d2, double sums[17]);
 int pcc_transform(pcc_index *ctx, const float T[16], const void *src, size_t n,

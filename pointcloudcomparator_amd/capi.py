@@ -28,7 +28,7 @@ SYMBOLS = [
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
-    "pcc_normals", "pcc_region_growing", "pcc_sac_plane",
+    "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
 ]
 
 
@@ -77,6 +77,7 @@ def _load() -> C.CDLL:
     lib.pcc_knn.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp]
     lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_first_within.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
+    lib.pcc_rigid_from_sums.argtypes = [vp, vp]
     lib.pcc_sac_plane.argtypes = [vp, vp, sz, sz, i32, i32, C.c_double, C.c_double, i32, vp, C.POINTER(sz), vp, vp]
     lib.pcc_normals.argtypes = [vp, i32, vp, i32, vp]
     lib.pcc_region_growing.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
@@ -140,6 +141,15 @@ def _out(like, shape, dtype):
         return t, t.data_ptr()
     a = np.empty(shape, dtype=dtype)
     return a, a.ctypes.data
+
+
+def rigid_from_sums(sums):
+    """4x4 float32 rigid transform from the 17 ICP sums (pcc_rigid_from_sums; host arithmetic, no handle)."""
+    sm = np.ascontiguousarray(sums, dtype=np.float64)
+    assert sm.shape == (17,)
+    T = np.zeros(16, dtype=np.float32)
+    _check(LIB.pcc_rigid_from_sums(sm.ctypes.data, T.ctypes.data))
+    return T.reshape(4, 4)
 
 
 class Index:

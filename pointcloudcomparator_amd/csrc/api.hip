@@ -787,6 +787,12 @@ static void mat4_mul_f(const float A[16], const float B[16], float C[16]) {
     memcpy(C, R, sizeof(R));
 }
 
+int pcc_rigid_from_sums(const double sums[17], float T[16]) {
+    if (!sums || !T) { set_error("null argument"); return PCC_ERR_INVALID; }
+    if (rigid_from_sums(sums, T) != 0) { set_error("fewer than 3 correspondences"); return PCC_ERR_INVALID; }
+    return PCC_OK;
+}
+
 int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int mem, int32_t* idx, float* d2,
                  double sums[17]) {
     PCC_ENTER(ix);

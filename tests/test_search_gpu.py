@@ -274,3 +274,23 @@ def test_bad_arguments_are_refused_with_a_message(gpu):
         # the handle is still usable afterwards
         idx, d2 = ix.nn1(pts[:10])
         assert (idx == np.arange(10)).all() and (d2 == 0).all()
+
+
+def test_sharded_icp_loop_equals_icp_align(gpu):
+    """pcc_rigid_from_sums + the python sharded loop (one rank here) reproduce pcc_icp_align; the solver agrees
+    with the oracle's Umeyama on the same sums"""
+    from pointcloudcomparator_amd import sharding
+    tgt = _scene(20000)
+    src = synth.rigid_offset(tgt[:8000].copy(), jitter=0.001)
+    with capi.Index(tgt) as ix:
+        T_ref, fit, its, conv = ix.icp_align(src, max_iter=6, fixed=True)
+        T, it, mse = sharding.icp_align_sharded(lambda p: ix.icp_step(p, want_corr=False)[2], ix.transform,
+                                                capi.rigid_from_sums, src, 6, None)
+        _, _, sums = ix.icp_step(src)
+    assert it == its == 6
+    assert (T.view(np.uint32) == np.asarray(T_ref, np.float32).reshape(4, 4).view(np.uint32)).all()
+    rc, To = oracle.umeyama_from_sums(sums)
+    assert rc == 0
+    np.testing.assert_allclose(capi.rigid_from_sums(sums), To.reshape(4, 4), atol=2e-6)
+    with pytest.raises(capi.PccError):
+        capi.rigid_from_sums(np.zeros(17))

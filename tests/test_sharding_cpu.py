@@ -64,3 +64,45 @@ def test_two_rank_gloo_sharded_search_matches_unsharded():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and tmax == 2.0 and start0 == 0
+
+
+def _icp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tgt = synth.corridor_cloud(4000, synth.SEED_A)
+    src = synth.rigid_offset(tgt[:3001].copy(), jitter=0.001)
+    tree = oracle.KdTree(tgt)
+    start, count = sharding.shard_range(len(src), rank, world)
+    step = lambda pts: tree.icp_step_sums(tgt, np.ascontiguousarray(pts))[2]
+    solve = lambda sums: oracle.umeyama_from_sums(sums)[1].reshape(4, 4)
+    T, it, mse = sharding.icp_align_sharded(step, lambda M, pts: oracle.transform(M, np.ascontiguousarray(pts)), solve,
+                                            src[start:start + count], 5, dist)
+    if rank == 0:
+        # unsharded run of the same loop
+        T1, it1, mse1 = sharding.icp_align_sharded(step, lambda M, pts: oracle.transform(M, np.ascontiguousarray(pts)), solve, src, 5, None)
+        q.put((np.abs(T - T1).max(), it, it1, abs(mse - mse1) / mse1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_icp_matches_unsharded():
+    """source cloud split over two ranks, 17 sums all-reduced per iteration: same transform as one rank (the
+    double sums differ only in their last bits through the order of addition)"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_icp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    dT, it, it1, dm = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert it == it1 == 5 and dT < 1e-6 and dm < 1e-9
