@@ -1,0 +1,99 @@
+"""Random sequences of operations of random sizes on ONE handle, every result checked against the oracle:
+the operations share grow-only scratch buffers inside the handle, so an aliasing or stale-pointer bug shows up
+as a wrong result somewhere along such a sequence."""
+import numpy as np
+import pytest
+
+import oracle
+from pointcloudcomparator_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, n):
+    k = max(1, n // 400)
+    c = rng.random((k, 3)) * 3
+    pts = c[rng.integers(0, k, n)] + rng.normal(0, 0.05, (n, 3))
+    extra = rng.random((max(1, n // 10), 3)) * 3
+    return np.ascontiguousarray(np.concatenate([pts, extra])[:n].astype(np.float32))
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_operation_sequences(gpu, seed):
+    rng = np.random.default_rng(seed)
+    ref = _cloud(rng, int(rng.integers(5000, 30000)))
+    ix = capi.Index(ref)
+    ops = ["nn1", "knn", "radius", "sor", "clusters", "normals", "region", "sac", "voxel", "first", "icp", "set_input"]
+    for step in range(40):
+        op = ops[int(rng.integers(0, len(ops)))]
+        nq = int(rng.integers(1, 6000))
+        q = _cloud(rng, nq)
+        if op == "set_input":
+            ref = _cloud(rng, int(rng.integers(4100, 40000)))
+            ix.set_input(ref)
+        elif op == "nn1":
+            idx, d2 = ix.nn1(q)
+            oi, od = oracle.nn1_exhaustive(ref, q)
+            assert (idx == oi).all() and (_bits(d2) == _bits(od)).all(), (step, op)
+        elif op == "knn":
+            k = int(rng.integers(1, 70))
+            ki, kd = ix.knn(q[:300], k)
+            oi, od = oracle.knn_exhaustive(ref, q[:300], k)
+            assert (ki == oi).all() and (_bits(kd) == _bits(od)).all(), (step, op, k)
+        elif op == "radius":
+            r = float(rng.uniform(0.02, 0.12))
+            cnt = ix.radius_count(q, r)
+            assert (cnt == oracle.radius_count_exhaustive(ref, q, r)).all(), (step, op)
+            offs, idx, d2 = ix.radius_search(q[:200], r, sorted=True)
+            assert (np.diff(offs) == cnt[:200]).all()
+            for i in range(0, 200, 17):
+                s, e = offs[i], offs[i + 1]
+                dd = ((ref - q[i]) ** 2).astype(np.float32)
+                w = (dd[:, 0] + dd[:, 1]) + dd[:, 2]
+                ins = np.nonzero(w < np.float32(r * r))[0]
+                o = np.lexsort((ins, w[ins]))
+                assert (idx[s:e] == ins[o]).all(), (step, op)
+        elif op == "sor":
+            md, inl, thr, kept = ix.sor(10, 1.0)
+            omd, oinl, othr, okept = oracle.sor(ref, 10, 1.0)
+            assert (_bits(md) == _bits(omd)).all() and kept == okept and abs(thr - othr) < 1e-12, (step, op)
+        elif op == "clusters":
+            labels, ncl, sizes = ix.euclidean_clusters(0.05, 20, 100000)
+            ol, on, osz = oracle.euclidean_clusters(ref, 0.05, 20, 100000)
+            assert ncl == on and (labels == ol).all(), (step, op)
+        elif op == "normals":
+            nrm = ix.normals(12)
+            nb, _ = ix.knn(ref, 12)
+            want = oracle.normals(ref, 12, neighbours=nb)
+            ok = np.isfinite(nrm).all(1) & np.isfinite(want).all(1)
+            assert (np.isnan(nrm).all(1) == np.isnan(want).all(1)).all()
+            assert (np.abs((nrm[ok, :3] * want[ok, :3]).sum(1)) > 1 - 1e-5).all(), (step, op)
+        elif op == "region":
+            nb, _ = ix.knn(ref, 15)
+            nrm = oracle.normals(ref, 15, neighbours=nb)
+            thr = float(rng.choice([1.0, 0.1]))
+            labels, ncl = ix.region_growing(nrm, k=15, smoothness=0.3, curvature_threshold=thr, min_size=5, max_size=len(ref))
+            want, wn = oracle.region_growing(nrm, nb, 0.3, thr, 5, len(ref))
+            assert ncl == wn and (labels == want).all(), (step, op, thr)
+        elif op == "sac":
+            inl, c, its = ix.sac_plane(q, 50, 0.03, 0.99, True)
+            w_inl, w_c, w_its = oracle.sac_plane(q, 50, 0.03, 0.99, True)
+            assert its == w_its and len(inl) == len(w_inl) and (inl == w_inl).all(), (step, op)
+            assert (_bits(c) == _bits(w_c)).all() or (np.isnan(c).all() and np.isnan(w_c).all())
+        elif op == "voxel":
+            out = ix.voxel_grid(q, 0.05)
+            want, nv = oracle.voxel_grid(q, 0.05)
+            assert len(out) == nv and np.allclose(out, want[:, :3], atol=1e-5), (step, op)
+        elif op == "first":
+            fw = ix.first_within(q, 0.06)
+            assert (fw == oracle.first_within(ref, q, 0.06)).all(), (step, op)
+        elif op == "icp":
+            idx, d2, sums = ix.icp_step(q)
+            oi, od = oracle.nn1_exhaustive(ref, q)
+            assert (idx == oi).all(), (step, op)
+            assert abs(sums[16] - len(q)) < 0.5 and abs(sums[15] - od.astype(np.float64).sum()) <= 1e-9 * max(1.0, sums[15])
+    ix.close()
