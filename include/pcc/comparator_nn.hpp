@@ -223,17 +223,19 @@ public:
     void setSearchMethod(const typename search::KdTree<PointT>::Ptr& tree) { tree_ = tree; }
     void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
     void setKSearch(int k) { k_ = k; }
+    void setRadiusSearch(double r) { radius_ = r; }  // as in PCL, the radius is used when no K was set
     void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; }
     void compute(PointCloud<NormalT>& out) {
         out.points.clear();
         out.width = 0;
         out.height = 1;
-        if (!input_ || input_->empty() || k_ < 1) return;
+        if (!input_ || input_->empty() || (k_ < 1 && !(radius_ > 0))) return;
         if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
         if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
         if (!tree_->handle()) return;
         std::vector<float> nc(input_->size() * 4);
-        check(pcc_normals(tree_->handle(), k_, vp_, PCC_MEM_HOST, nc.data()));
+        if (k_ >= 1) check(pcc_normals(tree_->handle(), k_, vp_, PCC_MEM_HOST, nc.data()));
+        else check(pcc_normals_radius(tree_->handle(), radius_, vp_, PCC_MEM_HOST, nc.data()));
         out.points.resize(input_->size());
         out.width = (std::uint32_t)input_->size();
         out.is_dense = true;
@@ -248,6 +250,7 @@ private:
     typename search::KdTree<PointT>::Ptr tree_;
     typename PointCloud<PointT>::ConstPtr input_;
     int k_ = 0;
+    double radius_ = 0.0;
     float vp_[3] = {0.f, 0.f, 0.f};
 };
 

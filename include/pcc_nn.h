@@ -230,6 +230,10 @@ int pcc_sac_plane(pcc_index *ctx, const void *pts, size_t n, size_t stride_bytes
  *   *n_clusters (host) = clusters.size().  Equal curvatures are taken in index order (PCL:
  *   std::sort, unspecified). */
 int pcc_normals(pcc_index *index, int k, const float viewpoint[3], int mem, float *out);
+/* the same with setRadiusSearch(radius) instead of setKSearch (the normals of the RIFT pipeline,
+ * src/comparator.cpp:628-635, radius 0.03): the neighbourhood is the sorted radiusSearch result
+ * (d2 < float(radius^2), ascending (d2, index)); NaN where it holds fewer than 3 points. */
+int pcc_normals_radius(pcc_index *index, double radius, const float viewpoint[3], int mem, float *out);
 int pcc_region_growing(pcc_index *index, const float *normals, int mem, int k, float smoothness,
                        float curvature_threshold, uint32_t min_size, uint32_t max_size,
                        int32_t *labels, int32_t *n_clusters);

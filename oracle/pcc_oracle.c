@@ -607,6 +607,32 @@ void orc_normals(const void *pts, size_t n, size_t stride, int k, const float vp
     orc_kdtree_free(t);
 }
 
+/* NormalEstimation with setRadiusSearch(radius) (src/comparator.cpp:628-635, radius 0.03): the neighbours are the
+ * sorted radiusSearch result (search::KdTree sorts by default), r2 = float(radius * radius) in double */
+void orc_normals_radius(const void *pts, size_t n, size_t stride, double radius, const float vp[3], float *out) {
+    orc_kdtree *t = orc_kdtree_build(pts, n, stride);
+    const float r2 = (float)(radius * radius);
+    int cap = 1024;
+    int32_t *ni = (int32_t *)malloc(sizeof(int32_t) * cap);
+    float *nd = (float *)malloc(sizeof(float) * cap);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = pt_at(pts, stride, i);
+        int cnt = 0;
+        if (t && finite3(p)) {
+            cnt = orc_kdtree_radius(t, p, r2, 1, ni, nd, cap);
+            if (cnt > cap) {  /* the count is returned even when the buffers were too small */
+                cap = cnt + cnt / 2;
+                ni = (int32_t *)realloc(ni, sizeof(int32_t) * cap);
+                nd = (float *)realloc(nd, sizeof(float) * cap);
+                cnt = orc_kdtree_radius(t, p, r2, 1, ni, nd, cap);
+            }
+        }
+        normal_of(pts, stride, ni, cnt, p, vp, out + i * 4);
+    }
+    free(ni); free(nd);
+    orc_kdtree_free(t);
+}
+
 /* ======== SACSegmentation, SACMODEL_PLANE + SAC_RANSAC (src/segmentation.cpp:79-117) ========
  * [recalled from PCL 1.7 sample_consensus/{ransac,sac_model,sac_model_plane}.hpp, segmentation/sac_segmentation.hpp,
  *  Boost.Random, Eigen 3.2 with SSE3+ (the PCL 1.7 Ubuntu packages are built with -msse4.2)]

@@ -91,6 +91,8 @@ void orc_first_within(const void *pts, size_t m, size_t stride, const void *qry,
  * roots), curvature = |lambda0 / trace|, normal flipped towards the viewpoint.  out: n x 4 floats
  * (nx, ny, nz, curvature); NaN for non-finite points or fewer than 3 neighbours. */
 void orc_normals(const void *pts, size_t n, size_t stride, int k, const float vp[3], float *out);
+/* the same with setRadiusSearch(radius): neighbours = sorted radiusSearch result (src/comparator.cpp:628-635) */
+void orc_normals_radius(const void *pts, size_t n, size_t stride, double radius, const float vp[3], float *out);
 /* the same arithmetic on given neighbour lists (n rows of k indices, -1 = unused) */
 void orc_normals_from_neighbours(const void *pts, size_t n, size_t stride, const int32_t *nbr, int k,
                                  const float vp[3], float *out);

@@ -50,6 +50,8 @@ def lib() -> C.CDLL:
         L.orc_kdtree_nn1_batch_mt.restype = None
         L.orc_normals.argtypes = [vp, sz, sz, i32, vp, vp]
         L.orc_normals.restype = None
+        L.orc_normals_radius.argtypes = [vp, sz, sz, C.c_double, vp, vp]
+        L.orc_normals_radius.restype = None
         L.orc_normals_from_neighbours.argtypes = [vp, sz, sz, vp, i32, vp, vp]
         L.orc_normals_from_neighbours.restype = None
         L.orc_region_growing.argtypes = [sz, vp, vp, i32, C.c_float, C.c_float, i32, i32, vp]
@@ -200,6 +202,14 @@ def normals(pts, k, viewpoint=(0.0, 0.0, 0.0), neighbours=None):
     else:
         nb = np.ascontiguousarray(neighbours, dtype=np.int32)
         lib().orc_normals_from_neighbours(ap, n, s1, nb.ctypes.data, nb.shape[1], vpt.ctypes.data, out.ctypes.data)
+    return out
+
+
+def normals_radius(pts, radius, viewpoint=(0.0, 0.0, 0.0)):
+    a, ap, n, s1 = _f32(pts)
+    vpt = np.asarray(viewpoint, np.float32)
+    out = np.empty((n, 4), np.float32)
+    lib().orc_normals_radius(ap, n, s1, float(radius), vpt.ctypes.data, out.ctypes.data)
     return out
 
 

@@ -29,6 +29,7 @@ SYMBOLS = [
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
+    "pcc_normals_radius",
 ]
 
 
@@ -80,6 +81,7 @@ def _load() -> C.CDLL:
     lib.pcc_rigid_from_sums.argtypes = [vp, vp]
     lib.pcc_sac_plane.argtypes = [vp, vp, sz, sz, i32, i32, C.c_double, C.c_double, i32, vp, C.POINTER(sz), vp, vp]
     lib.pcc_normals.argtypes = [vp, i32, vp, i32, vp]
+    lib.pcc_normals_radius.argtypes = [vp, C.c_double, vp, i32, vp]
     lib.pcc_region_growing.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
     lib.pcc_voxel_grid.argtypes = [vp, vp, sz, sz, i32, C.c_float, i32, vp, sz, C.POINTER(sz)]
     lib.pcc_radius_fill.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, vp]
@@ -336,6 +338,16 @@ class Index:
             return out
         out = np.empty((self.n_original, 4), dtype=np.float32)
         _check(LIB.pcc_normals(self._h, k, vp, MEM_HOST, out.ctypes.data))
+        return out
+
+    def normals_radius(self, radius: float, viewpoint=None):
+        """pcl::NormalEstimation with setRadiusSearch(radius): (n, 4) = nx, ny, nz, curvature (host array)."""
+        vp = None
+        if viewpoint is not None:
+            vpa = np.ascontiguousarray(viewpoint, dtype=np.float32)
+            vp = vpa.ctypes.data
+        out = np.empty((self.n_original, 4), dtype=np.float32)
+        _check(LIB.pcc_normals_radius(self._h, float(radius), vp, MEM_HOST, out.ctypes.data))
         return out
 
     def region_growing(self, normals, k: int = 100, smoothness: float = 3.0 / 180.0 * np.pi,

@@ -560,6 +560,27 @@ int pcc_normals(pcc_index* ix, int k, const float viewpoint[3], int mem, float* 
     return PCC_OK;
 }
 
+int pcc_normals_radius(pcc_index* ix, double radius, const float viewpoint[3], int mem, float* out) {
+    PCC_ENTER(ix);
+    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
+    if (!out) { set_error("null output"); return PCC_ERR_INVALID; }
+    if (!(radius >= 0)) { set_error("bad radius"); return PCC_ERR_INVALID; }
+    PCC_TRY(ensure_grid(ix));
+    ev_next(ix);
+    ev_mark(ix, EV_CALL0);
+    const size_t n = ix->n_orig;
+    const float origin[3] = {0.f, 0.f, 0.f};
+    float4* dout = reinterpret_cast<float4*>(out);
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_d2.reserve(n * sizeof(float4))); dout = ix->out_d2.as<float4>(); }
+    PCC_TRY(normals_radius(ix, radius, viewpoint ? viewpoint : origin, dout));
+    ev_mark(ix, EV_CALL1);
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, reinterpret_cast<const float*>(dout), out, n * 4, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
 int pcc_region_growing(pcc_index* ix, const float* normals, int mem, int k, float smoothness,
                        float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels,
                        int32_t* n_clusters) {

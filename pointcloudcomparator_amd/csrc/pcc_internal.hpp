@@ -200,6 +200,7 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n, const char* host_b
               size_t* n_inliers, float coeff[4], int* iterations_out);
 int launch_normals(hipStream_t s, const unsigned long long* keys, const float4* refs, const float4* cell_refs,
                    const GridDev* gd, size_t n, int K, const float vp[3], float4* out);
+int normals_radius(pcc_index* ix, double radius, const float vp[3], float4* out);
 int grid_region_growing(pcc_index* ix, const unsigned long long* keys, const float4* normals, int K, float smoothness,
                         float curvature_threshold, uint32_t min_size, uint32_t max_size, int32_t* labels_dev,
                         int32_t* n_clusters);

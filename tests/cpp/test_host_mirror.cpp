@@ -100,6 +100,15 @@ int main() {
         if (i < 3000) REQUIRE(q.normal_z < -0.99f); else REQUIRE(q.normal_y < -0.99f);
         REQUIRE(q.curvature >= 0.f && q.curvature < 0.01f);
     }
+    NormalEstimation<PointXYZRGB, Normal> ner;  // the RIFT pipeline's form: radius search (src/comparator.cpp:628-635)
+    PointCloud<Normal>::Ptr normals_r(new PointCloud<Normal>);
+    ner.setSearchMethod(ptree); ner.setInputCloud(plates); ner.setRadiusSearch(0.08);
+    ner.compute(*normals_r);
+    REQUIRE(normals_r->size() == plates->size());
+    for (int i = 0; i < 6000; i += 7) {
+        const Normal& q = normals_r->points[i];
+        if (std::isfinite(q.normal_x)) { if (i < 3000) REQUIRE(q.normal_z < -0.99f); else REQUIRE(q.normal_y < -0.99f); }
+    }
     RegionGrowing<PointXYZRGB, Normal> reg;
     reg.setMinClusterSize(50); reg.setMaxClusterSize(1000000); reg.setSearchMethod(ptree);
     reg.setNumberOfNeighbours(100); reg.setInputCloud(plates); reg.setInputNormals(normals);

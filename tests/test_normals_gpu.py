@@ -157,3 +157,26 @@ def test_region_growing_order_free_form_equals_pcl_walk(seed, k, theta_deg, nan_
     assert ncl == want_n
     np.testing.assert_array_equal(labels, want)
     assert ncl > 10
+
+
+@pytest.mark.parametrize("radius", [0.03, 0.06, 0.15])
+def test_normals_with_radius_search(radius):
+    """NormalEstimation::setRadiusSearch (the RIFT pipeline's normals, src/comparator.cpp:628-635): neighbourhood =
+    sorted radius search result"""
+    pts = _room(2500, seed=21)
+    pts[11] = np.nan
+    ix = capi.Index(pts)
+    got = ix.normals_radius(radius)
+    want = oracle.normals_radius(pts, radius)
+    assert np.isnan(got[11]).all() and np.isnan(want[11]).all()
+    # same rows (sorted by (d2, index); FLANN's tie order differs only where distances tie), same arithmetic
+    both_nan = np.isnan(got).all(1) & np.isnan(want).all(1)
+    assert (np.isnan(got).all(1) == np.isnan(want).all(1)).all()
+    ok = ~both_nan
+    same = (got[ok].view(np.uint32) == want[ok].view(np.uint32)).all(axis=1)
+    assert same.mean() > 0.9
+    dots = np.abs((got[ok, :3].astype(np.float64) * want[ok, :3]).sum(1))
+    assert (dots > 1 - 1e-5).all()
+    np.testing.assert_allclose(got[ok, 3], want[ok, 3], rtol=0, atol=1e-6)
+    if radius == 0.03:
+        assert both_nan.sum() > 1  # sparse corners: fewer than 3 points within 3 cm
