@@ -216,7 +216,7 @@ def main():
                 "kernel": "k_grid_nn1", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": load_pmc_traffic("k_grid_nn1", wl_key),
                 "kernel_ms": tm[0], "algorithmic_bytes": alg_bytes,
-                "note": "pruned exact search: bound by the per-lane 16-byte gather rate of the L1/texture-address path (DESIGN.md 4.2), far below the HBM roof by construction",
+                "note": "pruned exact search: ~80 % of its time is L1 line lookups and L2->L1 fills of per-lane 16-byte gathers (csrc/ubench_gather.hip prices them; DESIGN.md 4.2); compulsory HBM bytes are a few % of the roof by construction",
             }
         else:
             pairs = float(M) * N
