@@ -457,7 +457,7 @@ int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int 
     PCC_TRY(ix->out_packed.reserve((size_t)total * sizeof(unsigned long long)));
     auto* keys = ix->out_packed.as<unsigned long long>();
     PCC_HIP(hipMemsetAsync(keys, 0xff, (size_t)total * sizeof(unsigned long long), ix->stream));
-    PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), nullptr, doff, keys, sorted));
+    PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), nullptr, doff, keys, sorted, (size_t)total));
     int32_t* didx = idx;
     float* dd2 = d2;
     if (mem == PCC_MEM_HOST) {

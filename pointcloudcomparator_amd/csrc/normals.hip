@@ -154,7 +154,7 @@ int normals_radius(pcc_index* ix, double radius, const float vp[3], float4* out)
     // sorted fill
     PCC_TRY(ix->out_packed.reserve((size_t)(total ? total : 1) * sizeof(unsigned long long)));
     auto* keys = ix->out_packed.as<unsigned long long>();
-    if (total) PCC_TRY(grid_radius(ix, self, n, (float)radius, r2, nullptr, off64, keys, 1));
+    if (total) PCC_TRY(grid_radius(ix, self, n, (float)radius, r2, nullptr, off64, keys, 1, (size_t)total));
     PCC_HIP(hipMemsetAsync(out, 0xff, n * sizeof(float4), s));
     hipLaunchKernelGGL(k_normals_csr, dim3(blocks), dim3(256), 0, s, keys, off32, self, ix->cell_refs.as<float4>(),
                        ix->d_grid.as<GridDev>(), vp[0], vp[1], vp[2], out);
