@@ -185,7 +185,7 @@ class Index:
         return list(t)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and LIB is not None:  # (LIB is gone when the interpreter tears the module down)
             LIB.pcc_index_destroy(self._h)
             self._h = None
 

@@ -99,7 +99,9 @@ k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
-// ---- wave-cooperative k-NN (K <= 128) ---------------------------------------------------------
+constexpr int KNN_BOX_MAX = 64;  // half-width (cells) up to which a box is walked (row by row beyond the LDS table); past it: whole grid
+
+// ---- wave-cooperative k-NN (K <= 512) ---------------------------------------------------------
 // One WAVE per query.  The 64 lanes read a row's candidates with ONE coalesced load, turn them
 // into (d2, position) keys, drop everything not below the current K-th key (tau), and compact
 // the survivors into a small LDS staging buffer (ballot + prefix count).  Whenever 64 survivors
@@ -135,18 +137,19 @@ __device__ __forceinline__ unsigned long long bitonic_merge64(unsigned long long
     return v;  // bitonic in -> ascending out
 }
 
+// merge a batch of 64 keys into the sorted top list (64 * KR keys, ascending over (register, lane)): the sorted
+// batch enters register 0; what each register pushes out (the upper half of a 128-key bitonic split) cascades
+// into the next one; the overflow of the last register is dropped
 template <int KR>
 __device__ __forceinline__ void topk_merge(unsigned long long (&top)[KR], unsigned long long batch, unsigned int lane) {
-    batch = bitonic_sort64(batch, lane);
-    unsigned long long rev = reverse_lanes_u64(batch, lane);
-    unsigned long long lo = rev < top[0] ? rev : top[0];
-    unsigned long long hi = rev < top[0] ? top[0] : rev;
-    top[0] = bitonic_merge64(lo, lane);
-    if (KR > 1) {
-        hi = bitonic_merge64(hi, lane);
-        rev = reverse_lanes_u64(hi, lane);
-        lo = rev < top[KR - 1] ? rev : top[KR - 1];
-        top[KR - 1] = bitonic_merge64(lo, lane);
+    unsigned long long carry = bitonic_sort64(batch, lane);
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+        const unsigned long long rev = reverse_lanes_u64(carry, lane);
+        const unsigned long long lo = rev < top[r] ? rev : top[r];
+        const unsigned long long hi = rev < top[r] ? top[r] : rev;
+        top[r] = bitonic_merge64(lo, lane);
+        if (r + 1 < KR) carry = bitonic_merge64(hi, lane);
     }
 }
 
@@ -155,9 +158,11 @@ __global__ void __launch_bounds__(256)
 k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                 const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
                 const unsigned int* __restrict__ n_sorted_ptr, int K, unsigned long long* __restrict__ keys) {
-    static_assert(KR == 1 || KR == 2, "top list lives in one or two registers per lane");
+    static_assert(KR == 1 || KR == 2 || KR == 4 || KR == 8, "top list: 64 * KR keys in KR registers per lane");
     __shared__ unsigned long long stage_all[4][128];
-    constexpr int ROWCAP2 = 2 * 11 * 11;  // two spans per row; boxes of up to 11 x 11 rows take the flat walk
+    // two spans per row; boxes of up to 11 x 11 rows take the flat walk -- up to the largest cube (19 x 19) for
+    // the big-K instantiations, whose sparse neighbourhoods need it
+    constexpr int ROWCAP2 = KR <= 2 ? 2 * 11 * 11 : 2 * (2 * GRID_KMAX + 3) * (2 * GRID_KMAX + 3);
     __shared__ unsigned int tab_s_all[4][ROWCAP2], tab_o_all[4][ROWCAP2], win_all[4][64];
     unsigned int* tab_s = tab_s_all[threadIdx.x >> 6];
     unsigned int* tab_o = tab_o_all[threadIdx.x >> 6];
@@ -180,7 +185,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
         const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
         const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
-        // first pass: the smallest cube that holds at least `want` points (its K-th key is then an upper
+        // first pass: the smallest cube that holds at least 2 x `want` points (its K-th key is then an upper
         // bound); the second pass covers what the ball of that bound adds around the cube.  Every pass scans
         // its box MINUS the box already scanned, so no point is seen twice and nothing is rescanned.
         int k = 1;
@@ -195,7 +200,9 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 cnt += cell_start[row + x1 + 1] - cell_start[row + x0];
             }
             cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(cnt), 63);
-            if (cnt >= (unsigned int)want || k >= GRID_KMAX) break;
+            // (twice `want`: with barely `want` points in the cube the K-th of them sits in a corner and the
+            // ball of that bound is several times the cube -- for large K in sparse regions wider than KMAX cells)
+            if (cnt >= 2u * (unsigned int)want || k >= GRID_KMAX) break;
         }
         unsigned long long top[KR];
 #pragma unroll
@@ -336,12 +343,12 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
             } else {
                 // fewer than `want` points so far: a bigger cube
                 k = k >= 2 ? 2 * k : k + 1;
-                if (k > GRID_KMAX) go_whole = true;
+                if (k > KNN_BOX_MAX) go_whole = true;
                 x0 = max(cx - k, 0); x1 = min(cx + k, g.dim[0] - 1);
                 y0 = max(cy - k, 0); y1 = min(cy + k, g.dim[1] - 1);
                 z0 = max(cz - k, 0); z1 = min(cz + k, g.dim[2] - 1);
             }
-            if (!go_whole && (x1 - x0 > 2 * GRID_KMAX + 2 || y1 - y0 > 2 * GRID_KMAX + 2 || z1 - z0 > 2 * GRID_KMAX + 2)) go_whole = true;
+            if (!go_whole && (x1 - x0 > 2 * KNN_BOX_MAX || y1 - y0 > 2 * KNN_BOX_MAX || z1 - z0 > 2 * KNN_BOX_MAX)) go_whole = true;
             if (!go_whole && 2 * (y1 - y0 + 1) * (z1 - z0 + 1) > ROWCAP2) {
                 ix0 = iy0 = iz0 = 1; ix1 = iy1 = iz1 = 0;  // too many rows for the table: this box row by row, from scratch
             }
@@ -370,15 +377,17 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
-    if (K <= 128) {
+    if (K <= 512) {
         unsigned int gw = (n + 3) / 4;  // one wave per query, 4 waves per workgroup, waves loop
         if (gw > 8192) gw = 8192;
-        if (K <= 64)
-            hipLaunchKernelGGL((k_grid_knn_wave<1>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                               ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, keys);
-        else
-            hipLaunchKernelGGL((k_grid_knn_wave<2>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                               ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, keys);
+#define PCC_LAUNCH_KNN(KR)                                                                                         \
+    hipLaunchKernelGGL((k_grid_knn_wave<KR>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),               \
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, keys)
+        if (K <= 64) PCC_LAUNCH_KNN(1);
+        else if (K <= 128) PCC_LAUNCH_KNN(2);
+        else if (K <= 256) PCC_LAUNCH_KNN(4);
+        else PCC_LAUNCH_KNN(8);
+#undef PCC_LAUNCH_KNN
     } else
     hipLaunchKernelGGL(k_grid_knn, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                        ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, K, keys);

@@ -17,7 +17,7 @@ def _scene(n, seed=synth.SEED_A):
     return synth.corridor_cloud(n, seed)
 
 
-@pytest.mark.parametrize("k", [1, 5, 51, 128])
+@pytest.mark.parametrize("k", [1, 5, 51, 128, 129, 200, 256, 257, 400, 512, 513])
 def test_knn_matches_exhaustive(gpu, k):
     a = _scene(30000)
     b = _scene(2000, synth.SEED_B)
