@@ -297,3 +297,53 @@ def test_sac_plane_restatement():
     assert abs(abs(c3[2]) - 1) < 0.02
     # fewer than three points -> no model
     assert len(oracle.sac_plane(pts[:2])[0]) == 0
+
+
+def test_voxel_grid_restatement_against_numpy_groupby():
+    """independent route: numpy lexsort + reduceat in float64 over the same leaf lattice"""
+    rng = np.random.default_rng(9)
+    pts = (rng.random((20000, 3)) * [3.0, 2.0, 1.0] - [1.0, 0.5, 0.2]).astype(np.float32)
+    leaf = np.float32(0.05)
+    out, nv = oracle.voxel_grid(pts, float(leaf))
+    inv = np.float32(1.0) / leaf
+    ijk = np.floor(pts * inv).astype(np.int64)
+    ijk -= ijk.min(0)
+    dims = ijk.max(0) + 1
+    key = ijk[:, 0] + ijk[:, 1] * dims[0] + ijk[:, 2] * dims[0] * dims[1]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.r_[0, np.nonzero(np.diff(ks))[0] + 1]
+    cnt = np.diff(np.r_[starts, len(ks)])
+    cen = np.add.reduceat(pts[order].astype(np.float64), starts, axis=0) / cnt[:, None]
+    assert nv == len(starts)
+    np.testing.assert_allclose(out[:, :3], cen, rtol=0, atol=2e-6)  # ascending voxel index, float sums vs double
+
+
+def test_region_growing_restatement_equals_components_when_edges_are_symmetric():
+    """independent route: with curvature threshold 1 and a SYMMETRIC neighbour relation the regions are the
+    connected components of the smooth-edge graph (scipy), whatever the seed order"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    rng = np.random.default_rng(4)
+    n, k = 3000, 7
+    # symmetric neighbour rows: a ring lattice i +- 1, 2, 3
+    nbr = np.stack([(np.arange(n) + d) % n for d in (0, 1, -1, 2, -2, 3, -3)], 1).astype(np.int32)
+    nrm = np.zeros((n, 4), np.float32)
+    ang = np.cumsum(rng.normal(0, 0.08, n))  # slowly turning normals with occasional jumps
+    ang[rng.random(n) < 0.02] += 1.0
+    ang = np.cumsum(np.r_[0, np.diff(ang)])
+    nrm[:, 0], nrm[:, 1] = np.cos(ang), np.sin(ang)
+    nrm[:, 3] = rng.random(n) * 0.3
+    theta = 0.15
+    lab, ncl = oracle.region_growing(nrm, nbr, theta, 1.0, 1, n)
+    rows, cols = [], []
+    for j in range(1, k):
+        d = np.abs((nrm[:, :3] * nrm[nbr[:, j], :3]).sum(1))
+        ok = ~(d < np.cos(np.float32(theta)))
+        rows += list(np.arange(n)[ok]); cols += list(nbr[ok, j])
+    g = coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    nc, comp = connected_components(g, directed=True, connection="weak")
+    assert ncl == nc
+    # same partition: labels are a relabelling of the components
+    pairs = set(zip(lab.tolist(), comp.tolist()))
+    assert len(pairs) == nc
