@@ -57,7 +57,7 @@ enum pcc_mem { PCC_MEM_HOST = 0, PCC_MEM_DEVICE = 1 };
  *   AUTO : GRID when the cloud is large enough to amortise its build. */
 enum pcc_engine { PCC_ENGINE_AUTO = 0, PCC_ENGINE_BRUTE = 1, PCC_ENGINE_GRID = 2 };
 
-#define PCC_KNN_MAX_K 65536 /* tuned for k <= 128; larger k works, O(k) per insertion */
+#define PCC_KNN_MAX_K 65536 /* k <= 512: wave-cooperative selection; larger k works, one lane per query with O(k) insertion */
 
 int pcc_version(void);
 /* thread-local message for the last non-OK status returned on this thread */
