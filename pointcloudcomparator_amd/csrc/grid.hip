@@ -141,13 +141,6 @@ int sync_info(pcc_index* ix) {
     return PCC_OK;
 }
 
-static inline int grid1d(size_t n) {
-    size_t b = (n + 255) / 256;
-    if (b < 1) b = 1;
-    if (b > 4096) b = 4096;
-    return (int)b;
-}
-
 constexpr int SEED_STRIDE = PCC_SEED_STRIDE;
 constexpr int FAR_SPAN = 1024;
 
