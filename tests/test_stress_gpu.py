@@ -98,3 +98,34 @@ def test_random_operation_sequences(gpu, seed):
             assert (idx == oi).all(), (step, op)
             assert abs(sums[16] - len(q)) < 0.5 and abs(sums[15] - od.astype(np.float64).sum()) <= 1e-9 * max(1.0, sums[15])
     ix.close()
+
+
+def test_distinct_handles_from_concurrent_threads(gpu):
+    """one handle = one stream, handles are not thread-safe, DISTINCT handles are.  Four threads, each
+    with its own index, interleave searches (ctypes drops the GIL inside the calls)"""
+    import threading
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            ref = _cloud(rng, 20000 + 1000 * seed)
+            q = _cloud(rng, 3000)
+            oi, od = oracle.nn1_exhaustive(ref, q)
+            ki, kd = oracle.knn_exhaustive(ref, q[:200], 9)
+            with capi.Index(ref) as ix:
+                for _ in range(15):
+                    idx, d2 = ix.nn1(q)
+                    assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+                    a, b = ix.knn(q[:200], 9)
+                    assert (a == ki).all() and (_bits(b) == _bits(kd)).all()
+                    ix.set_input(ref)
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
