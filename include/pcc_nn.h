@@ -83,6 +83,17 @@ int pcc_index_size(const pcc_index *index, size_t *n_valid);
 /* run this index's work on a caller-owned hipStream_t (NULL = library stream) */
 int pcc_index_set_stream(pcc_index *index, void *hip_stream);
 int pcc_index_sync(pcc_index *index);
+/* Device-memory calls (PCC_MEM_DEVICE) are enqueued on the index's stream and return at once.  A caller
+ * that produces its inputs or consumes the outputs on ANOTHER stream of the same device orders the two
+ * without blocking the host (hipEventRecord + hipStreamWaitEvent):
+ *   pcc_index_wait_stream: work submitted to the index after this call starts only when everything
+ *     submitted so far to `producer_stream` (a hipStream_t; NULL = the legacy default stream) has finished;
+ *   pcc_stream_wait_index: work submitted to `consumer_stream` after this call waits for everything the
+ *     index has been asked to do so far.
+ * (The reference is single-threaded host code, src/comparator.cpp:571-577: this is what "the call has
+ * returned, the vectors are filled" becomes for asynchronous device buffers.) */
+int pcc_index_wait_stream(pcc_index *index, void *producer_stream);
+int pcc_stream_wait_index(pcc_index *index, void *consumer_stream);
 /* engine actually in use (PCC_ENGINE_BRUTE or PCC_ENGINE_GRID) */
 int pcc_index_engine(const pcc_index *index, int *engine);
 /* force the engine for subsequent searches on this index */

@@ -1001,7 +1001,8 @@ size_t orc_sor(const void *pts, size_t n, size_t stride, int mean_k, double stdd
         ++valid;
     }
     double sum = 0, sq = 0;
-    for (size_t i = 0; i < n; ++i) { sum += mean_dist[i]; sq += (double)mean_dist[i] * mean_dist[i]; }
+    /* PCL: sq_sum += distances[i] * distances[i] -- a float product (rounded to float), widened for the sum */
+    for (size_t i = 0; i < n; ++i) { const float f = mean_dist[i]; sum += f; sq += (double)(f * f); }
     double mean = sum / (double)valid;
     double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
     double thr = mean + stddev_mult * sqrt(var);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
-    "pcc_normals_radius",
+    "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index",
 ]
 
 
@@ -70,6 +70,8 @@ def _load() -> C.CDLL:
     lib.pcc_index_size.argtypes = [vp, C.POINTER(sz)]
     lib.pcc_index_set_stream.argtypes = [vp, vp]
     lib.pcc_index_sync.argtypes = [vp]
+    lib.pcc_index_wait_stream.argtypes = [vp, vp]
+    lib.pcc_stream_wait_index.argtypes = [vp, vp]
     lib.pcc_index_engine.argtypes = [vp, C.POINTER(i32)]
     lib.pcc_index_set_engine.argtypes = [vp, i32]
     lib.pcc_index_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -157,19 +159,48 @@ def rigid_from_sums(sums):
 class Index:
     """Owner of one pcc_index handle (the role pcl::KdTreeFLANN plays in the reference)."""
 
-    def __init__(self, points, engine: int = ENGINE_AUTO, device: int = 0):
+    def __init__(self, points, engine: int = ENGINE_AUTO, device: int = 0, auto_sync: bool = True):
+        """auto_sync: calls that take torch CUDA tensors are ordered against torch's current stream on both
+        sides (inputs produced by torch are complete before the library reads them; torch work issued after the
+        call sees the outputs) with pcc_index_wait_stream / pcc_stream_wait_index -- two event records per call,
+        no host wait.  A caller that brackets its calls with sync() itself (bench.py's timed region) turns it off."""
         ptr, n, stride, mem = _points(points)
         if _is_torch(points) and points.is_cuda:
             device = points.device.index or 0
+            import torch
+            torch.cuda.current_stream(points.device).synchronize()  # create is synchronous anyway
         h = C.c_void_p()
         _check(LIB.pcc_index_create(ptr, n, stride, 3, mem, device, engine, C.byref(h)))
         self._h = h
         self.n_original = n
+        self.auto_sync = auto_sync
+
+    def _torch_stream(self, *tensors):
+        """hipStream_t of torch's current stream on the device of the first CUDA tensor argument (None: no
+        device tensor involved, or auto_sync off)."""
+        if not self.auto_sync:
+            return None
+        for t in tensors:
+            if t is not None and _is_torch(t) and t.is_cuda:
+                import torch
+                return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return None
+
+    def _before(self, *tensors):
+        st = self._torch_stream(*tensors)
+        if st is not None:
+            _check(LIB.pcc_index_wait_stream(self._h, st))
+        return st
+
+    def _after(self, st):
+        if st is not None:
+            _check(LIB.pcc_stream_wait_index(self._h, st))
 
     def set_input(self, points):
         """pcl::KdTreeFLANN::setInputCloud on an existing object: rebuild over a new cloud,
         reusing the device allocations."""
         ptr, n, stride, mem = _points(points)
+        self._before(points)
         _check(LIB.pcc_index_set_input(self._h, ptr, n, stride, 3, mem))
         self.n_original = n
 
@@ -234,20 +265,26 @@ class Index:
             out_d2, pd = _out(queries, (n,), np.float32)
         else:
             pd = out_d2.data_ptr() if _is_torch(out_d2) else out_d2.ctypes.data
+        st = self._before(queries, out_idx, out_d2)
         _check(LIB.pcc_nn1(self._h, ptr, n, stride, mem, pi, pd))
+        self._after(st)
         return out_idx, out_d2
 
     def knn(self, queries, k: int):
         ptr, n, stride, mem = _points(queries)
         idx, pi = _out(queries, (n, k), np.int32)
         d2, pd = _out(queries, (n, k), np.float32)
+        st = self._before(queries)
         _check(LIB.pcc_knn(self._h, ptr, n, stride, mem, k, pi, pd))
+        self._after(st)
         return idx, d2
 
     def radius_count(self, queries, radius: float):
         ptr, n, stride, mem = _points(queries)
         cnt, pc = _out(queries, (n,), np.int32)
+        st = self._before(queries)
         _check(LIB.pcc_radius_count(self._h, ptr, n, stride, mem, float(radius), pc))
+        self._after(st)
         return cnt
 
     def voxel_grid(self, points, leaf: float, has_rgb: bool = False):
@@ -264,7 +301,9 @@ class Index:
         """lowest index of a reference within `radius` (double-precision test), -1 if none"""
         ptr, n, stride, mem = _points(queries)
         idx, pi = _out(queries, (n,), np.int32)
+        st = self._before(queries)
         _check(LIB.pcc_first_within(self._h, ptr, n, stride, mem, float(radius), pi))
+        self._after(st)
         return idx
 
     def radius_search(self, queries, radius: float, sorted: bool = True):
@@ -273,7 +312,8 @@ class Index:
         cnt = self.radius_count(queries, radius)
         if _is_torch(cnt):
             import torch
-            self.sync()  # device results are written on the library's stream, torch works on its own
+            if not self.auto_sync:
+                self.sync()  # device results are written on the library's stream, torch works on its own
             offs = torch.zeros(n + 1, dtype=torch.int64, device=cnt.device)
             offs[1:] = torch.cumsum(cnt.to(torch.int64), 0)
             total = int(offs[-1].item())
@@ -285,7 +325,9 @@ class Index:
             po = offs.ctypes.data
         idx, pi = _out(queries, (max(total, 1),), np.int32)
         d2, pd = _out(queries, (max(total, 1),), np.float32)
+        st = self._before(queries, offs)
         _check(LIB.pcc_radius_fill(self._h, ptr, n, stride, mem, float(radius), int(sorted), po, pi, pd))
+        self._after(st)
         return offs, idx[:total], d2[:total]
 
     def euclidean_clusters(self, tolerance: float, min_size: int, max_size: int, device_out=None,
@@ -298,8 +340,10 @@ class Index:
             pl, mem = labels.ctypes.data, MEM_HOST
         ncl = C.c_int32(0)
         sizes = np.zeros(max_sizes, dtype=np.int32)
+        st = self._before(device_out)
         _check(LIB.pcc_euclidean_clusters(self._h, float(tolerance), min_size, max_size, mem, pl,
                                           C.byref(ncl), sizes.ctypes.data, max_sizes))
+        self._after(st)
         return labels, ncl.value, sizes[:min(ncl.value, max_sizes)]
 
     def sor(self, mean_k: int = 50, stddev_mult: float = 1.5):
@@ -319,8 +363,10 @@ class Index:
         cnt = C.c_size_t(0)
         its = C.c_int(0)
         coeff = np.zeros(4, dtype=np.float32)
+        st = self._before(points)
         _check(LIB.pcc_sac_plane(self._h, ptr, n, stride, mem, max_iterations, float(threshold), float(probability),
                                  int(optimize), pi, C.byref(cnt), coeff.ctypes.data, C.byref(its)))
+        self._after(st)
         return inl[:cnt.value], coeff, its.value
 
     def normals(self, k: int = 50, viewpoint=None, device=None):
@@ -333,8 +379,11 @@ class Index:
         if device is not None:
             import torch
             out = torch.empty((self.n_original, 4), dtype=torch.float32, device=device)
+            st = self._before(out)
             _check(LIB.pcc_normals(self._h, k, vp, MEM_DEVICE, out.data_ptr()))
-            self.sync()
+            self._after(st)
+            if st is None:
+                self.sync()
             return out
         out = np.empty((self.n_original, 4), dtype=np.float32)
         _check(LIB.pcc_normals(self._h, k, vp, MEM_HOST, out.ctypes.data))
@@ -358,10 +407,13 @@ class Index:
             import torch
             assert normals.dtype == torch.float32 and normals.is_contiguous()
             labels = torch.empty(self.n_original, dtype=torch.int32, device=normals.device)
-            torch.cuda.current_stream(normals.device).synchronize()
+            st = self._before(normals)
+            if st is None:
+                torch.cuda.current_stream(normals.device).synchronize()
             _check(LIB.pcc_region_growing(self._h, normals.data_ptr(), MEM_DEVICE, k, np.float32(smoothness),
                                           np.float32(curvature_threshold), min_size, max_size, labels.data_ptr(),
                                           C.byref(ncl)))
+            self._after(st)
             return labels, ncl.value
         nm = np.ascontiguousarray(normals, dtype=np.float32)
         assert nm.shape == (self.n_original, 4)
@@ -380,7 +432,9 @@ class Index:
         else:
             idx = d2 = None
             pi = pd = None
+        st = self._before(src)
         _check(LIB.pcc_icp_step(self._h, ptr, n, stride, mem, pi, pd, sums))
+        self._after(st)
         return idx, d2, np.array(list(sums), dtype=np.float64)
 
     def transform(self, T, src, dst=None):
@@ -394,8 +448,10 @@ class Index:
                 dst = np.empty((n, 3), dtype=np.float32)
         dptr, dn, dstride, dmem = _points(dst)
         assert dn == n and dmem == mem
+        st = self._before(src, dst)
         _check(LIB.pcc_transform(self._h, Tm.ctypes.data_as(C.POINTER(C.c_float)), ptr, n, stride, dptr,
                                  dstride, mem))
+        self._after(st)
         return dst
 
     def icp_align(self, src, max_iter: int = 20, fixed: bool = False):
@@ -404,6 +460,7 @@ class Index:
         fit = C.c_double(0)
         it = C.c_int(0)
         conv = C.c_int(0)
+        self._before(src)  # (the call synchronises the index's stream before it returns)
         _check(LIB.pcc_icp_align(self._h, ptr, n, stride, mem, max_iter, int(fixed), T, C.byref(fit),
                                  C.byref(it), C.byref(conv)))
         return np.array(list(T), dtype=np.float32).reshape(4, 4), fit.value, it.value, bool(conv.value)
@@ -412,6 +469,7 @@ class Index:
         ptr, n, stride, mem = _points(des2)
         out = np.empty(n + 1, dtype=np.int32)
         sz = C.c_int32(0)
+        self._before(des2)
         _check(LIB.pcc_match_knn(self._h, ptr, n, stride, mem, np.float32(threshold), out.ctypes.data,
                                  C.byref(sz)))
         return out[:sz.value]

@@ -153,10 +153,7 @@ static int resolve_engine(int requested, size_t n) {
 // pack (+ per-workgroup bbox / non-finite counts) -> grid sizing ON THE DEVICE -> cell sort.
 // Non-finite points stay in place flagged w = -1 (no compaction: position == original index).
 // Host-visible facts (n_valid, bbox, grid) arrive through a pinned mirror; sync_info() waits.
-static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
-    ix->n_valid = 0;
-    ix->has_grid = false;
-    ix->n_orig = n;
+static int set_input_impl(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
     ev_next(ix);
     ev_mark(ix, EV_BUILD0);
     PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
@@ -169,6 +166,17 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     if (ix->engine == PCC_ENGINE_GRID) PCC_TRY(grid_build(ix));
     ev_mark(ix, EV_BUILD1);
     return PCC_OK;
+}
+// on any failure the index is left EMPTY (n_orig = 0: every search then answers PCC_ERR_EMPTY instead of
+// launching over buffers a failed reserve() has freed)
+static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
+    ix->n_valid = 0;
+    ix->has_grid = false;
+    ix->order_valid = false;
+    ix->n_orig = n;  // the build steps size their launches from it
+    const int st = set_input_impl(ix, pts, n, stride, mem);
+    if (st != PCC_OK) { ix->n_orig = 0; ix->has_grid = false; }
+    return st;
 }
 
 }  // namespace pcc
@@ -204,6 +212,7 @@ int pcc_index_destroy(pcc_index* ix) {
     ix->host_b.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     if (ix->h_grid) (void)hipHostFree(ix->h_grid);
+    if (ix->edge_ev) (void)hipEventDestroy(ix->edge_ev);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
     return PCC_OK;
@@ -304,6 +313,22 @@ int pcc_index_set_stream(pcc_index* ix, void* s) {
     PCC_HIP(hipStreamSynchronize(ix->stream));
     ix->stream = s ? static_cast<hipStream_t>(s) : ix->own_stream;
     return PCC_OK;
+}
+// order the index's stream against another stream of the same device without blocking the host
+static int stream_edge(pcc_index* ix, hipStream_t from, hipStream_t to) {
+    if (from == to) return PCC_OK;
+    if (!ix->edge_ev) PCC_HIP(hipEventCreateWithFlags(&ix->edge_ev, hipEventDisableTiming));
+    PCC_HIP(hipEventRecord(ix->edge_ev, from));
+    PCC_HIP(hipStreamWaitEvent(to, ix->edge_ev, 0));
+    return PCC_OK;
+}
+int pcc_index_wait_stream(pcc_index* ix, void* producer) {
+    PCC_ENTER(ix);
+    return stream_edge(ix, static_cast<hipStream_t>(producer), ix->stream);
+}
+int pcc_stream_wait_index(pcc_index* ix, void* consumer) {
+    PCC_ENTER(ix);
+    return stream_edge(ix, ix->stream, static_cast<hipStream_t>(consumer));
 }
 int pcc_index_sync(pcc_index* ix) {
     PCC_ENTER(ix);
@@ -690,7 +715,7 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     PCC_TRY(sync_info(ix));
     size_t valid = ix->n_valid >= (size_t)K ? ix->n_valid : 0;
     double sum = 0, sq = 0;
-    for (size_t i = 0; i < no; ++i) { const double d = hm[i]; sum += d; sq += d * d; }
+    for (size_t i = 0; i < no; ++i) { const float f = hm[i]; sum += f; sq += (double)(f * f); }  // PCL squares in float (distances[i] * distances[i]), then widens
     double mean = sum / (double)valid;
     double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
     double thr = mean + stddev_mult * std::sqrt(var);

@@ -80,6 +80,7 @@ struct pcc_index {
     int device = 0;
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // library-owned stream
+    hipEvent_t edge_ev = nullptr;      // pcc_index_wait_stream / pcc_stream_wait_index
     size_t n_orig = 0;                 // points handed to pcc_index_create / set_input
     size_t n_valid = 0;                // finite points (PCL total_nr_points_); valid after sync_info()
     unsigned int nc_cap = 0;           // upper bound of the grid's cell count the host sizes launches with

@@ -77,7 +77,8 @@ int voxel_grid(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(ix->q_raw.reserve(n * stride));
-        PCC_HIP(hipMemcpyAsync(ix->q_raw.p, pts, n * stride, hipMemcpyHostToDevice, s));
+        // a strided host view may end with its last row: copy up to the last byte read (x, y, z [, rgb at 16]), not n rows
+        PCC_HIP(hipMemcpyAsync(ix->q_raw.p, pts, (n - 1) * stride + (has_rgb ? 20 : 12), hipMemcpyHostToDevice, s));
         src = ix->q_raw.p;
     }
     int nblk = 0;

@@ -60,7 +60,8 @@ inline int loadPLYFile(const std::string& path, PointCloud<PointXYZRGB>& cloud) 
             ble = fmt == "binary_little_endian";
             if (!ascii && !ble) return -1;
         } else if (tok == "element") {
-            std::string name; size_t cnt; ls >> name >> cnt;
+            std::string name; size_t cnt = 0;
+            if (!(ls >> name >> cnt)) return -1;  // a count that does not parse is a broken header, not a size
             in_vertex = name == "vertex";
             if (in_vertex) { nvert = cnt; vertex_first = !seen_element; }
             seen_element = true;
@@ -84,6 +85,18 @@ inline int loadPLYFile(const std::string& path, PointCloud<PointXYZRGB>& cloud) 
         else if (n == "blue" || n == "b") ib = (int)i; else if (n == "rgb" || n == "rgba") irgb = (int)i;
     }
     if (ix < 0 || iy < 0 || iz < 0) return -1;
+    {   // the header is not trusted: the vertex count is bounded by what the rest of the file can hold
+        // (binary: whole records; ascii: at least "0 0 0\n" per vertex), so a corrupt count fails here
+        // with -1 like loadPLYFile does, instead of throwing from a giant allocation
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streampos end = f.tellg();
+        f.seekg(here);
+        if (here < 0 || end < here) return -1;
+        const size_t rest = (size_t)(end - here);
+        const size_t min_rec = ascii ? 2 * props.size() : (size_t)(stride > 0 ? stride : 1);
+        if (nvert > rest / (min_rec ? min_rec : 1) + 1) return -1;
+    }
     cloud.points.assign(nvert, PointXYZRGB());
     std::vector<double> vals(props.size());
     std::vector<char> rec(stride > 0 ? stride : 1);

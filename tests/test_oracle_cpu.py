@@ -162,9 +162,12 @@ def test_sor_threshold_arithmetic():
     ki, kd = oracle.knn_exhaustive(pts, pts[:20], 51)
     want = (np.sqrt(kd[:, 1:].astype(np.float64)).sum(1) / 50).astype(np.float32)
     assert np.allclose(md[:20], want, rtol=1e-6)
-    s, sq = md.astype(np.float64).sum(), (md.astype(np.float64) ** 2).sum()
+    # PCL: sum += distances[i] (float widened), sq_sum += distances[i] * distances[i] (a FLOAT product, widened);
+    # both accumulated in index order -- np.cumsum adds sequentially, np.sum would add pairwise
+    s = float(np.cumsum(md.astype(np.float64))[-1])
+    sq = float(np.cumsum((md * md).astype(np.float64))[-1])
     var = (sq - s * s / 3000) / 2999
-    assert abs(thr - (s / 3000 + 1.5 * np.sqrt(var))) < 1e-12
+    assert thr == s / 3000 + 1.5 * np.sqrt(var)
     assert kept == int((md <= thr).sum())
 
 
