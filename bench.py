@@ -6,34 +6,38 @@ One "step" = what the reference does per cloud pair on this path (src/comparator
 query per point of the query cloud.  Inputs (raw AoS clouds) are resident in HBM
 when the timed region starts; outputs (idx int32, d2 float32) stay in HBM.
 
-Single GPU:   python bench.py [--steps K --warmup W --config c2|c3|c4|c5]
-Multi GPU:    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
-              one rank per GPU; the reference cloud is broadcast once over RCCL/xGMI,
-              every rank searches its own shard of queries (weak scaling, no collective
-              inside the timed region).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
 
-Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit...,
-plus "roofline" (dominant kernel of the measured path, HIP-event timed on the library's
-stream), "cpu_baseline" (the oracle's FLANN-restatement kd-tree on this host, reported
-only) and "exhaustive" (the north-star tiled brute-force kernel on the same workload,
-priced against the non-FMA fp32 VALU peak that bounds it).
+Workload (BASELINE.json configs):
+  default       C3, 10M x 10M XYZRGB (north_star's target size) at every N: each rank searches its own
+                10M queries against the replicated 10M references (weak scaling, so the driver's
+                1/2/4/8 values are one curve).  `extra` adds, at N = 1: C2 (1M x 1M, with the
+                exhaustive north-star kernel on the same data), the C3 radius-0.05 clustering leg
+                (-e path, 5M object points) and C4 (50 fixed ICP iterations, 2M x 2M); at N > 1:
+                C5 (32M queries sharded over the ranks vs 8M references, BASELINE configs[4]).
+  --config cX   only that configuration as the measured workload, no extras (profiling).
+Multi GPU: one rank per GPU over RCCL.  `--gpus N` without a torch.distributed environment launches
+  the N ranks itself (python -m torch.distributed.run ... as a CHILD process, before this process
+  touches the GPU); under the driver's own launcher the ranks are used as they come.  The reference
+  cloud is broadcast once (outside the timed region), queries are sharded, no collective inside a step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit..., "roofline"
+(dominant kernel of the measured path, HIP-event timed on the library's stream) and "cpu_baseline"
+(the oracle's FLANN-restatement kd-tree on this host, reported only).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch  # noqa: E402  (import before the C-ABI so one HIP runtime is shared)
-
 ROOT = Path(__file__).resolve().parent
-sys.path.insert(0, str(ROOT))
-
-from pointcloudcomparator_amd import capi, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_NOFMA_PEAK_TOPS = 78.65   # 157.3 TFLOP/s fp32 vector peak / 2 (no FMA allowed: bit parity with FLANN)
@@ -44,19 +48,53 @@ CONFIGS = {
     "c1": (10_000, 10_000, 3, "C1: 10k x 10k XYZ, k=1"),
     "c2": (1_000_000, 1_000_000, 3, "C2: 1M x 1M XYZ, k=1 NN"),
     "c3": (10_000_000, 10_000_000, 8, "C3: 10M x 10M XYZRGB (32-B stride), k=1 NN"),
-    "c4": (2_000_000, 2_000_000, 3, "C4: 2M x 2M XYZ, k=1 NN (one ICP correspondence pass)"),
+    "c4": (2_000_000, 2_000_000, 3, "C4: 2M x 2M XYZ, -i ICP, 50 fixed iterations"),
     "c5": (8_000_000, 4_000_000, 3, "C5 shard: 4M queries per GPU vs 8M references"),
 }
+C5_TOTAL_QUERIES = 32_000_000
+# sources whose kernels the committed PMC passes describe; a profile taken from other sources is flagged stale
+PROFILED_SOURCES = ["grid.hip", "grid_device.hpp", "cellsort.hip", "nn1_brute.hip", "pack.hip"]
 
 
-def make_cloud(n, seed, floats, start=0):
-    pts = synth.corridor_cloud(n, seed, start=start)
-    return synth.with_rgb_stride(pts) if floats == 8 else pts
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="auto", choices=["auto"] + sorted(CONFIGS))
+    ap.add_argument("--engine", default="auto", choices=["auto", "grid", "brute"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-exhaustive", action="store_true", help="skip the exhaustive-kernel leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations of the default run")
+    return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`bench.py --gpus N` outside a torch.distributed environment: start the N ranks as a child process group.
+    Nothing here has touched the GPU (no torch.cuda call, libpcc_nn not loaded): the child is a fresh program."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def source_digest() -> str:
+    h = hashlib.sha256()
+    for name in PROFILED_SOURCES:
+        p = ROOT / "pointcloudcomparator_amd" / "csrc" / name
+        h.update(p.read_bytes() if p.exists() else b"")
+    return h.hexdigest()[:16]
 
 
 def load_pmc_traffic(kernel_key, workload_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*.json)."""
-    best = None
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json), and whether
+    that profile was taken from the kernel sources in this tree."""
+    best, stale = None, None
     for f in sorted((ROOT / "profiles").glob("*pmc_traffic*.json")):
         try:
             d = json.loads(f.read_text())
@@ -65,19 +103,19 @@ def load_pmc_traffic(kernel_key, workload_key):
         v = d.get(workload_key, {}).get(kernel_key)
         if v is not None:
             best = v
-    return best
+            stale = d.get("source_digest") != source_digest()
+    return best, stale
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--engine", default="auto", choices=["auto", "grid", "brute"])
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-exhaustive", action="store_true", help="skip the exhaustive-kernel leg")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
+    import torch  # (import before the C-ABI so one HIP runtime is shared)
+    sys.path.insert(0, str(ROOT))
+    from pointcloudcomparator_amd import capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -88,198 +126,284 @@ def main():
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank % ndev
     backend = os.environ.get("PCC_BENCH_BACKEND", "nccl" if world <= ndev else "gloo")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev_index)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
             if rank == 0:
                 print(f"[bench] note: {world} ranks on {ndev} GPU(s): backend {backend}, devices shared", file=sys.stderr)
-    else:
-        torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    n_gpus = world
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-
-    M, N, floats, desc = CONFIGS[args.config]
+    n_gpus = dist.get_world_size() if dist is not None else 1  # the ranks the process group actually holds
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but the process group has {n_gpus} rank(s); using {n_gpus}", file=sys.stderr)
+    bcast_name = "RCCL" if backend == "nccl" else backend
+    engine = {"auto": capi.ENGINE_AUTO, "grid": capi.ENGINE_GRID, "brute": capi.ENGINE_BRUTE}[args.engine]
     K, W = args.steps, args.warmup
 
-    # ---- inputs: reference cloud on rank 0, broadcast once over RCCL; queries sharded ----------
-    ref_host = make_cloud(M, synth.SEED_A, floats) if rank == 0 else None
-    ref = torch.empty((M, floats), dtype=torch.float32, device=dev)
-    if rank == 0:
-        ref.copy_(torch.from_numpy(ref_host))
-    bcast_ms = 0.0
-    if dist is not None:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        dist.broadcast(ref, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-    qry_host = make_cloud(N, synth.SEED_B, floats, start=rank * N)  # this rank's shard
-    qry = torch.from_numpy(qry_host).to(dev)
-    idx = torch.empty(N, dtype=torch.int32, device=dev)
-    d2 = torch.empty(N, dtype=torch.float32, device=dev)
+    def make_cloud(n, seed, floats, start=0, chunk=4_000_000):
+        parts = [synth.corridor_cloud(min(chunk, n - o), seed, start=start + o) for o in range(0, n, chunk)]
+        pts = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        return synth.with_rgb_stride(pts) if floats == 8 else pts
 
-    engine = {"auto": capi.ENGINE_AUTO, "grid": capi.ENGINE_GRID, "brute": capi.ENGINE_BRUTE}[args.engine]
-    ix = capi.Index(ref, engine=engine)
-    engine_name = {capi.ENGINE_GRID: "grid", capi.ENGINE_BRUTE: "brute"}[ix.engine]
-
-    def step():
-        ix.set_input(ref)       # index build over the resident reference cloud
-        ix.nn1(qry, idx, d2)    # N queries; asynchronous on the library's stream
-
-    def timed(fn, k):
-        ix.sync()
-        torch.cuda.synchronize()
+    def barrier():
         if dist is not None:
             dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(ix, fn, k):
+        """K calls bracketed by barrier + synchronize on both sides; seconds, max over ranks"""
+        ix.sync()
+        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(k):
             fn()
         ix.sync()
         torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def broadcast_refs(M, floats):
+        """the reference cloud: generated on rank 0, one broadcast to every rank (RCCL over xGMI)"""
+        ref_host = make_cloud(M, synth.SEED_A, floats) if rank == 0 else None
+        ref = torch.empty((M, floats), dtype=torch.float32, device=dev)
+        if rank == 0:
+            ref.copy_(torch.from_numpy(ref_host))
+        ms = 0.0
         if dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            t0 = time.perf_counter()
+            dist.broadcast(ref, src=0)
+            torch.cuda.synchronize()
+            ms = max_over_ranks((time.perf_counter() - t0) * 1e3)
+        return ref, ref_host, ms
 
-    for _ in range(W):
+    # ---- k = 1 NN step of one configuration -----------------------------------------------------------------
+    def run_nn(cfg, n_per_rank=None, steps=K, warmup=W, with_exhaustive=False, with_cpu=False):
+        M, N, floats, desc = CONFIGS[cfg]
+        if n_per_rank is not None:
+            N = n_per_rank
+        ref, ref_host, bcast_ms = broadcast_refs(M, floats)
+        qry_host = make_cloud(N, synth.SEED_B, floats, start=rank * N)  # this rank's shard of cloud B
+        qry = torch.from_numpy(qry_host).to(dev)
+        idx = torch.empty(N, dtype=torch.int32, device=dev)
+        d2 = torch.empty(N, dtype=torch.float32, device=dev)
+        # auto_sync off: the timed region brackets its calls with ix.sync() itself (no per-call event records)
+        ix = capi.Index(ref, engine=engine, auto_sync=False)
+        engine_name = {capi.ENGINE_GRID: "grid", capi.ENGINE_BRUTE: "brute"}[ix.engine]
+
+        def step():
+            ix.set_input(ref)       # index build over the resident reference cloud
+            ix.nn1(qry, idx, d2)    # N queries; asynchronous on the library's stream
+
+        for _ in range(warmup):
+            step()
+        # timed region: only the dominant kernel is bracketed by HIP events (2 per step, recorded by the library
+        # on its own stream into a ring, no sync); the full breakdown costs ~48 us per step and runs untimed after
+        ix.enable_timing(1)
+        dt = timed(ix, step, steps)
+        tm_main = ix.timing()
+        t0 = time.perf_counter()
         step()
-    # timed region: only the dominant kernel is bracketed by HIP events (2 per step, recorded by
-    # the library on its own stream into a ring, no sync); a full 10-event breakdown costs
-    # ~48 us per 0.4 ms step, so it runs in a second, untimed pass
-    ix.enable_timing(1)
-    dt = timed(step, K)
-    tm_main = ix.timing()     # tm_main[0] = average k_grid_nn1 / k_nn1_brute duration over the K timed steps
-    ix.enable_timing(2)
-    timed(step, min(K, 10))
-    tm = ix.timing()
-    tm[0] = tm_main[0]
-    ix.enable_timing(0)
-    stats = ix.stats()
-    ms_per_step = dt / K * 1e3
-    bcast_name = "RCCL" if backend == "nccl" else backend
-    value = N * n_gpus / (dt / K)
+        ix.sync()
+        rank_ms = (time.perf_counter() - t0) * 1e3   # this rank alone, no barrier
+        ix.enable_timing(2)
+        timed(ix, step, min(steps, 10))
+        tm = ix.timing()
+        tm[0] = tm_main[0]
+        ix.enable_timing(0)
+        stats = ix.stats()
+        dtq = timed(ix, lambda: ix.nn1(qry, idx, d2), steps)  # index kept (ICP builds the target tree once)
+        per_rank_ms = None
+        if dist is not None:
+            t = torch.zeros(n_gpus, dtype=torch.float64, device=dev)
+            t[rank] = rank_ms
+            dist.all_reduce(t)
+            per_rank_ms = [round(float(v), 4) for v in t.tolist()]
+        r = {
+            "workload": f"{desc}; step = index build + {N} queries per GPU vs {M} references",
+            "value": N * n_gpus / (dt / steps), "unit": "queries/s", "ms_per_step": dt / steps * 1e3,
+            "steps": steps, "engine": engine_name, "references": M, "queries_per_gpu": N,
+            "queries_total": N * n_gpus, "point_stride_bytes": floats * 4,
+            "query_only_queries_per_sec": N * n_gpus / (dtq / steps),
+            "build_ms": tm[3], "search_call_ms": tm[2], "query_sort_ms": tm[4], "main_kernel_ms": tm[0],
+            "fallback_queries": stats[1] if engine_name == "grid" else 0,
+            "broadcast_ms": bcast_ms, "broadcast_bytes": M * floats * 4 if dist is not None else 0,
+        }
+        if per_rank_ms is not None:
+            r["per_rank_ms_per_step"] = per_rank_ms
+        # ---- roofline of the dominant kernel of the measured path -----------------------------------------
+        if engine_name == "grid":
+            # k_grid_nn1: every reference point (16 B packed) has to be read at least once, every query read
+            # once (16 B packed + 4 B order) and its result written (8 B)
+            alg = 16.0 * M + 28.0 * N
+            ach = alg / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else 0.0
+            traffic, stale = load_pmc_traffic("k_grid_nn1", cfg)
+            r["roofline"] = {"kernel": "k_grid_nn1", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale, "kernel_ms": tm[0],
+                             "algorithmic_bytes": alg,
+                             "note": "pruned exact search, bound by L1 line lookups and L2->L1 fills of per-lane 16-byte "
+                                     "gathers (DESIGN.md 4.2); compulsory HBM bytes are a few % of the roof by construction"}
+        else:
+            ach = float(M) * N * OPS_PER_PAIR / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else 0.0
+            traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
+            r["roofline"] = {"kernel": "k_nn1_brute", "bound": "valu", "achieved": ach, "peak": VALU_NOFMA_PEAK_TOPS,
+                             "unit": "Top/s", "frac": ach / VALU_NOFMA_PEAK_TOPS, "traffic": traffic,
+                             "traffic_stale": stale, "kernel_ms": tm[0]}
+        res_idx = res_d2 = None
+        if rank == 0 and (with_cpu or with_exhaustive):
+            res_idx, res_d2 = idx.cpu().numpy(), d2.cpu().numpy()
+        # ---- exhaustive (north-star) kernel on the same workload ---------------------------------------------
+        if with_exhaustive and n_gpus == 1 and engine_name != "brute" and float(M) * N <= 4e12:
+            ix.set_engine(capi.ENGINE_BRUTE)
+            idx_b, d2_b = torch.empty_like(idx), torch.empty_like(d2)
+            ix.nn1(qry, idx_b, d2_b)
+            ix.enable_timing(1)
+            kb = 3
+            dtb = timed(ix, lambda: ix.nn1(qry, idx_b, d2_b), kb)
+            tb = ix.timing()
+            ix.enable_timing(0)
+            pairs = float(M) * N
+            ach = pairs * OPS_PER_PAIR / (tb[0] * 1e-3) / 1e12
+            same = bool((idx_b == idx).all().item() and (d2_b.view(torch.int32) == d2.view(torch.int32)).all().item())
+            traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
+            r["exhaustive"] = {
+                "kernel": "k_nn1_brute", "value": N / (dtb / kb), "unit": "queries/s", "ms_per_pass": dtb / kb * 1e3,
+                "pairs_per_sec": pairs / (tb[0] * 1e-3),
+                "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s",
+                             "frac": ach / VALU_NOFMA_PEAK_TOPS, "kernel_ms": tb[0], "traffic": traffic,
+                             "traffic_stale": stale, "ops_per_pair": OPS_PER_PAIR},
+                "bit_identical_to_grid": same}
+            ix.set_engine(engine)
+        # ---- CPU baseline: the oracle's kd-tree restatement on this host (reported only) ---------------------
+        if with_cpu and rank == 0 and n_gpus == 1:
+            import oracle
+            ncores = len(os.sched_getaffinity(0))
+            sample = min(N, 1_000_000)
+            t0 = time.perf_counter()
+            kd = oracle.KdTree(ref_host)
+            tb_cpu = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ci, cd = kd.nn1_batch(qry_host[:sample])
+            tq_cpu = time.perf_counter() - t0
+            cpu_rate = N / (tb_cpu + tq_cpu * (N / sample))  # the same step, queries extrapolated from the sample
+            t0 = time.perf_counter()
+            kd.nn1_batch(qry_host[:sample], nthreads=ncores)
+            tq_mt = time.perf_counter() - t0
+            r["cpu_baseline"] = {
+                "value": cpu_rate, "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": f"kd-tree build over all {M} references ({tb_cpu:.3f} s) + first {sample} of {N} queries "
+                          f"({tq_cpu:.3f} s), one thread, oracle/pcc_oracle.c (FLANN KDTreeSingleIndex restatement)",
+                "all_cores": {"cores": ncores, "query_only_queries_per_sec": sample / tq_mt},
+                "query_only_queries_per_sec": sample / tq_cpu,
+                "gpu_matches_cpu": {"d2_bits_equal": bool((cd.view(np.uint32) == res_d2[:sample].view(np.uint32)).all()),
+                                    "index_mismatches": int((ci != res_idx[:sample]).sum())}}
+            del kd
+        ix.close()
+        del ref, qry, idx, d2
+        torch.cuda.empty_cache()
+        return r
 
-    # query-only rate (index kept, as inside ICP where the target tree is built once)
-    dtq = timed(lambda: ix.nn1(qry, idx, d2), K)
-    query_only = N * n_gpus / (dtq / K)
+    # ---- C3's second half: radius-0.05 Euclidean clustering of the object layer (-e path) -------------------
+    def run_clusters(n=5_000_000, reps=3):
+        obj = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_A, layer="objects")).to(dev)
+        ix = capi.Index(obj, auto_sync=False)
+        labels = torch.empty(n, dtype=torch.int32, device=dev)
+        out = ix.euclidean_clusters(0.05, 100, 250000, device_out=labels)  # warm-up + result
+        ix.sync()
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ix.set_input(obj)  # the tree EuclideanClusterExtraction is handed (src/segmentation.cpp:120-122)
+            out = ix.euclidean_clusters(0.05, 100, 250000, device_out=labels)
+            ix.sync()
+            best = min(best, time.perf_counter() - t0)
+        lab, ncl, sizes = out
+        ix.close()
+        return {"workload": f"C3 -e leg: index build + EuclideanClusterExtraction(0.05, 100, 250000) over the {n} object-layer "
+                            "points of cloud A (known partition: the 256 balls)",
+                "ms": best * 1e3, "points_per_sec": n / best, "clusters": int(ncl),
+                "clusters_expected": synth.N_BALLS, "points_clustered": int(np.asarray(sizes).sum()),
+                "all_points_clustered": bool(int(np.asarray(sizes).sum()) == n)}
+
+    # ---- C4: -i ICP, 50 fixed iterations, 2M x 2M -------------------------------------------------------------
+    def run_icp(reps=2, iters=50):
+        M, N, floats, desc = CONFIGS["c4"]
+        tgt = torch.from_numpy(make_cloud(M, synth.SEED_A, floats)).to(dev)
+        src = torch.from_numpy(synth.rigid_offset(make_cloud(N, synth.SEED_B, floats))).to(dev)
+        ix = capi.Index(tgt, auto_sync=False)
+        ix.icp_align(src, max_iter=iters, fixed=True)
+        ix.enable_timing(2)
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            T, fit, it, conv = ix.icp_align(src, max_iter=iters, fixed=True)
+            best = min(best, time.perf_counter() - t0)
+        tm = ix.timing()  # averages over the passes of the last calls: [0] NN kernel, [1] far/fallback, [2] whole pass
+        ix.enable_timing(0)
+        ix.close()
+        passes = iters + 1  # + getFitnessScore
+        return {"workload": f"{desc}: pcc_icp_align(max_iter={iters}, fixed=1) = {iters} x (NN of every source point + "
+                            "Umeyama sums + transform) + the fitness pass, source resident in HBM",
+                "ms": best * 1e3, "iterations": int(it), "converged": bool(conv), "fitness": fit,
+                "ms_per_pass": best * 1e3 / passes, "nn_queries_per_sec": N * passes / best,
+                "split_ms_per_pass": {"nn_kernel": tm[0], "far_and_fallback": tm[1], "pass_total_events": tm[2],
+                                      "sums_reduce_transform": max(tm[2] - tm[0] - tm[1], 0.0)}}
+
+    primary_cfg = "c3" if args.config == "auto" else args.config
+    if primary_cfg == "c4":
+        prim = None
+        icp = run_icp()
+        value, ms_per_step, workload = icp["nn_queries_per_sec"], icp["ms"], icp["workload"]
+    else:
+        prim = run_nn(primary_cfg, with_exhaustive=(not args.no_exhaustive and args.config != "auto"),
+                      with_cpu=not args.no_cpu)
+        value, ms_per_step, workload = prim["value"], prim["ms_per_step"], prim["workload"]
 
     out = {
-        "metric": "nn_queries_per_sec",
-        "value": value,
-        "unit": "queries/s",
-        "n_gpus": n_gpus,
-        "steps": K,
-        "warmup": W,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"{desc}; step = index build + {N} queries per GPU vs {M} references",
-            "engine": engine_name,
-            "references": M,
-            "queries_per_gpu": N,
-            "point_stride_bytes": floats * 4,
-            "parallelism": f"query-sharded x{n_gpus}, reference cloud replicated ({bcast_name} broadcast {bcast_ms:.2f} ms, outside the timed region)",
-        },
-        "query_only_queries_per_sec": query_only,
-        "build_ms": tm[3],
-        "search_call_ms": tm[2],
-        "fallback_queries": stats[1] if engine_name == "grid" else 0,
+        "metric": "nn_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "name": primary_cfg,
+                   "parallelism": f"query-sharded x{n_gpus}, reference cloud replicated "
+                                  f"({bcast_name} broadcast, outside the timed region)"},
     }
+    if prim is not None:
+        for k in ("engine", "references", "queries_per_gpu", "queries_total", "point_stride_bytes"):
+            out["config"][k] = prim[k]
+        for k in ("query_only_queries_per_sec", "build_ms", "search_call_ms", "query_sort_ms", "fallback_queries",
+                  "broadcast_ms", "broadcast_bytes", "per_rank_ms_per_step", "roofline", "exhaustive", "cpu_baseline"):
+            if k in prim:
+                out[k] = prim[k]
+    else:
+        out["icp"] = icp
 
-    if rank == 0:
-        res_idx = idx.cpu().numpy()
-        res_d2 = d2.cpu().numpy()
-        wl_key = f"{args.config}"
-        # ---- roofline of the dominant kernel of the measured path ---------------------------
-        if engine_name == "grid":
-            # k_grid_nn1: every reference point (16 B packed) has to be read at least once,
-            # every query read once (16 B packed + 4 B order) and its result written (8 B)
-            alg_bytes = 16.0 * M + 28.0 * N
-            ach = alg_bytes / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else 0.0
-            out["roofline"] = {
-                "kernel": "k_grid_nn1", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": load_pmc_traffic("k_grid_nn1", wl_key),
-                "kernel_ms": tm[0], "algorithmic_bytes": alg_bytes,
-                "note": "pruned exact search: ~80 % of its time is L1 line lookups and L2->L1 fills of per-lane 16-byte gathers (csrc/ubench_gather.hip prices them; DESIGN.md 4.2); compulsory HBM bytes are a few % of the roof by construction",
-            }
+    if args.config == "auto" and not args.no_extra:
+        extra = {}
+        if n_gpus == 1:
+            extra["c2"] = run_nn("c2", with_exhaustive=not args.no_exhaustive, with_cpu=False)
+            extra["c3_clusters"] = run_clusters()
+            extra["c4_icp"] = run_icp()
         else:
-            pairs = float(M) * N
-            ach = pairs * OPS_PER_PAIR / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else 0.0
-            out["roofline"] = {
-                "kernel": "k_nn1_brute", "bound": "valu", "achieved": ach, "peak": VALU_NOFMA_PEAK_TOPS,
-                "unit": "Top/s", "frac": ach / VALU_NOFMA_PEAK_TOPS,
-                "traffic": load_pmc_traffic("k_nn1_brute", wl_key), "kernel_ms": tm[0],
-            }
+            # BASELINE configs[4]: 32M queries vs 8M references, sharded over the ranks present
+            c5 = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // n_gpus, steps=min(K, 10), warmup=2)
+            c5["scaling"] = "strong (32M queries in total, whatever the rank count)"
+            extra["c5"] = c5
+        out["extra"] = extra
 
-    # ---- exhaustive (north-star) kernel on the same workload, N=1 only -------------------------
-    if n_gpus == 1 and not args.no_exhaustive and engine_name != "brute" and M * N <= 4e12:
-        ix.set_engine(capi.ENGINE_BRUTE)
-        idx_b = torch.empty_like(idx)
-        d2_b = torch.empty_like(d2)
-        ix.nn1(qry, idx_b, d2_b)
-        ix.enable_timing(1)
-        kb = 3
-        dtb = timed(lambda: ix.nn1(qry, idx_b, d2_b), kb)
-        tb = ix.timing()
-        ix.enable_timing(0)
-        pairs = float(M) * N
-        ach = pairs * OPS_PER_PAIR / (tb[0] * 1e-3) / 1e12
-        same = bool((idx_b == idx).all().item() and (d2_b.view(torch.int32) == d2.view(torch.int32)).all().item())
-        out["exhaustive"] = {
-            "kernel": "k_nn1_brute", "value": N / (dtb / kb), "unit": "queries/s", "ms_per_pass": dtb / kb * 1e3,
-            "pairs_per_sec": pairs / (tb[0] * 1e-3),
-            "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s",
-                         "frac": ach / VALU_NOFMA_PEAK_TOPS, "kernel_ms": tb[0],
-                         "traffic": load_pmc_traffic("k_nn1_brute", args.config),
-                         "ops_per_pair": OPS_PER_PAIR},
-            "bit_identical_to_grid": same,
-        }
-        ix.set_engine(engine)
-
-    # ---- CPU baseline: the oracle's kd-tree restatement on this host (reported only) -----------
-    if rank == 0 and n_gpus == 1 and not args.no_cpu:
-        import oracle
-        ncores = len(os.sched_getaffinity(0))
-        sample = min(N, 1_000_000)
-        t0 = time.perf_counter()
-        kd = oracle.KdTree(ref_host)
-        tb_cpu = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        ci, cd = kd.nn1_batch(qry_host[:sample])
-        tq_cpu = time.perf_counter() - t0
-        # whole-job rate of the same step (build + all N queries), queries extrapolated from the sample
-        cpu_rate = N / (tb_cpu + tq_cpu * (N / sample))
-        t0 = time.perf_counter()
-        kd.nn1_batch(qry_host[:sample], nthreads=ncores)
-        tq_mt = time.perf_counter() - t0
-        d2_equal = bool((cd.view(np.uint32) == res_d2[:sample].view(np.uint32)).all())
-        idx_diff = int((ci != res_idx[:sample]).sum())
-        out["cpu_baseline"] = {
-            "value": cpu_rate, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"kd-tree build over all {M} references ({tb_cpu:.3f} s) + first {sample} of {N} queries "
-                      f"({tq_cpu:.3f} s), one thread, oracle/pcc_oracle.c (FLANN KDTreeSingleIndex restatement)",
-            "all_cores": {"cores": ncores, "query_only_queries_per_sec": sample / tq_mt},
-            "query_only_queries_per_sec": sample / tq_cpu,
-            "gpu_matches_cpu": {"d2_bits_equal": d2_equal, "index_mismatches": idx_diff},
-        }
-
-    ix.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -198,7 +198,7 @@ public:
         clusters.clear();
         if (!input_ || input_->empty()) return;
         if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
-        if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
+        if (!tree_->covers(input_)) tree_->setInputCloud(input_);
         if (!tree_->handle()) return;
         std::vector<int32_t> labels(input_->size());
         int32_t ncl = 0;
@@ -231,7 +231,7 @@ public:
         out.height = 1;
         if (!input_ || input_->empty() || (k_ < 1 && !(radius_ > 0))) return;
         if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
-        if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
+        if (!tree_->covers(input_)) tree_->setInputCloud(input_);
         if (!tree_->handle()) return;
         std::vector<float> nc(input_->size() * 4);
         if (k_ >= 1) check(pcc_normals(tree_->handle(), k_, vp_, PCC_MEM_HOST, nc.data()));
@@ -271,7 +271,7 @@ public:
         // PCL's prepareForSegmentation: no cloud, no normals or a size mismatch -> empty result
         if (!input_ || input_->empty() || !normals_ || normals_->size() != input_->size() || k_ == 0) return;
         if (!tree_) tree_.reset(new search::KdTree<PointT>(false));
-        if (tree_->getInputCloud() != input_ || !tree_->handle()) tree_->setInputCloud(input_);
+        if (!tree_->covers(input_)) tree_->setInputCloud(input_);
         if (!tree_->handle()) return;
         const size_t n = input_->size();
         std::vector<float> nc(n * 4);

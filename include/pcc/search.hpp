@@ -43,26 +43,43 @@ public:
     // A tree object can be pointed at a new cloud any number of times (PCL: cleanup() + rebuild);
     // the device handle, its stream and its buffers are kept and only the index is rebuilt, so a
     // long-lived tree (see matchRIFTFeaturesKnn) costs no allocation per call.
-    void setInputCloud(const CloudConstPtr& cloud) {
+    typedef std::shared_ptr<const std::vector<int>> IndicesConstPtr;
+
+    // pcl::search::Search<PointT>::setInputCloud(cloud, indices): with a non-empty index list
+    // the tree holds only cloud[indices[j]]; results still name points of `cloud` (PCL maps them back through
+    // index_mapping_ = indices), and nearestKSearch(int index, ...) takes its query from cloud[indices[index]].
+    void setInputCloud(const CloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) {
         input_ = cloud;
+        indices_ = indices;
         valid_ = false;
+        subset_.clear();
         if (!cloud || cloud->empty()) return;
+        const PointT* pts = cloud->points.data();
+        size_t n = cloud->size();
+        if (indices_ && !indices_->empty()) {
+            subset_.reserve(indices_->size());
+            for (int j : *indices_) subset_.push_back(cloud->points.at((size_t)j));
+            pts = subset_.data();
+            n = subset_.size();
+        }
         if (!index_) {
-            int st = pcc_index_create(cloud->points.data(), cloud->size(), sizeof(PointT), 3, PCC_MEM_HOST, device_,
-                                      engine_, &index_);
+            int st = pcc_index_create(pts, n, sizeof(PointT), 3, PCC_MEM_HOST, device_, engine_, &index_);
             if (st == PCC_ERR_EMPTY) { index_ = nullptr; return; }
             check(st);
             valid_ = true;
             return;
         }
-        check(pcc_index_set_input(index_, cloud->points.data(), cloud->size(), sizeof(PointT), 3, PCC_MEM_HOST));
+        check(pcc_index_set_input(index_, pts, n, sizeof(PointT), 3, PCC_MEM_HOST));
         size_t n_valid = 0;
         check(pcc_index_size(index_, &n_valid));  // waits for the build; 0 == PCL's "empty input cloud"
         valid_ = n_valid > 0;
     }
     CloudConstPtr getInputCloud() const { return input_; }
+    IndicesConstPtr getIndices() const { return indices_; }
     bool getSortedResults() const { return sorted_; }
     pcc_index* handle() const { return valid_ ? index_ : nullptr; }
+    // the device index holds every point of `cloud` (not a subset selected by an index list)
+    bool covers(const CloudConstPtr& cloud) const { return valid_ && input_ == cloud && subset_.empty(); }
 
     int nearestKSearch(const PointT& p, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const {
         if (!handle() || !isFinite(p)) { k_indices.clear(); k_sqr_distances.clear(); return 0; }  // PCL asserts here
@@ -74,10 +91,12 @@ public:
         if (k == 0) return 0;
         if (k == 1) check(pcc_nn1(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, k_indices.data(), k_sqr_distances.data()));
         else check(pcc_knn(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, k, k_indices.data(), k_sqr_distances.data()));
+        remap(k_indices);
         return k;
     }
     int nearestKSearch(int index, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const {
-        return nearestKSearch(input_->points.at(index), k, k_indices, k_sqr_distances);
+        const size_t at = subset_.empty() ? (size_t)index : (size_t)indices_->at((size_t)index);
+        return nearestKSearch(input_->points.at(at), k, k_indices, k_sqr_distances);
     }
     int radiusSearch(const PointT& p, double radius, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances,
                      unsigned int max_nn = 0) const {
@@ -94,6 +113,7 @@ public:
         check(pcc_radius_fill(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, (sorted_ || max_nn) ? 1 : 0, offs,
                               k_indices.data(), k_sqr_distances.data()));
         if (max_nn && (unsigned)cnt > max_nn) { k_indices.resize(max_nn); k_sqr_distances.resize(max_nn); cnt = (int32_t)max_nn; }
+        remap(k_indices);
         return cnt;
     }
 
@@ -103,15 +123,25 @@ public:
         d2.assign(queries.size(), 0.f);
         if (!handle() || queries.empty()) return;
         check(pcc_nn1(index_, queries.points.data(), queries.size(), sizeof(PointT), PCC_MEM_HOST, idx.data(), d2.data()));
+        remap(idx);
     }
     void nearestKSearchBatch(const PointCloud<PointT>& queries, int k, std::vector<int>& idx, std::vector<float>& d2) const {
         idx.assign(queries.size() * (size_t)k, -1);
         d2.assign(queries.size() * (size_t)k, 0.f);
         if (!handle() || queries.empty()) return;
         check(pcc_knn(index_, queries.points.data(), queries.size(), sizeof(PointT), PCC_MEM_HOST, k, idx.data(), d2.data()));
+        remap(idx);
     }
 
 private:
+    // positions in the indexed subset -> indices of the input cloud (identity without an index list)
+    void remap(std::vector<int>& idx) const {
+        if (subset_.empty()) return;
+        for (int& v : idx)
+            if (v >= 0) v = (*indices_)[(size_t)v];
+    }
+    IndicesConstPtr indices_;
+    std::vector<PointT> subset_;  // cloud[indices]: what the device index was built from
     bool sorted_;
     int device_, engine_;
     CloudConstPtr input_;

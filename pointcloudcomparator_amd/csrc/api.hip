@@ -907,8 +907,6 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     if (iterations) *iterations = 0;
     if (converged) *converged = 0;
     if (n == 0) return PCC_OK;
-    ev_next(ix);
-    ev_mark(ix, EV_CALL0);
     // the source stays resident: q_packed is the moving cloud, icp_src keeps the input
     PCC_TRY(stage_queries(ix, src, n, stride, mem));
     PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
@@ -922,12 +920,15 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; }
     } keep_order_guard(ix);
     while (it < max_iter) {
+        ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)
+        ev_mark(ix, EV_CALL0);
         PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
         double sums[17];
         PCC_TRY(icp_reduce(ix, n, sums));
         float Ti[16];
         if (rigid_from_sums(sums, Ti) != 0) { conv = false; break; }  // < 3 correspondences: not converged
         PCC_TRY(launch_transform(ix->stream, nullptr, Ti, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
+        ev_mark(ix, EV_CALL1);
         mat4_mul_f(Ti, T, T);  // final = T_i * final
         const double mse = sums[15] / sums[16];
         ++it;
@@ -942,12 +943,14 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         PCC_TRY(launch_transform(ix->stream, nullptr, T, ix->icp_src.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
         // launch_transform writes x,y,z only: refresh the validity flags from the input
         PCC_TRY(launch_copy_w(ix->stream, ix->icp_src.as<float4>(), ix->q_packed.as<float4>(), n));
+        ev_next(ix);
+        ev_mark(ix, EV_CALL0);
         PCC_TRY(nn1_packed(ix, n));
         double sums[17];
         PCC_TRY(icp_reduce(ix, n, sums));
+        ev_mark(ix, EV_CALL1);
         *fitness = sums[16] > 0 ? sums[15] / sums[16] : 1.79769313486231570e308;
     }
-    ev_mark(ix, EV_CALL1);
     PCC_HIP(hipStreamSynchronize(ix->stream));
     return PCC_OK;
 }

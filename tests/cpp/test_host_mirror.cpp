@@ -50,6 +50,45 @@ int main() {
     REQUIRE(cnt == nr);
     REQUIRE(tree->nearestKSearch(cloud->points[0], 5000, idx, d2) == (int)cloud->size());  // k clamped
 
+    // setInputCloud(cloud, indices) (pcl::search::Search): the tree holds the listed points only,
+    // results name points of the whole cloud, nearestKSearch(int) takes cloud[indices[i]] as the query
+    {
+        std::shared_ptr<std::vector<int>> sel(new std::vector<int>);
+        for (int i = 1; i < (int)cloud->size(); i += 3) sel->push_back(i);
+        search::KdTree<PointXYZRGB> sub;
+        sub.setInputCloud(cloud, sel);
+        REQUIRE(sub.nearestKSearch(cloud->points[7], 1, idx, d2) == 1 && idx[0] == 7 && d2[0] == 0.f);  // 7 = 1 + 2*3 is listed
+        REQUIRE(sub.nearestKSearch(cloud->points[8], 4, idx, d2) == 4);
+        for (int j = 0; j < 4; ++j) {
+            REQUIRE(idx[j] % 3 == 1 && d2[j] == brute_d2(cloud->points[8], cloud->points[idx[j]]));
+            REQUIRE(j == 0 || d2[j] >= d2[j - 1]);
+        }
+        float best = 1e30f; int arg = -1;
+        for (int i : *sel) { float d = brute_d2(cloud->points[8], cloud->points[i]); if (d < best) { best = d; arg = i; } }
+        REQUIRE(idx[0] == arg && d2[0] == best);
+        REQUIRE(sub.nearestKSearch(2, 1, idx, d2) == 1 && idx[0] == (*sel)[2] && d2[0] == 0.f);  // query = cloud[indices[2]]
+        int nrs = sub.radiusSearch(cloud->points[7], 0.05, idx, d2);
+        int want = 0;
+        for (int i : *sel) want += brute_d2(cloud->points[7], cloud->points[i]) < (float)(0.05 * 0.05);
+        REQUIRE(nrs == want && idx[0] == 7);
+        for (int v : idx) REQUIRE(v % 3 == 1);
+        REQUIRE(sub.nearestKSearch(cloud->points[0], 5000, idx, d2) == (int)sel->size());  // k clamped to the subset
+        sub.setInputCloud(cloud);  // back to the whole cloud
+        REQUIRE(sub.nearestKSearch(cloud->points[8], 1, idx, d2) == 1 && idx[0] == 8);
+    }
+    // pcl::PointXYZ: 16-byte stride
+    {
+        static_assert(sizeof(PointXYZ) == 16, "pcl::PointXYZ is 16 bytes");
+        PointCloud<PointXYZ>::Ptr xyz(new PointCloud<PointXYZ>);
+        for (auto& p : cloud->points) { PointXYZ v; v.x = p.x; v.y = p.y; v.z = p.z; xyz->push_back(v); }
+        KdTreeFLANN<PointXYZ> t16;
+        t16.setInputCloud(xyz);
+        std::vector<int> i16; std::vector<float> d16;
+        t16.nearestKSearchBatch(*xyz, i16, d16);
+        for (size_t i = 0; i < xyz->size(); ++i) REQUIRE(d16[i] == 0.f);
+        REQUIRE(t16.nearestKSearch(xyz->points[11], 3, idx, d2) == 3 && idx[0] == 11);
+    }
+
     // EuclideanClusterExtraction (src/segmentation.cpp:125-131)
     EuclideanClusterExtraction<PointXYZRGB> ec;
     ec.setClusterTolerance(0.05); ec.setMinClusterSize(100); ec.setMaxClusterSize(250000);

@@ -121,6 +121,84 @@ def test_c4_icp_fixed_iterations_consistent_with_stepwise(gpu):
     assert np.allclose(T, Tacc, atol=5e-5)
 
 
+def _mat4_mul_f32(a, b):
+    """float 4x4 product with the accumulation order of the library's mat4_mul_f (k ascending, one float accumulator)"""
+    out = np.zeros((4, 4), dtype=np.float32)
+    for r in range(4):
+        for c in range(4):
+            acc = np.float32(0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(a[r, k] * b[k, c]))
+            out[r, c] = acc
+    return out
+
+
+def test_c4_icp_50_iterations_2m_x_2m(gpu):
+    """BASELINE configs[3] at its full size: -i ICP, 50 fixed iterations, 2M source points against 2M targets
+    (reference src/comparator.cpp:1089-1099).  The device-resident loop is replayed pass by pass through the step
+    API (same correspondences => the same transform, bit for bit), the correspondences of the first and of the
+    last pass are checked against the CPU kd-tree on a fixed sample, and the oracle's Umeyama agrees with the
+    library's Horn solution on those passes."""
+    tgt = synth.corridor_cloud(2_000_000, synth.SEED_A)
+    src = synth.rigid_offset(synth.corridor_cloud(2_000_000, synth.SEED_B))
+    tt, ts = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
+    tree = oracle.KdTree(tgt)
+    sel = np.sort(np.random.default_rng(50).choice(len(src), size=20000, replace=False))
+    with capi.Index(tt) as ix:
+        T, fit, it, conv = ix.icp_align(ts, max_iter=50, fixed=True)
+        assert it == 50 and conv
+        cur = ts.clone()
+        Tacc = np.eye(4, dtype=np.float32)
+        mse = []
+        for p in range(50):
+            want_corr = p in (0, 49)
+            ci, cd, sums = ix.icp_step(cur, want_corr=want_corr)
+            assert sums[16] == len(src)  # every source point has a correspondence (no distance threshold)
+            mse.append(sums[15] / sums[16])
+            Ti = capi.rigid_from_sums(sums)
+            if want_corr:
+                q = np.ascontiguousarray(cur.cpu().numpy()[sel])
+                oi, od = tree.nn1_batch(q)
+                gi, gd = ci.cpu().numpy()[sel], cd.cpu().numpy()[sel]
+                assert (_bits(gd) == _bits(od)).all()
+                for j in np.nonzero(gi != oi)[0]:  # exact-distance ties only, lowest index on the GPU side
+                    assert gi[j] < oi[j] and _bits(oracle.nn1_exhaustive(tgt[oi[j]:oi[j] + 1], q[j:j + 1])[1])[0] == _bits(od)[j]
+                rc, To = oracle.umeyama_from_sums(sums)
+                assert rc == 0 and np.allclose(Ti, To, atol=2e-5)
+            cur = ix.transform(Ti, cur)
+            Tacc = _mat4_mul_f32(Ti, Tacc)
+        # getFitnessScore: the INPUT moved by the final matrix, one more NN pass, mean squared distance
+        _, _, fs = ix.icp_step(ix.transform(T, ts), want_corr=False)
+    assert (T.view(np.uint32) == Tacc.view(np.uint32)).all()
+    assert fit == fs[15] / fs[16]
+    assert mse[-1] < mse[0]  # (the floor is the sampling distance of two different samples of the scene, not zero)
+    R = T[:3, :3].astype(np.float64)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+    ang = np.degrees(np.arctan2(R[1, 0], R[0, 0]))
+    # rigid_offset turned cloud B by +2 degrees: the loop turns it back (point-to-point ICP between two different
+    # samples of a scene creeps -- about half of the angle after 50 passes -- so only the direction is pinned)
+    assert -2.2 < ang < -0.5 and T[0, 3] < 0 < T[1, 3], (ang, T[:3, 3])
+
+
+def test_c5_one_full_shard_4m_vs_8m(gpu):
+    """BASELINE configs[4]: one of the 8 shards at its real size -- 4M queries (shard 3 of cloud B's 32M) against
+    the 8M-point reference cloud -- grid against the CPU kd-tree on a fixed sample, and the neighbouring shard
+    boundary: the last queries of shard 3 searched alone equal the same rows of the full shard."""
+    a = np.concatenate([synth.corridor_cloud(4_000_000, synth.SEED_A, start=o) for o in (0, 4_000_000)])
+    start, count = sharding.shard_range(32_000_000, 3, 8)
+    assert (start, count) == (12_000_000, 4_000_000)
+    b = synth.corridor_cloud(count, synth.SEED_B, start=start)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with capi.Index(ta) as ix:
+        idx, d2 = ix.nn1(tb)
+        tail_i, tail_d = ix.nn1(tb[-1000:])
+        assert ix.stats()[2] == len(a)
+        hi, hd = idx.cpu().numpy(), d2.cpu().numpy()
+        assert (tail_i.cpu().numpy() == hi[-1000:]).all() and (_bits(tail_d.cpu().numpy()) == _bits(hd[-1000:])).all()
+    assert (hi >= 0).all() and np.isfinite(hd).all()
+    _sample_check(a, b, hi, hd, n_sample=20000, seed=5)
+
+
 def test_1m_knn_normals_region_growing_against_the_sequential_walk(gpu):
     """1M corridor points: the k-NN rows (sampled against the exhaustive oracle), the normals built on them and
     the GPU's order-free region growing against PCL's sequential walk (oracle) over the same rows"""

@@ -49,6 +49,34 @@ def test_nn1_strides_and_nonfinite(gpu, engine):
 
 
 @pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_nn1_pointxyz_16_byte_stride(gpu, engine):
+    """pcl::PointXYZ (SURVEY.md 8a row a8): x, y, z + one float of padding = 16-byte elements, host and device"""
+    import torch
+    a = np.full((6000, 4), 1.0, dtype=np.float32)
+    b = np.full((2500, 4), 1.0, dtype=np.float32)
+    a[:, :3] = synth.corridor_cloud(6000, synth.SEED_A)
+    b[:, :3] = synth.corridor_cloud(2500, synth.SEED_B)
+    a[:, 3] = np.nan  # the padding word is never read as a coordinate
+    assert a.strides == (16, 4)
+    oi, od = oracle.nn1_exhaustive(a, b)
+    with capi.Index(a, engine=engine) as ix:
+        idx, d2 = ix.nn1(b)
+        ki, kd = ix.knn(b[:300], 7)
+    assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+    ei, ed = oracle.knn_exhaustive(a, b[:300], 7)
+    assert (ki == ei).all() and (_bits(kd) == _bits(ed)).all()
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with capi.Index(ta, engine=engine) as ix:
+        ti, td = ix.nn1(tb)
+        assert (ti.cpu().numpy() == oi).all() and (_bits(td.cpu().numpy()) == _bits(od)).all()
+        # a strided VIEW of a wider device array (every second row of 32-byte elements = 64-byte stride)
+        wide = torch.zeros((5000, 8), dtype=torch.float32, device="cuda")
+        wide[::2, :3] = tb[:, :3]
+        vi, vd = ix.nn1(wide[::2])
+        assert (vi.cpu().numpy() == oi).all() and (_bits(vd.cpu().numpy()) == _bits(od)).all()
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
 def test_nn1_duplicates_lowest_index(gpu, engine):
     rng = np.random.default_rng(7)
     base = rng.random((2000, 3), dtype=np.float32)
