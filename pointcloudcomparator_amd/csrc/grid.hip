@@ -40,10 +40,52 @@ unsigned int grid_nc_cap(size_t n) {
 // box is `ppc` points per cell, grown until the cell count fits nc_cap.  Keeping this on the
 // device removes the host round trip (D2H, wait, launch) from every index build: 46 us of a
 // 385 us step at 1M points.
+// k-th largest value over the lanes of a wave (lanes that do not take part pass -inf)
+__device__ __forceinline__ float wave_kth_max(float v, int k) {
+    const unsigned int lane = threadIdx.x & 63;
+    float m = v;
+    for (int it = 0; it < k; ++it) {
+        m = v;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (it + 1 < k) {
+            const unsigned long long hit = __ballot(v == m);
+            if (hit && lane == (unsigned int)__ffsll((long long)hit) - 1) v = -__builtin_inff();
+        }
+    }
+    return m;
+}
+
+// trim_k > 0: the grid is laid over a TRIMMED box.  Every row of `blk` is the bounding box of an interleaved
+// sample of the cloud (one pack workgroup); a stray point far from the scene inflates one row, not the others.
+// Per group of 64 rows the trim_k-th extreme is taken, then the widest group: a handful of outliers no longer
+// stretches the cells over empty space (one point at 10 km made every cell 10x wider and sent the search to its
+// exhaustive fallback).  Points beyond the box fall into the boundary cells, which every search already treats
+// as open-ended (cell_coord clamps, outside_bound2 takes no bound from a face on the grid's edge, cell_range
+// clamps): results stay exact, and the handle still reports the true bounding box.
 __global__ void __launch_bounds__(256)
-k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap,
+k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap, int trim_k,
               GridDev* __restrict__ out, GridDev* __restrict__ host_mirror) {
     __shared__ float red[4][8];
+    __shared__ float rob[4][6];
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        float tl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+        float th[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        if (trim_k > 0) {
+            for (int g0 = wave * 64; g0 < nblk; g0 += 256) {  // wave-uniform
+                if (nblk - g0 < 16) continue;                  // a short tail group says little
+                const int b = g0 + lane;
+                const float* r = blk + (size_t)(b < nblk ? b : 0) * 8;
+                for (int a = 0; a < 3; ++a) {
+                    const float l = b < nblk ? r[1 + a] : __builtin_inff(), h = b < nblk ? r[4 + a] : -__builtin_inff();
+                    th[a] = fmaxf(th[a], wave_kth_max(h, trim_k));
+                    tl[a] = fminf(tl[a], -wave_kth_max(-l, trim_k));
+                }
+            }
+        }
+        if (lane == 0)
+            for (int a = 0; a < 3; ++a) { rob[wave][a] = tl[a]; rob[wave][3 + a] = th[a]; }
+    }
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -77,8 +119,13 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
     float ext[3], maxext = 0.f, maxabs = 0.f;
     for (int a = 0; a < 3; ++a) {
         if (d.n_valid == 0) { lo[a] = 0.f; hi[a] = 0.f; }
-        d.lo[a] = lo[a];
+        d.lo[a] = lo[a];  // the true bounding box is what the handle reports
         d.hi[a] = hi[a];
+        if (trim_k > 0 && d.n_valid != 0) {  // the grid lies over the trimmed one (never wider than the true box)
+            float tl = __builtin_inff(), th = -__builtin_inff();
+            for (int w = 0; w < 4; ++w) { tl = fminf(tl, rob[w][a]); th = fmaxf(th, rob[w][3 + a]); }
+            if (tl <= th) { lo[a] = fmaxf(lo[a], tl); hi[a] = fminf(hi[a], th); }
+        }
         ext[a] = hi[a] - lo[a];
         if (!(ext[a] >= 0.f) || !(ext[a] < __builtin_inff())) ext[a] = 0.f;  // overflowed extents: one cell
         maxext = fmaxf(maxext, ext[a]);
@@ -120,10 +167,12 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
 
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
     static const float ppc = (getenv("PCC_GRID_PPC") && atof(getenv("PCC_GRID_PPC")) > 0) ? (float)atof(getenv("PCC_GRID_PPC")) : GRID_TARGET_PPC;
+    static const int trim = getenv("PCC_GRID_TRIM") ? atoi(getenv("PCC_GRID_TRIM")) : 3;
     PCC_TRY(ix->d_grid.reserve(sizeof(GridDev)));
     ix->nc_cap = grid_nc_cap(ix->n_orig);
+    // (trimming needs enough rows to tell an outlier from the scene: 128 pack workgroups = 64k points)
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
-                       ppc, ix->nc_cap, ix->d_grid.as<GridDev>(), ix->h_grid);
+                       ppc, ix->nc_cap, n_blocks >= 128 ? trim : 0, ix->d_grid.as<GridDev>(), ix->h_grid);
     PCC_HIP(hipGetLastError());
     ix->info_pending = true;
     return PCC_OK;
@@ -320,8 +369,9 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
 //      y/z distance and clipping every row's x-range to the chord of the (shrinking) ball
 //   3. only if the ball spans more than FAR_SPAN cells per axis: the exhaustive kernel
 // distance from coordinate v to the interval of cell c along one axis (0 inside), shrunk by slack
-__device__ __forceinline__ float axis_gap(float v, int c, float org, float h, float slack) {
-    const float lo = org + c * h, hi = org + (c + 1) * h;
+// (the boundary cells are open-ended: they also hold the references that lie beyond the grid's box)
+__device__ __forceinline__ float axis_gap(float v, int c, int dim, float org, float h, float slack) {
+    const float lo = c == 0 ? -__builtin_inff() : org + c * h, hi = c == dim - 1 ? __builtin_inff() : org + (c + 1) * h;
     return fmaxf(fmaxf(lo - v, v - hi) - slack, 0.f);
 }
 
@@ -379,7 +429,7 @@ k_grid_far(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
                     else { dy = rho; dz = r - 2 * (2 * rho + 1) - (2 * rho - 1) - rho + 1; }
                     const int y = cy + dy, z = cz + dz;
                     if (y < 0 || y >= g.dim[1] || z < 0 || z >= g.dim[2]) continue;
-                    const float gy = axis_gap(qy, y, g.org[1], g.h, slack), gz = axis_gap(qz, z, g.org[2], g.h, slack);
+                    const float gy = axis_gap(qy, y, g.dim[1], g.org[1], g.h, slack), gz = axis_gap(qz, z, g.dim[2], g.org[2], g.h, slack);
                     const float lbd = __uint_as_float((unsigned int)(best >> 32));
                     const float rem = lbd * 1.00002f - (gz * gz + gy * gy);
                     if (!(rem > 0.f)) continue;  // the whole row is at least as far as the current best
