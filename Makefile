@@ -43,13 +43,13 @@ build/test_lane_ops: tests/cpp/test_lane_ops.hip $(CSRC)/lane_ops.hpp
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -I$(CSRC) $< -o $@
 
-build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc/multi_device.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -Wall -Iinclude $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-build/comparator: pointcloudcomparator_amd/host/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+build/comparator: pointcloudcomparator_amd/host/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp pointcloudcomparator_amd/host/report.hpp include/pcc/multi_device.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 build/ply_dump: tests/cpp/ply_dump.cpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc/point_types.hpp
 	@mkdir -p build

@@ -23,6 +23,15 @@ inline void check(int status) {
     if (status != PCC_OK) throw Error(status, pcc_last_error());
 }
 
+// Device new search objects of THIS thread are created on (default 0).  The reference's call sites construct their
+// trees without saying where (src/comparator.cpp:564, src/segmentation.cpp:120); a host that spreads work over
+// the GPUs of a node gives each worker thread its device once (pcc/multi_device.hpp) instead of threading a
+// device argument through every object.
+inline int& threadDevice() {
+    static thread_local int device = 0;
+    return device;
+}
+
 namespace search {
 
 template <class PointT>
@@ -33,8 +42,10 @@ public:
 
     // pcl::KdTreeFLANN(bool sorted = true); the reference writes `= new KdTreeFLANN<T>(false)`,
     // a pointer-to-bool conversion that yields sorted == TRUE
-    explicit KdTree(bool sorted = true, int device = 0, int engine = PCC_ENGINE_AUTO)
-        : sorted_(sorted), device_(device), engine_(engine) {}
+    // device < 0: the calling thread's default device (threadDevice())
+    explicit KdTree(bool sorted = true, int device = -1, int engine = PCC_ENGINE_AUTO)
+        : sorted_(sorted), device_(device < 0 ? threadDevice() : device), engine_(engine) {}
+    int device() const { return device_; }
     ~KdTree() { if (index_) pcc_index_destroy(index_); }
     KdTree(const KdTree&) = delete;
     KdTree& operator=(const KdTree&) = delete;

@@ -78,6 +78,13 @@ int pcc_index_destroy(pcc_index *index);
  * the index is left empty (searches return PCC_ERR_EMPTY). */
 int pcc_index_set_input(pcc_index *index, const void *pts, size_t n, size_t stride_bytes,
                         int dim, int mem);
+/* One index per device from one upload (every GPU holds the full reference cloud, queries are
+ * sharded): the packed cloud of `src` is copied device-to-device (hipMemcpyPeerAsync over xGMI) into a new
+ * handle on `device` and indexed there -- rebuilding the grid (~0.1 ms per million points) is cheaper than
+ * shipping it.  Same cloud, same indices, same engine; `src` and `device` may be the same device (a second
+ * handle with its own stream).  The reference is single-GPU code; this is what its one tree per search site
+ * (src/comparator.cpp:564-565) becomes when the query loop is spread over several GPUs of a node. */
+int pcc_index_clone_to_device(pcc_index *src, int device, pcc_index **out);
 /* number of valid (finite) reference points == PCL total_nr_points_ */
 int pcc_index_size(const pcc_index *index, size_t *n_valid);
 /* run this index's work on a caller-owned hipStream_t (NULL = library stream) */

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
-    "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index",
+    "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device",
 ]
 
 
@@ -70,6 +70,7 @@ def _load() -> C.CDLL:
     lib.pcc_index_size.argtypes = [vp, C.POINTER(sz)]
     lib.pcc_index_set_stream.argtypes = [vp, vp]
     lib.pcc_index_sync.argtypes = [vp]
+    lib.pcc_index_clone_to_device.argtypes = [vp, i32, C.POINTER(vp)]
     lib.pcc_index_wait_stream.argtypes = [vp, vp]
     lib.pcc_stream_wait_index.argtypes = [vp, vp]
     lib.pcc_index_engine.argtypes = [vp, C.POINTER(i32)]
@@ -195,6 +196,14 @@ class Index:
     def _after(self, st):
         if st is not None:
             _check(LIB.pcc_stream_wait_index(self._h, st))
+
+    def clone_to_device(self, device: int) -> "Index":
+        """a second handle over the same cloud on `device` (packed cloud copied device to device, index rebuilt there)"""
+        h = C.c_void_p()
+        _check(LIB.pcc_index_clone_to_device(self._h, device, C.byref(h)))
+        other = Index.__new__(Index)
+        other._h, other.n_original, other.auto_sync = h, self.n_original, self.auto_sync
+        return other
 
     def set_input(self, points):
         """pcl::KdTreeFLANN::setInputCloud on an existing object: rebuild over a new cloud,

@@ -78,6 +78,7 @@ struct DeviceGuard {
 };
 #define PCC_ENTER(ix)                                                         \
     if (!(ix)) { pcc::set_error("null index"); return PCC_ERR_INVALID; }      \
+    std::lock_guard<std::mutex> _lock((ix)->mu);                              \
     pcc::DeviceGuard _guard((ix)->device);                                    \
     if (!_guard.ok) { pcc::set_error("hipSetDevice(%d) failed", (ix)->device); return PCC_ERR_DEVICE; }
 
@@ -218,17 +219,8 @@ int pcc_index_destroy(pcc_index* ix) {
     return PCC_OK;
 }
 
-int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem, int device, int engine,
-                     pcc_index** out) {
-    if (!out) { set_error("null out"); return PCC_ERR_INVALID; }
-    *out = nullptr;
-    if (dim != 3) { set_error("dim %d unsupported: every hot call site of the reference searches 3 floats", dim); return PCC_ERR_UNSUPPORTED; }
-    if (engine < PCC_ENGINE_AUTO || engine > PCC_ENGINE_GRID) { set_error("bad engine %d", engine); return PCC_ERR_INVALID; }
-    PCC_TRY(check_points(pts, n, stride, mem));
-    if (n == 0) { set_error("Cannot create a KDTree with an empty input cloud"); return PCC_ERR_EMPTY; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (libpcc_nn has no CPU path)"); return PCC_ERR_DEVICE; }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d present)", device, ndev); return PCC_ERR_INVALID; }
+// shared by pcc_index_create and pcc_index_clone_to_device: an empty handle on `device`
+static int new_handle(int device, int engine, pcc_index** out) {
     pcc_index* ix = new pcc_index();
     ix->device = device;
     DeviceGuard g(device);
@@ -245,10 +237,71 @@ int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem,
     memset(ix->pinned, 0, PACK_MAX_BLOCKS * 8 * sizeof(float) + 4096);
     if (hipHostMalloc((void**)&ix->h_grid, sizeof(GridDev), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
     memset(ix->h_grid, 0, sizeof(GridDev));
+    *out = ix;
+    return PCC_OK;
+}
+
+int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem, int device, int engine,
+                     pcc_index** out) {
+    if (!out) { set_error("null out"); return PCC_ERR_INVALID; }
+    *out = nullptr;
+    if (dim != 3) { set_error("dim %d unsupported: every hot call site of the reference searches 3 floats", dim); return PCC_ERR_UNSUPPORTED; }
+    if (engine < PCC_ENGINE_AUTO || engine > PCC_ENGINE_GRID) { set_error("bad engine %d", engine); return PCC_ERR_INVALID; }
+    PCC_TRY(check_points(pts, n, stride, mem));
+    if (n == 0) { set_error("Cannot create a KDTree with an empty input cloud"); return PCC_ERR_EMPTY; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (libpcc_nn has no CPU path)"); return PCC_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d present)", device, ndev); return PCC_ERR_INVALID; }
+    pcc_index* ix = nullptr;
+    PCC_TRY(new_handle(device, engine, &ix));
+    DeviceGuard g(device);
+    int st = PCC_OK;
+    auto fail = [&](int s) { pcc_index_destroy(ix); return s; };
     if ((st = set_input(ix, pts, n, stride, mem)) != PCC_OK) return fail(st);
     if ((st = sync_info(ix)) != PCC_OK) return fail(st);
     if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
     if (ix->n_valid == 0) { set_error("Cannot create a KDTree with an empty input cloud (all %zu points non-finite)", n); return fail(PCC_ERR_EMPTY); }
+    *out = ix;
+    return PCC_OK;
+}
+
+int pcc_index_clone_to_device(pcc_index* src, int device, pcc_index** out) {
+    if (!out) { set_error("null out"); return PCC_ERR_INVALID; }
+    *out = nullptr;
+    if (!src) { set_error("null index"); return PCC_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (libpcc_nn has no CPU path)"); return PCC_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d present)", device, ndev); return PCC_ERR_INVALID; }
+    size_t n = 0;
+    int engine = PCC_ENGINE_AUTO, src_device = 0;
+    const float4* src_refs = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(src->mu);
+        DeviceGuard g(src->device);
+        if (!g.ok) { set_error("hipSetDevice(%d) failed", src->device); return PCC_ERR_DEVICE; }
+        if (src->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+        PCC_HIP(hipStreamSynchronize(src->stream));  // the packed cloud is complete
+        n = src->n_orig;
+        engine = src->engine_requested;
+        src_device = src->device;
+        src_refs = src->refs.as<float4>();
+    }
+    pcc_index* ix = nullptr;
+    PCC_TRY(new_handle(device, engine, &ix));
+    DeviceGuard g(device);
+    auto fail = [&](int s) { pcc_index_destroy(ix); return s; };
+    int st = PCC_OK;
+    // the packed cloud (float4, w = validity) travels device to device; non-finite points get their NaN back so
+    // that the build sees what the original upload saw
+    if ((st = ix->icp_src.reserve(n * sizeof(float4))) != PCC_OK) return fail(st);
+    if (hipMemcpyPeerAsync(ix->icp_src.p, device, src_refs, src_device, n * sizeof(float4), ix->stream) != hipSuccess) {
+        set_error("hipMemcpyPeerAsync %d -> %d failed: %s", src_device, device, hipGetErrorString(hipGetLastError()));
+        return fail(PCC_ERR_DEVICE);
+    }
+    if ((st = launch_nanify(ix->stream, ix->icp_src.as<float4>(), n)) != PCC_OK) return fail(st);
+    if ((st = set_input(ix, ix->icp_src.p, n, sizeof(float4), PCC_MEM_DEVICE)) != PCC_OK) return fail(st);
+    if ((st = sync_info(ix)) != PCC_OK) return fail(st);
+    if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
     *out = ix;
     return PCC_OK;
 }

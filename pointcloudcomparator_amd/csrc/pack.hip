@@ -306,6 +306,20 @@ int launch_transform(hipStream_t s, const float* Tdev, const float T[16], const 
 
 
 __global__ void __launch_bounds__(256)
+k_nanify(float4* __restrict__ pts, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = pts[i];
+        if (__float_as_int(v.w) < 0) { v.x = v.y = v.z = __builtin_nanf(""); pts[i] = v; }
+    }
+}
+int launch_nanify(hipStream_t s, float4* pts, size_t n) {
+    if (n == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_nanify, dim3(grid_for(n, 256)), dim3(256), 0, s, pts, n);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+__global__ void __launch_bounds__(256)
 k_copy_w(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i].w = src[i].w;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include <string>
 #include "pcc_nn.h"
 
@@ -77,6 +78,7 @@ struct GridDev {
 #define PCC_EV_KINDS 10
 // The opaque handle of the C-ABI.
 struct pcc_index {
+    std::mutex mu;                     // every entry point holds it: calls on ONE handle from several threads are serialised
     int device = 0;
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // library-owned stream
@@ -156,6 +158,8 @@ int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4*
                   int32_t* idx, float* d2, const unsigned int* mirror_dev = nullptr, unsigned int* mirror_host = nullptr);
 int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[16],
                      const void* src, size_t n, size_t sstride, void* dst, size_t dstride);
+// packed points whose w flags them invalid get NaN coordinates again (in place): what a raw cloud looked like
+int launch_nanify(hipStream_t s, float4* pts, size_t n);
 // dst[i].w = src[i].w (validity flags of packed points)
 int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n);
 // SOR: mean_dist[orig(i)] = float(sum_{j=1..K-1} sqrt(double(d2_j)) / (K-1)) from the K-NN keys of

@@ -10,16 +10,26 @@
 // Euclidean clustering (-e, :64-156), each behind the VoxelGrid the reference applies first.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <sstream>
+#include <algorithm>
 #include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
 #include "pcc/comparator_nn.hpp"
+#include "pcc/multi_device.hpp"
 #include "ply_io.hpp"
+#include "report.hpp"
 
 using namespace pcc;
 
 static bool seeClusters = false, noise = false, euclidean = false, icp = false;
+// not in the reference: --gpus N (the two clouds are segmented / filtered as replicas on two devices),
+// --descriptors1/2 FILE (precomputed RIFT32 descriptors per cluster: the descriptor pipeline itself is out of scope),
+// --dump-clusters PREFIX (the clusters as PLY files, so that descriptors can be computed for them elsewhere)
+static int n_gpus = 1;
+static std::string descriptors_path[2], dump_prefix;
 
 static void printUsage() {
     std::cout << "\n\nUsage: [options] </pathToScene1.ply> </pathToScene2.ply>\n\n"
@@ -28,7 +38,12 @@ static void printUsage() {
               << "-v activate visualization of clusters and matches\n"
               << "-i activate ICP algorithm to know if both point clouds are enough similar \n"
               << "-e activate euclidean cluster segmentation as main segmentation algorithm; region growing segmentation is default\n"
-              << "-h show this help\n" << "\n\n";
+              << "-h show this help\n"
+              << "--gpus N           (this build) run the two clouds on N devices\n"
+              << "--descriptors1 F   (this build) precomputed RIFT32 descriptors of the clusters of scene 1\n"
+              << "--descriptors2 F   (this build) ... of scene 2\n"
+              << "--dump-clusters P  (this build) write the clusters as P_<scene>_<cluster>.ply\n"
+              << "--results F        (this build) results file (default ../../PointCloudComparatorResults/results.txt)\n" << "\n\n";
 }
 
 // src/segmentation.cpp:64-156 euclidean_cluster_segmentation: VoxelGrid 0.025 (:69-76) -> RANSAC plane
@@ -141,10 +156,9 @@ static double computeSimilarity(const std::string& file1, const std::string& fil
         std::cerr << "Was not able to open file \"" << file2 << "\".\n";
         return -2;
     }
-    std::ofstream myfile;
-    myfile.open(results_path.c_str());  // like the reference, a failure to open is not an error
-    myfile << "Results of comparison between " << file1 << " and " << file2
-           << "\n--------------------------------------------------------------------------------\n\n";
+    report::Writer out(results_path);
+    std::ofstream& myfile = out.file();
+    out.header(file1, file2);
     std::vector<int> indices2;
     io::removeNaNFromPointCloud(*point_cloud1_ptr, indices2);
     io::removeNaNFromPointCloud(*point_cloud2_ptr, indices2);
@@ -172,31 +186,57 @@ static double computeSimilarity(const std::string& file1, const std::string& fil
         }
     }
 
-    std::vector<PointCloud<PointXYZRGB>::Ptr> clusters_pcl_1, clusters_pcl_2;
-    if (euclidean) {
-        clusters_pcl_1 = euclidean_cluster_segmentation(point_cloud1_ptr);
-        clusters_pcl_2 = euclidean_cluster_segmentation(point_cloud2_ptr);
-    } else {
-        clusters_pcl_1 = region_growing_segmentation(point_cloud1_ptr);
-        clusters_pcl_2 = region_growing_segmentation(point_cloud2_ptr);
+    // the two clouds are independent until the cluster matching: replicas, one device each when there are several
+    // (clustering itself does not shard).  With one device the two jobs run one after the other, in
+    // the reference's order, so its printed lines keep their order.
+    std::vector<int> devices;
+    for (int d = 0; d < std::max(1, std::min(n_gpus, deviceCount())); ++d) devices.push_back(d);
+    std::vector<PointCloud<PointXYZRGB>::Ptr> clusters[2];
+    const PointCloud<PointXYZRGB>::Ptr clouds[2] = {point_cloud1_ptr, point_cloud2_ptr};
+    auto segment = [&](int k) { clusters[k] = euclidean ? euclidean_cluster_segmentation(clouds[k]) : region_growing_segmentation(clouds[k]); };
+    if (devices.size() > 1) onDevices(2, devices, segment);
+    else { segment(0); segment(1); }
+    std::vector<PointCloud<PointXYZRGB>::Ptr>&clusters_pcl_1 = clusters[0], &clusters_pcl_2 = clusters[1];
+
+    report::Writer& w = out;
+    w.counts(point_cloud1_ptr->points.size(), point_cloud2_ptr->points.size(), clusters_pcl_1.size(), clusters_pcl_2.size());
+    if (!dump_prefix.empty())
+        for (int k = 0; k < 2; ++k)
+            for (size_t j = 0; j < clusters[k].size(); ++j) {
+                std::ostringstream name;
+                name << dump_prefix << "_" << k + 1 << "_" << j << ".ply";
+                io::savePLYFileBinary(name.str(), *clusters[k][j]);
+            }
+
+    // descriptors per cluster: from files, or none (the SIFT / RIFT pipeline is not part of this build)
+    std::vector<report::DescPtr> des[2];
+    bool have_descriptors = true;
+    for (int k = 0; k < 2; ++k) {
+        if (descriptors_path[k].empty()) {
+            have_descriptors = false;
+            des[k].assign(clusters[k].size(), report::DescPtr());
+            for (report::DescPtr& d : des[k]) d.reset(new PointCloud<RIFT32>);
+        } else if (!report::loadDescriptors(descriptors_path[k], clusters[k].size(), des[k])) {
+            std::cerr << "Was not able to read descriptors \"" << descriptors_path[k] << "\".\n";
+            return -2;
+        }
     }
-    myfile << "Number of points of PCL 1: " << point_cloud1_ptr->points.size() << "\n";
-    myfile << "Number of points of PCL 2: " << point_cloud2_ptr->points.size() << "\n";
-    myfile << "++++++++++++++++++++++++++++++++++++++++\n";
-    myfile << "Number of clusters of PCL 1: " << clusters_pcl_1.size() << "\n";
-    myfile << "Number of clusters of PCL 2: " << clusters_pcl_2.size() << "\n";
+    std::vector<int> matches;
+    const report::Scores scores = report::clusterSections(w, clusters_pcl_1, clusters_pcl_2, des[0], des[1], matches);
 
     if (noise) {
-        PointCloud<PointXYZRGB> nonoise1, nonoise2;
-        StatisticalOutlierRemoval<PointXYZRGB> sor;
-        sor.setInputCloud(point_cloud1_ptr); sor.setMeanK(50); sor.setStddevMulThresh(1.5); sor.filter(nonoise1);
+        PointCloud<PointXYZRGB> nonoise[2];
+        auto filter = [&](int k) {
+            StatisticalOutlierRemoval<PointXYZRGB> sor;
+            sor.setInputCloud(clouds[k]); sor.setMeanK(50); sor.setStddevMulThresh(1.5); sor.filter(nonoise[k]);
+        };
+        if (devices.size() > 1) onDevices(2, devices, filter);
+        else { filter(0); filter(1); }
         // size_t integer division, as in the reference (:1533-1535): the ratio is always 0
-        double noise1 = (point_cloud1_ptr->points.size() - nonoise1.points.size()) / point_cloud1_ptr->points.size();
-        StatisticalOutlierRemoval<PointXYZRGB> sor2;
-        sor2.setInputCloud(point_cloud2_ptr); sor2.setMeanK(50); sor2.setStddevMulThresh(1.5); sor2.filter(nonoise2);
-        double noise2 = (point_cloud2_ptr->points.size() - nonoise2.points.size()) / point_cloud2_ptr->points.size();
-        std::cout << "Noise pass removed " << point_cloud1_ptr->points.size() - nonoise1.points.size() << " / "
-                  << point_cloud2_ptr->points.size() - nonoise2.points.size() << " points" << std::endl;
+        double noise1 = (point_cloud1_ptr->points.size() - nonoise[0].points.size()) / point_cloud1_ptr->points.size();
+        double noise2 = (point_cloud2_ptr->points.size() - nonoise[1].points.size()) / point_cloud2_ptr->points.size();
+        std::cout << "Noise pass removed " << point_cloud1_ptr->points.size() - nonoise[0].points.size() << " / "
+                  << point_cloud2_ptr->points.size() - nonoise[1].points.size() << " points" << std::endl;
         myfile << "----------------------------------------\n Noise analysis: \n";
         if (noise1 > noise2) {
             std::cout << "PCL1 has more noisy points: (%) " << noise1 * 100 << " over: (%) " << noise2 * 100 << std::endl;
@@ -209,8 +249,15 @@ static double computeSimilarity(const std::string& file1, const std::string& fil
             myfile << "Both pcl have the same percentage of noisy points: " << noise1 * 100 << "\n";
         }
     }
-    myfile.close();
-    return 0;  // the 0/1/2 verdict needs the descriptor scores (not part of this build): "same information"
+    const int verdict = report::scoreSections(w, scores, clusters_pcl_2.size());
+    if (!have_descriptors) {
+        // nothing was scored: saying "same information" would report a comparison that never happened
+        myfile << "\n(no descriptor files given: clusters could not be matched, no verdict)\n";
+        w.close();
+        return -3;
+    }
+    w.close();
+    return verdict;
 }
 
 int main(int argc, char** argv) {
@@ -226,6 +273,10 @@ int main(int argc, char** argv) {
         else if (a == "-i") icp = true;
         else if (a == "-e") euclidean = true;
         else if (a == "--results" && i + 1 < argc) results_path = argv[++i];
+        else if (a == "--gpus" && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
+        else if (a == "--descriptors1" && i + 1 < argc) descriptors_path[0] = argv[++i];
+        else if (a == "--descriptors2" && i + 1 < argc) descriptors_path[1] = argv[++i];
+        else if (a == "--dump-clusters" && i + 1 < argc) dump_prefix = argv[++i];
         else if (a.size() > 4 && a.substr(a.size() - 4) == ".ply") plys.push_back(a);
     }
     if (help) { printUsage(); return 1; }
@@ -239,13 +290,14 @@ int main(int argc, char** argv) {
     double similarity = -3;
     try {
         similarity = computeSimilarity(plys[0], plys[1], results_path);
-    } catch (const pcc::Error& e) {
+    } catch (const std::exception& e) {  // pcc::Error, and whatever a broken input makes the standard library throw
         std::cerr << e.what() << std::endl;
     }
     std::cout << "--------------------------------\n" << std::endl;
     if (similarity == 1) std::cout << "The first point cloud has more information" << std::endl;
     else if (similarity == 2) std::cout << "The second point cloud has more information" << std::endl;
     else if (similarity == 0) std::cout << "Both point clouds have the same information" << std::endl;
+    else if (similarity == -3) std::cout << "No descriptor files were given (--descriptors1/2): clusters were not matched, no verdict" << std::endl;
     std::cout << "--------------------------------\n" << std::endl;
     return 1;  // reference :1704
 }

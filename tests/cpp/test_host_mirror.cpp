@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <random>
 #include "pcc/comparator_nn.hpp"
+#include "pcc/multi_device.hpp"
 
 using namespace pcc;
 
@@ -87,6 +88,48 @@ int main() {
         t16.nearestKSearchBatch(*xyz, i16, d16);
         for (size_t i = 0; i < xyz->size(); ++i) REQUIRE(d16[i] == 0.f);
         REQUIRE(t16.nearestKSearch(xyz->points[11], 3, idx, d2) == 3 && idx[0] == 11);
+    }
+
+    // one index per device, queries sharded -- with one GPU: two handles on device 0
+    {
+        std::vector<int> i1, i2; std::vector<float> d1, d2b;
+        tree->nearestKSearchBatch(*cloud, i1, d1);
+        ShardedKdTree<PointXYZRGB> sharded(std::vector<int>{0, 0, 0});
+        sharded.setInputCloud(cloud);
+        REQUIRE(sharded.shards() == 3 && sharded.handle(0) != sharded.handle(1));
+        size_t nv = 0;
+        REQUIRE(pcc_index_size(sharded.handle(2), &nv) == PCC_OK && nv == cloud->size());
+        sharded.nearestKSearchBatch(*cloud, i2, d2b);
+        REQUIRE(i1 == i2 && d1 == d2b);
+        std::vector<int> k1, k2; std::vector<float> e1, e2;
+        tree->nearestKSearchBatch(*cloud, 6, k1, e1);
+        sharded.nearestKSearchBatch(*cloud, 6, k2, e2);
+        REQUIRE(k1 == k2 && e1 == e2);
+        // a clone keeps the indices of the original cloud, non-finite points included
+        PointCloud<PointXYZRGB>::Ptr holes(new PointCloud<PointXYZRGB>(*cloud));
+        holes->points[3].x = NAN; holes->points[700].z = INFINITY;
+        pcc_index *a = nullptr, *b = nullptr;
+        REQUIRE(pcc_index_create(holes->points.data(), holes->size(), sizeof(PointXYZRGB), 3, PCC_MEM_HOST, 0, PCC_ENGINE_AUTO, &a) == PCC_OK);
+        REQUIRE(pcc_index_clone_to_device(a, 0, &b) == PCC_OK);
+        REQUIRE(pcc_index_size(b, &nv) == PCC_OK && nv == holes->size() - 2);
+        std::vector<int32_t> ia(cloud->size()), ib(cloud->size()); std::vector<float> da(cloud->size()), db(cloud->size());
+        REQUIRE(pcc_nn1(a, cloud->points.data(), cloud->size(), sizeof(PointXYZRGB), PCC_MEM_HOST, ia.data(), da.data()) == PCC_OK);
+        REQUIRE(pcc_nn1(b, cloud->points.data(), cloud->size(), sizeof(PointXYZRGB), PCC_MEM_HOST, ib.data(), db.data()) == PCC_OK);
+        REQUIRE(ia == ib && da == db && ia[3] != 3 && ia[700] != 700 && ia[5] == 5);
+        REQUIRE(pcc_index_clone_to_device(a, 99, &b) == PCC_ERR_INVALID);
+        pcc_index_destroy(a); pcc_index_destroy(b);
+        // replicas: two jobs, each on "its" device, objects created inside pick the device up
+        int seen[2] = {-1, -1};
+        onDevices(2, std::vector<int>{0}, [&](int k) {
+            search::KdTree<PointXYZRGB> t;
+            t.setInputCloud(cloud);
+            std::vector<int> ii; std::vector<float> dd;
+            seen[k] = t.nearestKSearch(cloud->points[k], 1, ii, dd) == 1 && ii[0] == k ? t.device() : -2;
+        });
+        REQUIRE(seen[0] == 0 && seen[1] == 0);
+        size_t s0, c0;
+        shardRange(10, 3, 4, s0, c0);
+        REQUIRE(s0 == 8 && c0 == 2);
     }
 
     // EuclideanClusterExtraction (src/segmentation.cpp:125-131)

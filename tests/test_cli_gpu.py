@@ -135,3 +135,106 @@ def test_cli_missing_file_and_usage(gpu, tmp_path):
     assert "Was not able to open file" in r.stderr and r.returncode == 1
     r = subprocess.run([str(EXE), "-h"], capture_output=True, text=True)
     assert "Usage: [options] </pathToScene1.ply> </pathToScene2.ply>" in r.stdout and r.returncode == 1
+
+
+# ---- the cluster sections of results.txt (reference src/comparator.cpp:1220-1255, 1257-1384, 1386-1518, 1570-1635) -----
+def _read_cluster_ply(path):
+    raw = Path(path).read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    n = int([l for l in head.decode().splitlines() if l.startswith("element vertex")][0].split()[-1])
+    rec = np.frombuffer(body, dtype=np.dtype([("p", "<f4", 3), ("c", "u1", 3)]), count=n)
+    return np.ascontiguousarray(rec["p"])
+
+
+def _centroid_f32(pts):
+    """float accumulators in point order, one division at the end (reference :1238-1250)"""
+    s = np.add.accumulate(pts.astype(np.float32), axis=0, dtype=np.float32)[-1]
+    return (s / np.float32(len(pts))).astype(np.float32)
+
+
+def _g(x):
+    return "%g" % float(x)  # std::ostream's default float formatting
+
+
+def _write_descriptors(path, per_cluster):
+    with open(path, "w") as f:
+        f.write("pcc_descriptors 1\n")
+        for j, d in per_cluster.items():
+            f.write(f"cluster {j} {len(d)}\n")
+            for row in d:
+                f.write(" ".join(repr(float(v)) for v in row) + "\n")
+
+
+def test_cli_cluster_sections_matches_scores_verdict(gpu, tmp_path):
+    """-e run with precomputed descriptor files: the per-cluster sections, the matching of clusters through
+    matchRIFTFeaturesKnn (GPU k=1 search on the descriptors), the score block and the 0/1/2 verdict."""
+    a, b = _scene(1), _scene(2, shift=(0.004, -0.003, 0.002))
+    fa, fb, res = tmp_path / "a.ply", tmp_path / "b.ply", tmp_path / "results.txt"
+    write_ply(fa, a, fmt="binary")
+    write_ply(fb, b, fmt="binary")
+    # run 1: no descriptors -> clusters dumped, no verdict
+    r = subprocess.run([str(EXE), "-e", str(fa), str(fb), "--results", str(res), "--dump-clusters", str(tmp_path / "cl")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1
+    assert "no verdict" in r.stdout and "same information" not in r.stdout
+    txt = res.read_text()
+    assert "(no descriptor files given: clusters could not be matched, no verdict)" in txt
+    cl = [[_read_cluster_ply(tmp_path / f"cl_{k}_{j}.ply") for j in range(4)] for k in (1, 2)]
+    assert all(len(c) == 216 for k in range(2) for c in cl[k])
+    cen = [[_centroid_f32(c) for c in cl[k]] for k in range(2)]
+    # which cluster of scene 2 sits where cluster i of scene 1 sits
+    twin = [int(np.argmin([np.linalg.norm(cen[0][i] - c2) for c2 in cen[1]])) for i in range(4)]
+    rng = np.random.default_rng(9)
+    des1, des2 = {}, {}
+    mk = lambda n: rng.random((n, 32)).astype(np.float32)
+    d = mk(10); des1[0] = d; des2[twin[0]] = d.copy()                       # 10 / 10, all match: 11 / 10 -> accepted
+    d = mk(12); des1[1] = d; des2[twin[1]] = d[:10].copy()                  # 12 / 10: 11 / 12 -> 0, rejected
+    des1[2] = mk(3); des2[twin[2]] = mk(9)                                  # 3 descriptors: never tried
+    d = mk(8); des1[3] = d; des2[twin[3]] = np.concatenate([d, d[:1]])      # 8 / 9, all 9 match: 10 / 9 -> accepted
+    _write_descriptors(tmp_path / "d1.txt", des1)
+    _write_descriptors(tmp_path / "d2.txt", des2)
+    r = subprocess.run([str(EXE), "-e", str(fa), str(fb), "--results", str(res), "--descriptors1", str(tmp_path / "d1.txt"),
+                        "--descriptors2", str(tmp_path / "d2.txt")], capture_output=True, text=True, timeout=300)
+    out, txt = r.stdout, res.read_text()
+    assert r.returncode == 1
+    rule = "\n" + "-" * 36 + "\n"
+    # per-cluster sections, PCL2 first
+    want = rule + "Information of clusters of PCL2:\n" + "-" * 36 + "\n"
+    for j in range(4):
+        c = cen[1][j]
+        want += (f"PCL2 cluster {j}:\n\tNumber of points: 216\n\tNumber of descriptors: {len(des2[j])}\n"
+                 f"\tCoordinates of centroid: [{_g(c[0])},{_g(c[1])},{_g(c[2])}]\n")
+    want += rule + "Information of clusters of PCL 1:\n" + "-" * 36 + "\n"
+    for i in range(4):
+        c = cen[0][i]
+        want += (f"PCL1 cluster {i}:\n\tNumber of points: 216\n\tNumber of descriptors: {len(des1[i])}\n"
+                 f"\tCoordinates of centroid: [{_g(c[0])},{_g(c[1])},{_g(c[2])}]\n")
+    assert want in txt
+    # matches: clusters 0 and 3
+    plus = "      " + "+" * 58 + "\t\n"
+    m = rule + "Information of matches of clusters of PCL 1 and PCL 2:\n" + "-" * 36 + "\n"
+    m += (f"\tMatched cluster 0 of PCL 1 with cluster {twin[0]} of PCL 2:\n\t\tBoth segments have the same number of points: 216\n"
+          "\t\tBoth segments have the same number of descriptors: 10\n" + plus)
+    m += "\t\tCluster 1 of PCL 1 has no match in PCL 2\n" + plus
+    m += "\t\tCluster 2 of PCL 1 has no match in PCL 2\n" + plus
+    m += (f"\tMatched cluster 3 of PCL 1 with cluster {twin[3]} of PCL 2:\n\t\tBoth segments have the same number of points: 216\n"
+          "\t\tSegment of PCL 2 has more descriptors: 9 over: 8\n" + plus)
+    m += "Total number of matches found: 2\n\n"
+    assert m in txt
+    # scores, ratios, verdict: points tie (432 / 432), descriptors 18 vs 19 -> the second cloud wins
+    s = ("\n" + "-" * 28 + "\n\npoints score pcl1: 432\npoints score pcl2: 432\n\ndescriptors score pcl1: 18\n"
+         "descriptors score pcl2: 19\n\ncolor elements score pcl1: 0\ncolor elements score pcl2: 0\n\n" + "-" * 28 + "\n\n")
+    ratio = (432 / 432 + 18 / 19 + 0) / 3
+    s += f"Ratio of similarity over the 2 matches: {_g(ratio)}\nRatio of general similarity of pcl 1 over pcl 2: {_g(ratio * (2 / 4))}\n"
+    assert txt.endswith(s)
+    assert f"Percentage of RIFT correspondences of clusters 0 and {twin[0]} is: 100" in out
+    assert f"Percentage of RIFT correspondences of clusters 1 and {twin[1]} is: 0" in out
+    assert out.count("Match accepted") == 0 and out.count("No match") == 2  # (the reference prints "Match accepted" only when des1 > des2)
+    assert "The second point cloud has more information" in out
+    # --gpus 2 (replicas on the devices present; one here): the same report
+    res2 = tmp_path / "results2.txt"
+    r2 = subprocess.run([str(EXE), "-e", "-n", "--gpus", "2", str(fa), str(fb), "--results", str(res2), "--descriptors1",
+                         str(tmp_path / "d1.txt"), "--descriptors2", str(tmp_path / "d2.txt")], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 1 and "The second point cloud has more information" in r2.stdout
+    t2 = res2.read_text()
+    assert want in t2 and m in t2 and t2.endswith(s) and " Noise analysis: \n" in t2

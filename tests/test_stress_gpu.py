@@ -101,7 +101,7 @@ def test_random_operation_sequences(gpu, seed):
 
 
 def test_distinct_handles_from_concurrent_threads(gpu):
-    """one handle = one stream, handles are not thread-safe, DISTINCT handles are.  Four threads, each
+    """one handle = one stream; DISTINCT handles run concurrently.  Four threads, each
     with its own index, interleave searches (ctypes drops the GIL inside the calls)"""
     import threading
     errors = []
@@ -128,4 +128,37 @@ def test_distinct_handles_from_concurrent_threads(gpu):
         t.start()
     for t in threads:
         t.join(timeout=300)
+    assert not errors, errors
+
+
+def test_one_handle_shared_by_concurrent_threads(gpu):
+    """searches on one handle from several threads.  The handle serialises them (a mutex in every entry
+    point; one stream, shared scratch): each thread must get ITS answers."""
+    import threading
+    rng = np.random.default_rng(11)
+    ref = _cloud(rng, 30000)
+    qs = [_cloud(rng, 2000 + 500 * t) for t in range(4)]
+    want = [oracle.nn1_exhaustive(ref, q) for q in qs]
+    want_knn = [oracle.knn_exhaustive(ref, q[:150], 5) for q in qs]
+    want_cnt = [oracle.radius_count_exhaustive(ref, q[:500], 0.06) for q in qs]
+    errors = []
+    ix = capi.Index(ref)
+
+    def worker(t):
+        try:
+            for _ in range(12):
+                idx, d2 = ix.nn1(qs[t])
+                assert (idx == want[t][0]).all() and (_bits(d2) == _bits(want[t][1])).all()
+                a, b = ix.knn(qs[t][:150], 5)
+                assert (a == want_knn[t][0]).all() and (_bits(b) == _bits(want_knn[t][1])).all()
+                assert (ix.radius_count(qs[t][:500], 0.06) == want_cnt[t]).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    ix.close()
     assert not errors, errors
