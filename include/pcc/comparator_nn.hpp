@@ -31,6 +31,9 @@ inline std::vector<int> matchRIFTFeaturesKnn(const PointCloud<RIFT32>::Ptr& desc
     // up to three times per cluster (:1322) and a fresh device handle per call would cost ~1 ms of
     // allocations for microseconds of work.
     static thread_local KdTreeFLANN<RIFT32> matching;
+    // the matched indices go back to the caller (:580): among descriptors at exactly the same distance name the one
+    // PCL's FLANN tree would (descriptor clouds are full of duplicates in their first three bins)
+    matching.setTieOrder(PCC_TIES_FLANN);
     matching.setInputCloud(descriptors1);
     if (!matching.handle() || !descriptors2 || descriptors2->empty()) return correspondence;
     std::vector<int> out(descriptors2->size() + 1);

@@ -77,6 +77,7 @@ public:
             int st = pcc_index_create(pts, n, sizeof(PointT), 3, PCC_MEM_HOST, device_, engine_, &index_);
             if (st == PCC_ERR_EMPTY) { index_ = nullptr; return; }
             check(st);
+            if (ties_ != PCC_TIES_LOWEST_INDEX) check(pcc_index_set_tie_order(index_, ties_));
             valid_ = true;
             return;
         }
@@ -84,6 +85,12 @@ public:
         size_t n_valid = 0;
         check(pcc_index_size(index_, &n_valid));  // waits for the build; 0 == PCL's "empty input cloud"
         valid_ = n_valid > 0;
+    }
+    // PCC_TIES_FLANN: k = 1 results name, among equally near points, the one PCL's FLANN tree reaches first
+    // (default: the lowest index); kept across setInputCloud calls
+    void setTieOrder(int ties) {
+        ties_ = ties;
+        if (index_) check(pcc_index_set_tie_order(index_, ties_));
     }
     CloudConstPtr getInputCloud() const { return input_; }
     IndicesConstPtr getIndices() const { return indices_; }
@@ -154,6 +161,7 @@ private:
     IndicesConstPtr indices_;
     std::vector<PointT> subset_;  // cloud[indices]: what the device index was built from
     bool sorted_;
+    int ties_ = PCC_TIES_LOWEST_INDEX;
     int device_, engine_;
     CloudConstPtr input_;
     pcc_index* index_ = nullptr;

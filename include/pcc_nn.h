@@ -56,6 +56,15 @@ enum pcc_mem { PCC_MEM_HOST = 0, PCC_MEM_DEVICE = 1 };
  *          BRUTE fallback for queries the rings do not resolve
  *   AUTO : GRID when the cloud is large enough to amortise its build. */
 enum pcc_engine { PCC_ENGINE_AUTO = 0, PCC_ENGINE_BRUTE = 1, PCC_ENGINE_GRID = 2 };
+/* which of several references at EXACTLY the same distance a k = 1 search names.
+ *   LOWEST_INDEX: the lowest original index (default; what every engine computes on the GPU)
+ *   FLANN       : the one pcl::KdTreeFLANN returns -- the first its kd-tree walk reaches.  The GPU
+ *                 result is kept for every query whose minimiser is unique; queries with a second reference at
+ *                 the same distance are flagged on the GPU and only those are walked through a host-side
+ *                 restatement of FLANN's KDTreeSingleIndex (built once per indexed cloud).  Applies to pcc_nn1
+ *                 and pcc_match_knn (the call sites that hand indices on, src/comparator.cpp:576-580); distances
+ *                 are the same bits either way. */
+enum pcc_ties { PCC_TIES_LOWEST_INDEX = 0, PCC_TIES_FLANN = 1 };
 
 #define PCC_KNN_MAX_K 65536 /* k <= 512: wave-cooperative selection; larger k works, one lane per query with O(k) insertion */
 
@@ -105,6 +114,8 @@ int pcc_stream_wait_index(pcc_index *index, void *consumer_stream);
 int pcc_index_engine(const pcc_index *index, int *engine);
 /* force the engine for subsequent searches on this index */
 int pcc_index_set_engine(pcc_index *index, int engine);
+
+int pcc_index_set_tie_order(pcc_index *index, int ties);
 
 /* ---- k = 1 nearest neighbour ------------------------------------------------
  * replaces: N calls of KdTreeFLANN::nearestKSearch(pt, 1, idx, d2)
@@ -269,7 +280,8 @@ int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t st
  * counters of the last search on this index (host):
  *  stats[0] queries resolved by the GRID engine, [1] queries sent to the BRUTE
  *  fallback, [2] reference points valid, [3] grid cells, [4] pair evaluations
- *  (GRID engine, when counting is compiled in; else 0). */
+ *  (GRID engine, when counting is compiled in; else 0), [5] queries flagged as tied and [6] indices changed by
+ *  the FLANN walk (PCC_TIES_FLANN, last search). */
 int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
 /* HIP-event timing of the library's own kernels, recorded on the index's stream
  * (events of another stream would not see them).  After enabling, every

@@ -13,6 +13,7 @@ from pathlib import Path
 import numpy as np
 
 MEM_HOST, MEM_DEVICE = 0, 1
+TIES_LOWEST_INDEX, TIES_FLANN = 0, 1
 ENGINE_AUTO, ENGINE_BRUTE, ENGINE_GRID = 0, 1, 2
 KNN_MAX_K = 65536
 
@@ -29,7 +30,7 @@ SYMBOLS = [
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
-    "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device",
+    "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
 ]
 
 
@@ -70,6 +71,7 @@ def _load() -> C.CDLL:
     lib.pcc_index_size.argtypes = [vp, C.POINTER(sz)]
     lib.pcc_index_set_stream.argtypes = [vp, vp]
     lib.pcc_index_sync.argtypes = [vp]
+    lib.pcc_index_set_tie_order.argtypes = [vp, i32]
     lib.pcc_index_clone_to_device.argtypes = [vp, i32, C.POINTER(vp)]
     lib.pcc_index_wait_stream.argtypes = [vp, vp]
     lib.pcc_stream_wait_index.argtypes = [vp, vp]
@@ -251,6 +253,10 @@ class Index:
 
     def set_engine(self, engine: int):
         _check(LIB.pcc_index_set_engine(self._h, engine))
+
+    def set_tie_order(self, ties: int):
+        """TIES_LOWEST_INDEX (default) or TIES_FLANN: which of several equally near references nn1 / match_knn name"""
+        _check(LIB.pcc_index_set_tie_order(self._h, ties))
 
     def set_stream(self, stream_ptr: int):
         _check(LIB.pcc_index_set_stream(self._h, C.c_void_p(stream_ptr)))

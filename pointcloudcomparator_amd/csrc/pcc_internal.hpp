@@ -6,6 +6,7 @@
 #include <mutex>
 #include <string>
 #include "pcc_nn.h"
+#include "flann_order.hpp"
 
 // every PCC_SEED_STRIDE-th reference is a "seed": the exhaustive scan of the seeds bounds a far query's ball
 #define PCC_SEED_SHIFT 6
@@ -114,6 +115,12 @@ struct pcc_index {
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
         scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, vox_a, vox_b, vox_c;
+    // PCC_TIES_FLANN (flann_order.hpp): host-side kd-tree in FLANN's shape, built on first use after every set_input
+    int tie_mode = PCC_TIES_LOWEST_INDEX;
+    pcc::FlannOrder flann;
+    bool flann_valid = false;
+    pcc::DevBuf tie_buf;
+    uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     pcc::HostBuf host_a, host_b;  // large pinned read-back buffers
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -213,6 +220,8 @@ int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, 
 // ---- cluster.hip ------------------------------------------------------------------------
 int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t max_size,
                   int32_t* labels_dev /* n_orig, device */, int32_t* n_clusters, int32_t* sizes, int max_sizes);
+// ---- flann_order.hip: flags[i] = 1 when another reference shares query i's minimum distance --------
+int launch_tie_flags(pcc_index* ix, const float4* q, const unsigned long long* keys, size_t nq, uint8_t* flags);
 // ---- icp.hip -----------------------------------------------------------------------------
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,

@@ -138,3 +138,67 @@ def test_far_queries_take_the_seed_and_ball_route(gpu, monkeypatch):
             for _ in range(2):  # second call: the heuristic has seen the first call's fallbacks
                 idx, d2 = ix.nn1(b)
                 assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+
+
+# ---- PCC_TIES_FLANN: among equally near references, the one pcl::KdTreeFLANN's tree walk reaches first ---------------
+def _tie_clouds():
+    rng = np.random.default_rng(17)
+    base = rng.random((3000, 3), dtype=np.float32)
+    dup = np.concatenate([base, base[::-1], base[:700]])                      # exact duplicates: d2 = 0 ties
+    lattice = (rng.integers(0, 12, (6000, 3)) * np.float32(0.25)).astype(np.float32)  # many equidistant references
+    plane = rng.random((5000, 3), dtype=np.float32)
+    plane[:, 2] = 0.5
+    plane[::3] = np.round(plane[::3] * 8) / 8
+    small = (rng.integers(0, 5, (300, 3)) * np.float32(0.5)).astype(np.float32)       # BRUTE engine under AUTO
+    q_dup = np.concatenate([base[rng.integers(0, 3000, 800)], rng.random((400, 3), dtype=np.float32)])
+    q_lat = np.concatenate([(rng.integers(0, 12, (1500, 3)) * np.float32(0.25) + np.float32(0.125)).astype(np.float32),
+                            lattice[:500], rng.random((300, 3), dtype=np.float32) * 3])
+    q_plane = np.concatenate([plane[:600] + np.float32([0, 0, 0.25]), rng.random((600, 3), dtype=np.float32)])
+    q_small = (rng.integers(0, 9, (500, 3)) * np.float32(0.25)).astype(np.float32)
+    return [("duplicates", dup, q_dup), ("lattice", lattice, q_lat), ("plane", plane, q_plane), ("small", small, q_small)]
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_AUTO, capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_ties_flann_order_equals_the_kdtree_walk(gpu, engine):
+    for name, a, q in _tie_clouds():
+        fi, fd = oracle.KdTree(a).nn1_batch(q)          # FLANN restatement: first visited
+        li, ld = oracle.nn1_exhaustive(a, q)            # lowest index
+        assert (_bits(fd) == _bits(ld)).all()
+        assert (fi != li).sum() > 20, name              # the case is not vacuous
+        with capi.Index(a, engine=engine) as ix:
+            idx, d2 = ix.nn1(q)
+            assert (idx == li).all() and (_bits(d2) == _bits(ld)).all(), name
+            ix.set_tie_order(capi.TIES_FLANN)
+            idx, d2 = ix.nn1(q)
+            st = ix.stats()
+            assert (_bits(d2) == _bits(ld)).all(), name
+            assert (idx == fi).all(), (name, np.nonzero(idx != fi)[0][:5])
+            assert st[6] == (fi != li).sum() and st[5] >= st[6], (name, st[5], st[6])
+            ix.set_input(a[::-1].copy())                # a new cloud: the host tree is rebuilt
+            idx, _ = ix.nn1(q)
+            assert (idx == oracle.KdTree(a[::-1].copy()).nn1_batch(q)[0]).all(), name
+            ix.set_tie_order(capi.TIES_LOWEST_INDEX)
+            assert (ix.nn1(q)[0] == oracle.nn1_exhaustive(a[::-1].copy(), q)[0]).all()
+
+
+def test_ties_flann_device_buffers_and_match_knn(gpu):
+    import torch
+    name, a, q = _tie_clouds()[1]
+    fi, fd = oracle.KdTree(a).nn1_batch(q)
+    with capi.Index(torch.from_numpy(a).cuda()) as ix:
+        ix.set_tie_order(capi.TIES_FLANN)
+        idx, d2 = ix.nn1(torch.from_numpy(q).cuda())
+        assert (idx.cpu().numpy() == fi).all() and (_bits(d2.cpu().numpy()) == _bits(fd)).all()
+    # matchRIFTFeaturesKnn returns the matched indices to its caller (reference src/comparator.cpp:576-580)
+    rng = np.random.default_rng(3)
+    d1 = np.zeros((900, 32), np.float32)
+    d1[:, :3] = (rng.integers(0, 6, (900, 3)) * np.float32(0.1))
+    d2_ = np.zeros((700, 32), np.float32)
+    d2_[:, :3] = (rng.integers(0, 11, (700, 3)) * np.float32(0.05))
+    want = oracle.match_rift_knn(d1, d2_)
+    with capi.Index(d1) as ix:
+        low = ix.match_knn(d2_, 0.05)
+        ix.set_tie_order(capi.TIES_FLANN)
+        got = ix.match_knn(d2_, 0.05)
+    assert len(low) == len(want) and (low != want).any()
+    assert (got == want).all()
