@@ -151,7 +151,7 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) kv[u] = (j0 + u * CS_T < end) ? tmp_kv[j0 + u * CS_T] : make_uint2(0xffffffffu, 0u);
-        if (REFS) {
+        if (out_pts) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (kv[u].x != 0xffffffffu) v[u] = pts[kv[u].y];  // gather from the original-order array
@@ -160,12 +160,11 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
         for (int u = 0; u < 4; ++u) {
             if (kv[u].x == 0xffffffffu) continue;
             const unsigned int pos = atomicAdd(&cnt[kv[u].x - cell0], 1u);
-            if (REFS) {
+            if (out_pts) {
                 v[u].w = __int_as_float((int)kv[u].y);  // cell-sorted copies carry the packed position
                 out_pts[pos] = v[u];
-            } else {
-                out_order[pos] = kv[u].y;
             }
+            if (out_order) out_order[pos] = kv[u].y;
         }
     }
 }
@@ -176,6 +175,12 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
 int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4* out_pts, unsigned int* out_order,
               unsigned int* cell_start, unsigned int** n_sorted_dev, const GridDev* gd_override,
               unsigned int nc_cap_override) {
+    // clouds past the L2s: three coalesced levels with the payload carried along (cellsort_mp.hip)
+    // (the index-only sort of the queries moves 8 bytes per point where this one moves 16: it stays ahead there, 340 vs
+    // 375 us at 10M)
+    static const size_t mp_min = getenv("PCC_SORT_MP_MIN") ? (size_t)atof(getenv("PCC_SORT_MP_MIN")) : (size_t)3000000;
+    static const size_t mp_min_q = getenv("PCC_SORT_MP_MIN_Q") ? (size_t)atof(getenv("PCC_SORT_MP_MIN_Q")) : ~(size_t)0;
+    if (n_pts >= (refs ? mp_min : mp_min_q)) return cell_sort_mp(ix, pts, n_pts, refs, out_pts, out_order, cell_start, n_sorted_dev, gd_override, nc_cap_override);
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)n_pts;
     // planned from the host-known upper bound of the cell count; buckets past the actual grid stay empty

@@ -1,0 +1,287 @@
+// cellsort_mp.hip -- cell sort for clouds that do not fit the L2s (gfx950): three coalesced levels, the 16-byte
+// payload travels with its key, nothing is gathered.
+//
+// cellsort.hip sorts (cell, index) pairs in two levels and lets the last pass GATHER the 16-byte points through the
+// sort order.  Up to ~2M points everything it touches stays in the 32 MiB of L2 and that is the fastest form.  At
+// 10M points the pair scatter writes 2048 streams per workgroup in 76-byte pieces and the gather reads one 128-byte
+// line per 16 bytes used out of a 160 MB array: 172 us + 453 us per sort, ~0.9 TB/s (profiles/r01_c3_kernel_stats.csv).
+// Here every level moves whole points between buffers, reading its input front to back and writing long runs:
+//   level 1   B1 <= 256 buckets of F1 = B2 * F2 cells.  Per-workgroup LDS histogram, scan of the B1 x G matrix,
+//             scatter through LDS cursors: a workgroup's slice lands in B1 runs of ~slice / B1 points.
+//   level 2   inside every level-1 bucket, B2 = 128 buckets of F2 cells.  The input is already grouped, so a slice
+//             touches a short window of (b1, b2) pairs: LDS counts over the window, ONE returning global atomic per
+//             non-empty pair reserves the slice's run in that bucket, LDS cursors place the points.
+//   level 3   one workgroup per (b1, b2) bucket, as cellsort.hip's last pass: LDS histogram over its F2 cells, scan
+//             (= cell_start), cursor scatter -- but the points are read front to back from level 2's output.
+// Same results as cell_sort() (order inside a cell is arbitrary in both); plays the role of
+// KDTreeSingleIndex::buildIndex (reference src/comparator.cpp:565) and of the per-call query ordering.
+#include "pcc_internal.hpp"
+#include "grid_device.hpp"
+#include "lane_ops.hpp"
+
+namespace pcc {
+
+constexpr int MP_T = 256;
+constexpr unsigned int MP_F2 = 2048;      // cells per level-2 bucket (8 KiB of LDS counters in level 3)
+constexpr unsigned int MP_B2 = 128;       // level-2 buckets per level-1 bucket
+constexpr unsigned int MP_MAX_B1 = 256;
+constexpr unsigned int MP_MAX_G = 512;    // level-1 workgroups
+constexpr unsigned int MP_SLICE2 = 8192;  // points per level-2 workgroup
+constexpr unsigned int MP_WIN = 8;        // level-1 buckets a level-2 slice keeps LDS counters for
+
+struct MpPlan {
+    unsigned int F1, F2, B1, G1, slice1;
+};
+static MpPlan mp_plan(unsigned int ncells_cap, unsigned int n) {
+    MpPlan p;
+    p.F2 = MP_F2;
+    while ((unsigned long long)p.F2 * MP_B2 * MP_MAX_B1 < (unsigned long long)ncells_cap + 1) p.F2 *= 2;
+    p.F1 = p.F2 * MP_B2;
+    p.B1 = (ncells_cap + p.F1) / p.F1;  // ceil((ncells_cap + 1) / F1)
+    p.G1 = (n + 16383) / 16384;
+    if (p.G1 > MP_MAX_G) p.G1 = MP_MAX_G;
+    if (p.G1 < 1) p.G1 = 1;
+    p.slice1 = (n + p.G1 - 1) / p.G1;
+    return p;
+}
+
+__device__ __forceinline__ unsigned int mp_cell(const float4& v, const GridParams& g, bool voxel) {
+    return voxel ? voxel_id(v, g) : cell_id(v, g);
+}
+
+// ---- level 1 ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MP_T)
+k_mp_hist1(const float4* __restrict__ pts, unsigned int n, const GridDev* __restrict__ gd, unsigned int F1, unsigned int B1,
+           unsigned int slice, unsigned int* __restrict__ H) {
+    __shared__ unsigned int cnt[MP_MAX_B1];
+    const GridParams g = gd->g;
+    const bool voxel = gd->voxel != 0;
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) cnt[b] = 0;
+    __syncthreads();
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * MP_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MP_T < end) v[u] = pts[i0 + u * MP_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MP_T < end && __float_as_int(v[u].w) >= 0) atomicAdd(&cnt[mp_cell(v[u], g, voxel) / F1], 1u);
+    }
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) H[(size_t)b * gridDim.x + blockIdx.x] = cnt[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)B1 * gridDim.x] = 0;  // slot of the grand total
+}
+
+__global__ void __launch_bounds__(MP_T)
+k_mp_scatter1(const float4* __restrict__ pts, unsigned int n, const GridDev* __restrict__ gd, unsigned int F1, unsigned int B1,
+              unsigned int slice, const unsigned int* __restrict__ H, float4* __restrict__ out) {
+    __shared__ unsigned int cur[MP_MAX_B1];
+    const GridParams g = gd->g;
+    const bool voxel = gd->voxel != 0;
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) cur[b] = H[(size_t)b * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * MP_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MP_T < end) v[u] = pts[i0 + u * MP_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MP_T < end && __float_as_int(v[u].w) >= 0) out[atomicAdd(&cur[mp_cell(v[u], g, voxel) / F1], 1u)] = v[u];
+    }
+}
+
+// ---- level 2 ---------------------------------------------------------------------------------------------------
+// pair id of a cell: (level-1 bucket) * B2 + (level-2 bucket inside it)
+__device__ __forceinline__ unsigned int mp_pair(unsigned int c, unsigned int F1, unsigned int F2) {
+    return (c / F1) * MP_B2 + (c % F1) / F2;
+}
+
+// PLACE = false: C[pair] += points of the slice in that pair.  PLACE = true: C holds the cursors (scanned counts);
+// the slice reserves its runs and writes its points.
+template <bool PLACE>
+__global__ void __launch_bounds__(MP_T)
+k_mp_level2(const float4* __restrict__ in, const unsigned int* __restrict__ n_valid_ptr, const GridDev* __restrict__ gd,
+            unsigned int F1, unsigned int F2, unsigned int* __restrict__ C, float4* __restrict__ out) {
+    __shared__ unsigned int cnt[MP_WIN * MP_B2];
+    const GridParams g = gd->g;
+    const bool voxel = gd->voxel != 0;
+    const unsigned int n = *n_valid_ptr;
+    const unsigned int beg = blockIdx.x * MP_SLICE2, end = min(n, beg + MP_SLICE2);
+    if (beg >= end) return;
+    // the input is grouped by level-1 bucket: the slice's first point names the start of the LDS window
+    const unsigned int w0 = (mp_cell(in[beg], g, voxel) / F1) * MP_B2;
+    for (unsigned int k = threadIdx.x; k < MP_WIN * MP_B2; k += MP_T) cnt[k] = 0;
+    __syncthreads();
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * MP_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MP_T < end) v[u] = in[i0 + u * MP_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * MP_T >= end) break;
+            const unsigned int pr = mp_pair(mp_cell(v[u], g, voxel), F1, F2);
+            if (pr - w0 < MP_WIN * MP_B2) atomicAdd(&cnt[pr - w0], 1u);
+            else if (!PLACE) atomicAdd(&C[pr], 1u);              // beyond the window (tiny level-1 buckets): straight to memory
+            else out[atomicAdd(&C[pr], 1u)] = v[u];
+        }
+    }
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < MP_WIN * MP_B2; k += MP_T) {
+        const unsigned int c = cnt[k];
+        if (c) {
+            if (!PLACE) atomicAdd(&C[w0 + k], c);
+            else cnt[k] = atomicAdd(&C[w0 + k], c);  // the slice's run in that bucket: count -> cursor
+        } else if (PLACE) cnt[k] = 0;
+    }
+    if (!PLACE) return;
+    __syncthreads();
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * MP_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * MP_T < end) v[u] = in[i0 + u * MP_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * MP_T >= end) break;
+            const unsigned int pr = mp_pair(mp_cell(v[u], g, voxel), F1, F2);
+            if (pr - w0 < MP_WIN * MP_B2) out[atomicAdd(&cnt[pr - w0], 1u)] = v[u];
+        }
+    }
+}
+
+// C[0 .. np) counts -> exclusive prefix in place (one workgroup: np <= 256 * 128 pairs, a contiguous chunk per
+// thread); base[k] = the same prefix kept for level 3 (C itself turns into cursors), base[np] = total
+__global__ void __launch_bounds__(1024)
+k_mp_scan_pairs(unsigned int* __restrict__ C, unsigned int* __restrict__ base, unsigned int np) {
+    __shared__ unsigned int wsum[16];
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int per = (np + 1023) / 1024;
+    const unsigned int k0 = threadIdx.x * per, k1 = min(np, k0 + per);
+    unsigned int s = 0;
+    for (unsigned int k = k0; k < k1; ++k) s += C[k];
+    const unsigned int inc = wave_incl_scan_add(s);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int run = inc - s, total = 0;
+    for (unsigned int w = 0; w < 16; ++w) {
+        if (w < wave) run += wsum[w];
+        total += wsum[w];
+    }
+    for (unsigned int k = k0; k < k1; ++k) {
+        const unsigned int c = C[k];
+        C[k] = run;
+        base[k] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) base[np] = total;
+}
+
+// ---- level 3 ---------------------------------------------------------------------------------------------------
+template <bool REFS>
+__global__ void __launch_bounds__(MP_T)
+k_mp_fine(const float4* __restrict__ in, const unsigned int* __restrict__ base, const GridDev* __restrict__ gd,
+          unsigned int F2, float4* __restrict__ out_pts, unsigned int* __restrict__ out_order,
+          unsigned int* __restrict__ cell_start) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // F2 counters + 4 scan words
+    unsigned int* cnt = lds;
+    unsigned int* wsum = lds + F2;
+    const GridParams g = gd->g;
+    const bool voxel = gd->voxel != 0;
+    const unsigned int ncells = (unsigned int)g.ncells;
+    const unsigned int b = blockIdx.x;
+    const unsigned int cell0 = b * F2;
+    if (cell0 > ncells) return;  // (entry [ncells] of cell_start belongs to the bucket that holds it)
+    const unsigned int beg = base[b], end = base[b + 1];
+    if (!REFS && beg == end) return;
+    for (unsigned int f = threadIdx.x; f < F2; f += MP_T) cnt[f] = 0;
+    __syncthreads();
+    for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * MP_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u * MP_T < end) v[u] = in[j0 + u * MP_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u * MP_T < end) atomicAdd(&cnt[mp_cell(v[u], g, voxel) - cell0], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the F2 counters: thread t owns a contiguous chunk
+    const unsigned int per = (F2 + MP_T - 1) / MP_T;
+    const unsigned int f0 = threadIdx.x * per, f1 = min(F2, f0 + per);
+    unsigned int s = 0;
+    for (unsigned int f = f0; f < f1; ++f) s += cnt[f];
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int inc = wave_incl_scan_add(s);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int run = beg + inc - s;
+    for (unsigned int w = 0; w < wave; ++w) run += wsum[w];
+    for (unsigned int f = f0; f < f1; ++f) {
+        const unsigned int c = cnt[f];
+        cnt[f] = run;  // becomes the cursor of cell f
+        if (REFS && cell0 + f <= ncells) cell_start[cell0 + f] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * MP_T) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u * MP_T < end) v[u] = in[j0 + u * MP_T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u * MP_T >= end) break;
+            const unsigned int pos = atomicAdd(&cnt[mp_cell(v[u], g, voxel) - cell0], 1u);
+            if (out_pts) out_pts[pos] = v[u];  // .w still carries the packed position (the original index)
+            if (out_order) out_order[pos] = (unsigned int)__float_as_int(v[u].w);
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+// Same contract as cell_sort(); additionally out_pts may be given for queries (cell-sorted copies, .w = position in
+// the query array).  Uses ix->mp_a / mp_b as the two intermediate point buffers.
+int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4* out_pts, unsigned int* out_order,
+                 unsigned int* cell_start, unsigned int** n_sorted_dev, const GridDev* gd_override,
+                 unsigned int nc_cap_override) {
+    hipStream_t s = ix->stream;
+    const unsigned int n = (unsigned int)n_pts;
+    const unsigned int ncap = gd_override ? nc_cap_override : ix->nc_cap;
+    const MpPlan p = mp_plan(ncap, n);
+    const GridDev* gd = gd_override ? gd_override : ix->d_grid.as<GridDev>();
+    const unsigned int np = p.B1 * MP_B2;  // (b1, b2) pairs
+    PCC_TRY(ix->mp_a.reserve((size_t)n * sizeof(float4) + 256));
+    PCC_TRY(ix->mp_b.reserve((size_t)n * sizeof(float4) + 256));
+    const size_t h_elems = (size_t)p.B1 * p.G1 + 1;
+    PCC_TRY(ix->scratch_b.reserve(((h_elems + 3) & ~(size_t)3) * sizeof(unsigned int)));
+    PCC_TRY(ix->mp_c.reserve(((size_t)np * 2 + 8) * sizeof(unsigned int)));
+    unsigned int* H = ix->scratch_b.as<unsigned int>();
+    unsigned int* C = ix->mp_c.as<unsigned int>();   // counts -> cursors
+    unsigned int* base = C + np;                     // np + 1 bucket starts for level 3
+    float4* t1 = ix->mp_a.as<float4>();
+    float4* t2 = ix->mp_b.as<float4>();
+    hipLaunchKernelGGL(k_mp_hist1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H);
+    PCC_HIP(hipGetLastError());
+    PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
+    unsigned int* n_valid = H + h_elems - 1;  // grand total == number of valid points
+    if (n_sorted_dev) *n_sorted_dev = n_valid;
+    hipLaunchKernelGGL(k_mp_scatter1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+    PCC_HIP(hipMemsetAsync(C, 0, (size_t)np * sizeof(unsigned int), s));
+    const unsigned int g2 = (n + MP_SLICE2 - 1) / MP_SLICE2;
+    hipLaunchKernelGGL((k_mp_level2<false>), dim3(g2), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
+    hipLaunchKernelGGL(k_mp_scan_pairs, dim3(1), dim3(1024), 0, s, C, base, np);
+    hipLaunchKernelGGL((k_mp_level2<true>), dim3(g2), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
+    const size_t lds3 = ((size_t)p.F2 + 4) * sizeof(unsigned int);
+    if (refs)
+        hipLaunchKernelGGL((k_mp_fine<true>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+    else
+        hipLaunchKernelGGL((k_mp_fine<false>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+}  // namespace pcc

@@ -40,19 +40,29 @@ unsigned int grid_nc_cap(size_t n) {
 // box is `ppc` points per cell, grown until the cell count fits nc_cap.  Keeping this on the
 // device removes the host round trip (D2H, wait, launch) from every index build: 46 us of a
 // 385 us step at 1M points.
-// k-th largest value over the lanes of a wave (lanes that do not take part pass -inf)
-__device__ __forceinline__ float wave_kth_max(float v, int k) {
+// k-th largest of each of six values over the lanes of a wave (lanes that do not take part pass -inf).  The six
+// reductions run side by side: a reduction step is a cross-lane move with ~100 clk of latency, and six independent
+// chains hide it where six reductions one after the other did not (26 us -> 5 us for this kernel).
+__device__ __forceinline__ void wave_kth_max6(float v[6], int k) {
     const unsigned int lane = threadIdx.x & 63;
-    float m = v;
+    float m[6];
     for (int it = 0; it < k; ++it) {
-        m = v;
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m[a] = v[a];
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = fmaxf(m[a], __shfl_xor(m[a], off, 64));
+        }
         if (it + 1 < k) {
-            const unsigned long long hit = __ballot(v == m);
-            if (hit && lane == (unsigned int)__ffsll((long long)hit) - 1) v = -__builtin_inff();
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const unsigned long long hit = __ballot(v[a] == m[a]);
+                if (hit && lane == (unsigned int)__ffsll((long long)hit) - 1) v[a] = -__builtin_inff();
+            }
         }
     }
-    return m;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = m[a];
 }
 
 // trim_k > 0: the grid is laid over a TRIMMED box.  Every row of `blk` is the bounding box of an interleaved
@@ -76,11 +86,13 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
                 if (nblk - g0 < 16) continue;                  // a short tail group says little
                 const int b = g0 + lane;
                 const float* r = blk + (size_t)(b < nblk ? b : 0) * 8;
+                float e[6];  // -lo (so that the smallest lo is a maximum too), hi
                 for (int a = 0; a < 3; ++a) {
-                    const float l = b < nblk ? r[1 + a] : __builtin_inff(), h = b < nblk ? r[4 + a] : -__builtin_inff();
-                    th[a] = fmaxf(th[a], wave_kth_max(h, trim_k));
-                    tl[a] = fminf(tl[a], -wave_kth_max(-l, trim_k));
+                    e[a] = b < nblk ? -r[1 + a] : -__builtin_inff();
+                    e[3 + a] = b < nblk ? r[4 + a] : -__builtin_inff();
                 }
+                wave_kth_max6(e, trim_k);
+                for (int a = 0; a < 3; ++a) { tl[a] = fminf(tl[a], -e[a]); th[a] = fmaxf(th[a], e[3 + a]); }
             }
         }
         if (lane == 0)

@@ -114,7 +114,8 @@ struct pcc_index {
     unsigned int last_fallback_seen = 0;  // fallback count of an earlier search (heuristic only, may be stale)
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
-        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, vox_a, vox_b, vox_c;
+        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, vox_a, vox_b, vox_c,
+        mp_a, mp_b, mp_c;  // cellsort_mp.hip: two intermediate point buffers, bucket counters
     // PCC_TIES_FLANN (flann_order.hpp): host-side kd-tree in FLANN's shape, built on first use after every set_input
     int tie_mode = PCC_TIES_LOWEST_INDEX;
     pcc::FlannOrder flann;
@@ -198,6 +199,10 @@ float grid_slack(const GridParams& g);
 int cell_sort(pcc_index* ix, const float4* pts, size_t n, bool refs, float4* out_pts, unsigned int* out_order,
               unsigned int* cell_start, unsigned int** n_sorted_dev, const GridDev* gd_override = nullptr,
               unsigned int nc_cap_override = 0);
+// ---- cellsort_mp.hip: the same contract in three coalesced levels (large clouds); out_pts may also be given for queries
+int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n, bool refs, float4* out_pts, unsigned int* out_order,
+                 unsigned int* cell_start, unsigned int** n_sorted_dev, const GridDev* gd_override = nullptr,
+                 unsigned int nc_cap_override = 0);
 // ---- voxel.hip: pcl::VoxelGrid (leaf-lattice centroids) ---------------------------------------------
 int voxel_grid(pcc_index* ctx, const void* pts, size_t n, size_t stride, int mem, float leaf, int has_rgb,
                void* out, size_t out_stride, size_t* out_n);
