@@ -26,7 +26,8 @@ constexpr unsigned int MP_F2 = 2048;      // cells per level-2 bucket (8 KiB of 
 constexpr unsigned int MP_B2 = 128;       // level-2 buckets per level-1 bucket
 constexpr unsigned int MP_MAX_B1 = 256;
 constexpr unsigned int MP_MAX_G = 512;    // level-1 workgroups
-constexpr unsigned int MP_SLICE2 = 8192;  // points per level-2 workgroup
+constexpr unsigned int MP_SLICE2 = 8192;  // points per level-2 workgroup (counting form)
+constexpr unsigned int MP_STAGE_BYTES = 32768;  // LDS the placing form stages its slice in (2048 points or 4096 pairs)
 constexpr unsigned int MP_WIN = 8;        // level-1 buckets a level-2 slice keeps LDS counters for
 
 struct MpPlan {
@@ -45,8 +46,18 @@ static MpPlan mp_plan(unsigned int ncells_cap, unsigned int n) {
     return p;
 }
 
+// What travels through the levels: the packed point itself (reference clouds: the last level writes the cell-sorted
+// copies) or, for query clouds that only need their ORDER, the 8-byte pair (cell, position) made once in level 1.
 __device__ __forceinline__ unsigned int mp_cell(const float4& v, const GridParams& g, bool voxel) {
     return voxel ? voxel_id(v, g) : cell_id(v, g);
+}
+__device__ __forceinline__ unsigned int mp_cell(const uint2& v, const GridParams&, bool) { return v.x; }
+__device__ __forceinline__ unsigned int mp_position(const float4& v) { return (unsigned int)__float_as_int(v.w); }
+__device__ __forceinline__ unsigned int mp_position(const uint2& v) { return v.y; }
+template <class E> __device__ __forceinline__ E mp_make(const float4& v, unsigned int cell);
+template <> __device__ __forceinline__ float4 mp_make<float4>(const float4& v, unsigned int) { return v; }
+template <> __device__ __forceinline__ uint2 mp_make<uint2>(const float4& v, unsigned int cell) {
+    return make_uint2(cell, (unsigned int)__float_as_int(v.w));
 }
 
 // ---- level 1 ---------------------------------------------------------------------------------------------------
@@ -73,9 +84,10 @@ k_mp_hist1(const float4* __restrict__ pts, unsigned int n, const GridDev* __rest
     if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)B1 * gridDim.x] = 0;  // slot of the grand total
 }
 
+template <class E>
 __global__ void __launch_bounds__(MP_T)
 k_mp_scatter1(const float4* __restrict__ pts, unsigned int n, const GridDev* __restrict__ gd, unsigned int F1, unsigned int B1,
-              unsigned int slice, const unsigned int* __restrict__ H, float4* __restrict__ out) {
+              unsigned int slice, const unsigned int* __restrict__ H, E* __restrict__ out) {
     __shared__ unsigned int cur[MP_MAX_B1];
     const GridParams g = gd->g;
     const bool voxel = gd->voxel != 0;
@@ -89,7 +101,10 @@ k_mp_scatter1(const float4* __restrict__ pts, unsigned int n, const GridDev* __r
             if (i0 + u * MP_T < end) v[u] = pts[i0 + u * MP_T];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * MP_T < end && __float_as_int(v[u].w) >= 0) out[atomicAdd(&cur[mp_cell(v[u], g, voxel) / F1], 1u)] = v[u];
+            if (i0 + u * MP_T < end && __float_as_int(v[u].w) >= 0) {
+                const unsigned int c = mp_cell(v[u], g, voxel);
+                out[atomicAdd(&cur[c / F1], 1u)] = mp_make<E>(v[u], c);
+            }
     }
 }
 
@@ -100,29 +115,33 @@ __device__ __forceinline__ unsigned int mp_pair(unsigned int c, unsigned int F1,
 }
 
 // PLACE = false: C[pair] += points of the slice in that pair.  PLACE = true: C holds the cursors (scanned counts);
-// the slice reserves its runs and writes its points.
-template <bool PLACE>
+// the slice is read ONCE into LDS, reserves its runs and writes its points from there.
+template <bool PLACE, class E>
 __global__ void __launch_bounds__(MP_T)
-k_mp_level2(const float4* __restrict__ in, const unsigned int* __restrict__ n_valid_ptr, const GridDev* __restrict__ gd,
-            unsigned int F1, unsigned int F2, unsigned int* __restrict__ C, float4* __restrict__ out) {
+k_mp_level2(const E* __restrict__ in, const unsigned int* __restrict__ n_valid_ptr, const GridDev* __restrict__ gd,
+            unsigned int F1, unsigned int F2, unsigned int* __restrict__ C, E* __restrict__ out) {
+    constexpr unsigned int SLICE = PLACE ? MP_STAGE_BYTES / sizeof(E) : MP_SLICE2;
     __shared__ unsigned int cnt[MP_WIN * MP_B2];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[PLACE ? MP_STAGE_BYTES : 16];
+    E* stage = reinterpret_cast<E*>(stage_raw);
     const GridParams g = gd->g;
     const bool voxel = gd->voxel != 0;
     const unsigned int n = *n_valid_ptr;
-    const unsigned int beg = blockIdx.x * MP_SLICE2, end = min(n, beg + MP_SLICE2);
+    const unsigned int beg = blockIdx.x * SLICE, end = min(n, beg + SLICE);
     if (beg >= end) return;
     // the input is grouped by level-1 bucket: the slice's first point names the start of the LDS window
     const unsigned int w0 = (mp_cell(in[beg], g, voxel) / F1) * MP_B2;
     for (unsigned int k = threadIdx.x; k < MP_WIN * MP_B2; k += MP_T) cnt[k] = 0;
     __syncthreads();
     for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * MP_T) {
-        float4 v[4];
+        E v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (i0 + u * MP_T < end) v[u] = in[i0 + u * MP_T];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i0 + u * MP_T >= end) break;
+            if (PLACE) stage[i0 + u * MP_T - beg] = v[u];
             const unsigned int pr = mp_pair(mp_cell(v[u], g, voxel), F1, F2);
             if (pr - w0 < MP_WIN * MP_B2) atomicAdd(&cnt[pr - w0], 1u);
             else if (!PLACE) atomicAdd(&C[pr], 1u);              // beyond the window (tiny level-1 buckets): straight to memory
@@ -135,21 +154,14 @@ k_mp_level2(const float4* __restrict__ in, const unsigned int* __restrict__ n_va
         if (c) {
             if (!PLACE) atomicAdd(&C[w0 + k], c);
             else cnt[k] = atomicAdd(&C[w0 + k], c);  // the slice's run in that bucket: count -> cursor
-        } else if (PLACE) cnt[k] = 0;
+        }
     }
     if (!PLACE) return;
     __syncthreads();
-    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 4 * MP_T) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i0 + u * MP_T < end) v[u] = in[i0 + u * MP_T];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u * MP_T >= end) break;
-            const unsigned int pr = mp_pair(mp_cell(v[u], g, voxel), F1, F2);
-            if (pr - w0 < MP_WIN * MP_B2) out[atomicAdd(&cnt[pr - w0], 1u)] = v[u];
-        }
+    for (unsigned int j = threadIdx.x; j < end - beg; j += MP_T) {
+        const E v = stage[j];
+        const unsigned int pr = mp_pair(mp_cell(v, g, voxel), F1, F2);
+        if (pr - w0 < MP_WIN * MP_B2) out[atomicAdd(&cnt[pr - w0], 1u)] = v;
     }
 }
 
@@ -180,10 +192,13 @@ k_mp_scan_pairs(unsigned int* __restrict__ C, unsigned int* __restrict__ base, u
     if (threadIdx.x == 0) base[np] = total;
 }
 
+__device__ __forceinline__ void mp_store_point(float4* out, unsigned int pos, const float4& v) { if (out) out[pos] = v; }
+__device__ __forceinline__ void mp_store_point(float4*, unsigned int, const uint2&) {}
+
 // ---- level 3 ---------------------------------------------------------------------------------------------------
-template <bool REFS>
+template <bool REFS, class E>
 __global__ void __launch_bounds__(MP_T)
-k_mp_fine(const float4* __restrict__ in, const unsigned int* __restrict__ base, const GridDev* __restrict__ gd,
+k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ base, const GridDev* __restrict__ gd,
           unsigned int F2, float4* __restrict__ out_pts, unsigned int* __restrict__ out_order,
           unsigned int* __restrict__ cell_start) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // F2 counters + 4 scan words
@@ -200,7 +215,7 @@ k_mp_fine(const float4* __restrict__ in, const unsigned int* __restrict__ base, 
     for (unsigned int f = threadIdx.x; f < F2; f += MP_T) cnt[f] = 0;
     __syncthreads();
     for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * MP_T) {
-        float4 v[4];
+        E v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (j0 + u * MP_T < end) v[u] = in[j0 + u * MP_T];
@@ -228,7 +243,7 @@ k_mp_fine(const float4* __restrict__ in, const unsigned int* __restrict__ base, 
     }
     __syncthreads();
     for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * MP_T) {
-        float4 v[4];
+        E v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (j0 + u * MP_T < end) v[u] = in[j0 + u * MP_T];
@@ -236,8 +251,8 @@ k_mp_fine(const float4* __restrict__ in, const unsigned int* __restrict__ base, 
         for (int u = 0; u < 4; ++u) {
             if (j0 + u * MP_T >= end) break;
             const unsigned int pos = atomicAdd(&cnt[mp_cell(v[u], g, voxel) - cell0], 1u);
-            if (out_pts) out_pts[pos] = v[u];  // .w still carries the packed position (the original index)
-            if (out_order) out_order[pos] = (unsigned int)__float_as_int(v[u].w);
+            mp_store_point(out_pts, pos, v[u]);  // .w still carries the packed position (the original index)
+            if (out_order) out_order[pos] = mp_position(v[u]);
         }
     }
 }
@@ -262,24 +277,39 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
     unsigned int* H = ix->scratch_b.as<unsigned int>();
     unsigned int* C = ix->mp_c.as<unsigned int>();   // counts -> cursors
     unsigned int* base = C + np;                     // np + 1 bucket starts for level 3
-    float4* t1 = ix->mp_a.as<float4>();
-    float4* t2 = ix->mp_b.as<float4>();
     hipLaunchKernelGGL(k_mp_hist1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
     unsigned int* n_valid = H + h_elems - 1;  // grand total == number of valid points
     if (n_sorted_dev) *n_sorted_dev = n_valid;
-    hipLaunchKernelGGL(k_mp_scatter1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
-    PCC_HIP(hipMemsetAsync(C, 0, (size_t)np * sizeof(unsigned int), s));
-    const unsigned int g2 = (n + MP_SLICE2 - 1) / MP_SLICE2;
-    hipLaunchKernelGGL((k_mp_level2<false>), dim3(g2), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
-    hipLaunchKernelGGL(k_mp_scan_pairs, dim3(1), dim3(1024), 0, s, C, base, np);
-    hipLaunchKernelGGL((k_mp_level2<true>), dim3(g2), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
     const size_t lds3 = ((size_t)p.F2 + 4) * sizeof(unsigned int);
-    if (refs)
-        hipLaunchKernelGGL((k_mp_fine<true>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
-    else
-        hipLaunchKernelGGL((k_mp_fine<false>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+    PCC_HIP(hipMemsetAsync(C, 0, (size_t)np * sizeof(unsigned int), s));
+    const unsigned int g2c = (n + MP_SLICE2 - 1) / MP_SLICE2;
+    if (out_pts) {  // the points travel (reference clouds)
+        float4* t1 = ix->mp_a.as<float4>();
+        float4* t2 = ix->mp_b.as<float4>();
+        const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(float4) - 1) / (MP_STAGE_BYTES / sizeof(float4));
+        hipLaunchKernelGGL((k_mp_scatter1<float4>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+        hipLaunchKernelGGL((k_mp_level2<false, float4>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
+        hipLaunchKernelGGL(k_mp_scan_pairs, dim3(1), dim3(1024), 0, s, C, base, np);
+        hipLaunchKernelGGL((k_mp_level2<true, float4>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
+        if (refs)
+            hipLaunchKernelGGL((k_mp_fine<true, float4>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+        else
+            hipLaunchKernelGGL((k_mp_fine<false, float4>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+    } else {        // only the order is wanted (query clouds): (cell, position) pairs travel, half the bytes
+        uint2* t1 = ix->mp_a.as<uint2>();
+        uint2* t2 = ix->mp_b.as<uint2>();
+        const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(uint2) - 1) / (MP_STAGE_BYTES / sizeof(uint2));
+        hipLaunchKernelGGL((k_mp_scatter1<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+        hipLaunchKernelGGL((k_mp_level2<false, uint2>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
+        hipLaunchKernelGGL(k_mp_scan_pairs, dim3(1), dim3(1024), 0, s, C, base, np);
+        hipLaunchKernelGGL((k_mp_level2<true, uint2>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
+        if (refs)
+            hipLaunchKernelGGL((k_mp_fine<true, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+        else
+            hipLaunchKernelGGL((k_mp_fine<false, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+    }
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
