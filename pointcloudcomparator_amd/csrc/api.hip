@@ -86,14 +86,14 @@ struct DeviceGuard {
 // host: one H2D copy of the raw AoS, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
                         DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr,
-                        unsigned int* zero_word = nullptr, float4* seeds = nullptr) {
+                        unsigned int* zero_word = nullptr, float4* seeds = nullptr, unsigned long long* invalid_keys = nullptr) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds);
+    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys);
 }
 
 static int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -107,10 +107,12 @@ static int check_points(const void* pts, size_t n, size_t stride, int mem) {
 // queries -> ix->q_packed (float4, w < 0 marks a non-finite query)
 static int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem) {
     PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
-    // the pack kernel also zeroes the GRID engine's fallback counter (small + 32)
+    PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
+    // the pack kernel also zeroes the GRID engine's fallback counter (small + 32) and presets the result key of
+    // every non-finite query to "nothing found"
     ix->fb_zeroed = true;
     return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>(), nullptr, nullptr,
-                        ix->small.as<unsigned int>() + 32);
+                        ix->small.as<unsigned int>() + 32, nullptr, ix->out_packed.as<unsigned long long>());
 }
 
 // deliver device results to the caller's memory space
@@ -499,7 +501,7 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), nq, didx, dd2,
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, nq, didx, dd2,
                           ix->small.as<unsigned int>() + 32, static_cast<unsigned int*>(ix->pinned) + 40));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
@@ -980,7 +982,7 @@ int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int me
             didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
             dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
         }
-        PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n, didx, dd2));
+        PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n, didx, dd2));
         if (mem == PCC_MEM_HOST) {
             PCC_TRY(deliver(ix, didx, idx, n, mem));
             PCC_TRY(deliver(ix, dd2, d2, n, mem));
@@ -1089,7 +1091,7 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
     if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, n2));
     PCC_TRY(ix->out_idx.reserve(n2 * sizeof(int32_t)));
     PCC_TRY(ix->out_d2.reserve(n2 * sizeof(float)));
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), ix->q_packed.as<float4>(), n2, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n2, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));
     ev_mark(ix, EV_CALL1);
     std::vector<int32_t> hi(n2);
     std::vector<float> hd(n2);

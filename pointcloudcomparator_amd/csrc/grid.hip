@@ -40,19 +40,27 @@ unsigned int grid_nc_cap(size_t n) {
 // box is `ppc` points per cell, grown until the cell count fits nc_cap.  Keeping this on the
 // device removes the host round trip (D2H, wait, launch) from every index build: 46 us of a
 // 385 us step at 1M points.
-// k-th largest of each of six values over the lanes of a wave (lanes that do not take part pass -inf).  The six
-// reductions run side by side: a reduction step is a cross-lane move with ~100 clk of latency, and six independent
-// chains hide it where six reductions one after the other did not (26 us -> 5 us for this kernel).
+// maximum over the 64 lanes, in every lane: DPP row shifts + row broadcasts (no LDS crossbar: a __shfl_xor chain cost
+// this kernel 11 us), the result read back from lane 63
+__device__ __forceinline__ float wave_max_f32(float x) {
+#define PCC_MAX_STEP(CTRL, ROWMASK) \
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000u, __float_as_int(x), CTRL, ROWMASK, 0xf, false)))
+    PCC_MAX_STEP(0x111, 0xf);  // row_shr:1
+    PCC_MAX_STEP(0x112, 0xf);  // row_shr:2
+    PCC_MAX_STEP(0x114, 0xf);  // row_shr:4
+    PCC_MAX_STEP(0x118, 0xf);  // row_shr:8
+    PCC_MAX_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    PCC_MAX_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef PCC_MAX_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+// k-th largest of each of six values over the lanes of a wave (lanes that do not take part pass -inf)
 __device__ __forceinline__ void wave_kth_max6(float v[6], int k) {
     const unsigned int lane = threadIdx.x & 63;
     float m[6];
     for (int it = 0; it < k; ++it) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) m[a] = v[a];
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = fmaxf(m[a], __shfl_xor(m[a], off, 64));
-        }
+        for (int a = 0; a < 6; ++a) m[a] = wave_max_f32(v[a]);
         if (it + 1 < k) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -72,17 +80,17 @@ __device__ __forceinline__ void wave_kth_max6(float v[6], int k) {
 // exhaustive fallback).  Points beyond the box fall into the boundary cells, which every search already treats
 // as open-ended (cell_coord clamps, outside_bound2 takes no bound from a face on the grid's edge, cell_range
 // clamps): results stay exact, and the handle still reports the true bounding box.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap, int trim_k,
               GridDev* __restrict__ out, GridDev* __restrict__ host_mirror) {
-    __shared__ float red[4][8];
-    __shared__ float rob[4][6];
+    __shared__ float red[16][8];
+    __shared__ float rob[16][6];  // (1024 threads: one wave per group of 64 rows)
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         float tl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
         float th[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         if (trim_k > 0) {
-            for (int g0 = wave * 64; g0 < nblk; g0 += 256) {  // wave-uniform
+            for (int g0 = wave * 64; g0 < nblk; g0 += (int)blockDim.x) {  // wave-uniform
                 if (nblk - g0 < 16) continue;                  // a short tail group says little
                 const int b = g0 + lane;
                 const float* r = blk + (size_t)(b < nblk ? b : 0) * 8;
@@ -120,7 +128,7 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
     __syncthreads();
     if (threadIdx.x != 0) return;
     bad = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
         bad += __float_as_uint(red[w][0]);
         for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], red[w][1 + a]); hi[a] = fmaxf(hi[a], red[w][4 + a]); }
     }
@@ -135,7 +143,7 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
         d.hi[a] = hi[a];
         if (trim_k > 0 && d.n_valid != 0) {  // the grid lies over the trimmed one (never wider than the true box)
             float tl = __builtin_inff(), th = -__builtin_inff();
-            for (int w = 0; w < 4; ++w) { tl = fminf(tl, rob[w][a]); th = fmaxf(th, rob[w][3 + a]); }
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tl = fminf(tl, rob[w][a]); th = fmaxf(th, rob[w][3 + a]); }
             if (tl <= th) { lo[a] = fmaxf(lo[a], tl); hi[a] = fminf(hi[a], th); }
         }
         ext[a] = hi[a] - lo[a];
@@ -183,7 +191,7 @@ int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
     PCC_TRY(ix->d_grid.reserve(sizeof(GridDev)));
     ix->nc_cap = grid_nc_cap(ix->n_orig);
     // (trimming needs enough rows to tell an outlier from the scene: 128 pack workgroups = 64k points)
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(256), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1024), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
                        ppc, ix->nc_cap, n_blocks >= 128 ? trim : 0, ix->d_grid.as<GridDev>(), ix->h_grid);
     PCC_HIP(hipGetLastError());
     ix->info_pending = true;

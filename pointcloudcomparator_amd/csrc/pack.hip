@@ -31,7 +31,8 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 template <bool VEC16, bool STATS>
 __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
-       float* __restrict__ blk, unsigned int* __restrict__ zero_word, float4* __restrict__ seeds) {
+       float* __restrict__ blk, unsigned int* __restrict__ zero_word, float4* __restrict__ seeds,
+       unsigned long long* __restrict__ invalid_keys) {
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // saves a 5 us memset node
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -57,6 +58,9 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
         } else {
             o = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             ++bad;
+            // query clouds: the result key of a non-finite query is "nothing found" from the start (the searches never
+            // touch it, and the unpack kernel then needs no second look at the queries)
+            if (invalid_keys) invalid_keys[i] = ~0ull;
         }
         out[i] = o;
         if (STATS && seeds && (i & (PCC_SEED_STRIDE - 1)) == 0) seeds[i >> PCC_SEED_SHIFT] = o;  // upper bounds for far queries
@@ -94,7 +98,7 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
 }
 
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                float* blk_stats, int* n_blocks, unsigned int* zero_word, float4* seeds) {
+                float* blk_stats, int* n_blocks, unsigned int* zero_word, float4* seeds, unsigned long long* invalid_keys) {
     if (n_blocks) *n_blocks = 0;
     if (n == 0) return PCC_OK;
     bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
@@ -103,10 +107,10 @@ int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4*
     if (n_blocks) *n_blocks = g;
     const char* a = (const char*)aos;
     bool st = blk_stats != nullptr;
-    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
-    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
-    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
-    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds);
+    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
+    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
+    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
+    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -155,7 +155,8 @@ inline void ev_next(pcc_index* ix) {
 // [0] bits(invalid count), [1..3] min xyz, [4..6] max xyz of its valid points; *n_blocks rows.
 constexpr int PACK_MAX_BLOCKS = 1024;
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                float* blk_stats, int* n_blocks, unsigned int* zero_word = nullptr, float4* seeds = nullptr);
+                float* blk_stats, int* n_blocks, unsigned int* zero_word = nullptr, float4* seeds = nullptr,
+                unsigned long long* invalid_keys = nullptr);
 // exclusive scan of uint32 data[n] in place; data[n] receives the total when
 // write_total.  tmp is grown as needed.
 int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
