@@ -53,7 +53,7 @@ CONFIGS = {
 }
 C5_TOTAL_QUERIES = 32_000_000
 # sources whose kernels the committed PMC passes describe; a profile taken from other sources is flagged stale
-PROFILED_SOURCES = ["grid.hip", "grid_device.hpp", "cellsort.hip", "nn1_brute.hip", "pack.hip"]
+PROFILED_SOURCES = ["grid.hip", "grid_device.hpp", "cellsort.hip", "cellsort_mp.hip", "nn1_brute.hip", "pack.hip"]
 
 
 def parse_args():

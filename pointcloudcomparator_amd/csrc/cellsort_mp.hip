@@ -165,40 +165,13 @@ k_mp_level2(const E* __restrict__ in, const unsigned int* __restrict__ n_valid_p
     }
 }
 
-// C[0 .. np) counts -> exclusive prefix in place (one workgroup: np <= 256 * 128 pairs, a contiguous chunk per
-// thread); base[k] = the same prefix kept for level 3 (C itself turns into cursors), base[np] = total
-__global__ void __launch_bounds__(1024)
-k_mp_scan_pairs(unsigned int* __restrict__ C, unsigned int* __restrict__ base, unsigned int np) {
-    __shared__ unsigned int wsum[16];
-    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int per = (np + 1023) / 1024;
-    const unsigned int k0 = threadIdx.x * per, k1 = min(np, k0 + per);
-    unsigned int s = 0;
-    for (unsigned int k = k0; k < k1; ++k) s += C[k];
-    const unsigned int inc = wave_incl_scan_add(s);
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    unsigned int run = inc - s, total = 0;
-    for (unsigned int w = 0; w < 16; ++w) {
-        if (w < wave) run += wsum[w];
-        total += wsum[w];
-    }
-    for (unsigned int k = k0; k < k1; ++k) {
-        const unsigned int c = C[k];
-        C[k] = run;
-        base[k] = run;
-        run += c;
-    }
-    if (threadIdx.x == 0) base[np] = total;
-}
-
 __device__ __forceinline__ void mp_store_point(float4* out, unsigned int pos, const float4& v) { if (out) out[pos] = v; }
 __device__ __forceinline__ void mp_store_point(float4*, unsigned int, const uint2&) {}
 
 // ---- level 3 ---------------------------------------------------------------------------------------------------
 template <bool REFS, class E>
 __global__ void __launch_bounds__(MP_T)
-k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ base, const GridDev* __restrict__ gd,
+k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ ends /* cursors after level 2: bucket ends */, const GridDev* __restrict__ gd,
           unsigned int F2, float4* __restrict__ out_pts, unsigned int* __restrict__ out_order,
           unsigned int* __restrict__ cell_start) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // F2 counters + 4 scan words
@@ -210,7 +183,7 @@ k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ base, const
     const unsigned int b = blockIdx.x;
     const unsigned int cell0 = b * F2;
     if (cell0 > ncells) return;  // (entry [ncells] of cell_start belongs to the bucket that holds it)
-    const unsigned int beg = base[b], end = base[b + 1];
+    const unsigned int beg = b ? ends[b - 1] : 0u, end = ends[b];
     if (!REFS && beg == end) return;
     for (unsigned int f = threadIdx.x; f < F2; f += MP_T) cnt[f] = 0;
     __syncthreads();
@@ -273,10 +246,11 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
     PCC_TRY(ix->mp_b.reserve((size_t)n * sizeof(float4) + 256));
     const size_t h_elems = (size_t)p.B1 * p.G1 + 1;
     PCC_TRY(ix->scratch_b.reserve(((h_elems + 3) & ~(size_t)3) * sizeof(unsigned int)));
-    PCC_TRY(ix->mp_c.reserve(((size_t)np * 2 + 8) * sizeof(unsigned int)));
+    PCC_TRY(ix->mp_c.reserve(((size_t)np + 8) * sizeof(unsigned int)));
     unsigned int* H = ix->scratch_b.as<unsigned int>();
-    unsigned int* C = ix->mp_c.as<unsigned int>();   // counts -> cursors
-    unsigned int* base = C + np;                     // np + 1 bucket starts for level 3
+    // per (b1, b2) bucket: counts -> (scan) first position -> (placement advances it) one past its last point,
+    // which is also where the next bucket starts: level 3 reads its range from there
+    unsigned int* C = ix->mp_c.as<unsigned int>();
     hipLaunchKernelGGL(k_mp_hist1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
@@ -291,24 +265,24 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
         const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(float4) - 1) / (MP_STAGE_BYTES / sizeof(float4));
         hipLaunchKernelGGL((k_mp_scatter1<float4>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         hipLaunchKernelGGL((k_mp_level2<false, float4>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
-        hipLaunchKernelGGL(k_mp_scan_pairs, dim3(1), dim3(1024), 0, s, C, base, np);
+        PCC_TRY(launch_exclusive_scan(s, C, np, ix->scratch_a));
         hipLaunchKernelGGL((k_mp_level2<true, float4>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
         if (refs)
-            hipLaunchKernelGGL((k_mp_fine<true, float4>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+            hipLaunchKernelGGL((k_mp_fine<true, float4>), dim3(np), dim3(MP_T), lds3, s, t2, C, gd, p.F2, out_pts, out_order, cell_start);
         else
-            hipLaunchKernelGGL((k_mp_fine<false, float4>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+            hipLaunchKernelGGL((k_mp_fine<false, float4>), dim3(np), dim3(MP_T), lds3, s, t2, C, gd, p.F2, out_pts, out_order, cell_start);
     } else {        // only the order is wanted (query clouds): (cell, position) pairs travel, half the bytes
         uint2* t1 = ix->mp_a.as<uint2>();
         uint2* t2 = ix->mp_b.as<uint2>();
         const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(uint2) - 1) / (MP_STAGE_BYTES / sizeof(uint2));
         hipLaunchKernelGGL((k_mp_scatter1<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         hipLaunchKernelGGL((k_mp_level2<false, uint2>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
-        hipLaunchKernelGGL(k_mp_scan_pairs, dim3(1), dim3(1024), 0, s, C, base, np);
+        PCC_TRY(launch_exclusive_scan(s, C, np, ix->scratch_a));
         hipLaunchKernelGGL((k_mp_level2<true, uint2>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
         if (refs)
-            hipLaunchKernelGGL((k_mp_fine<true, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+            hipLaunchKernelGGL((k_mp_fine<true, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, C, gd, p.F2, out_pts, out_order, cell_start);
         else
-            hipLaunchKernelGGL((k_mp_fine<false, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, base, gd, p.F2, out_pts, out_order, cell_start);
+            hipLaunchKernelGGL((k_mp_fine<false, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, C, gd, p.F2, out_pts, out_order, cell_start);
     }
     PCC_HIP(hipGetLastError());
     return PCC_OK;

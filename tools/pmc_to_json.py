@@ -20,6 +20,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from bench import source_digest  # noqa: E402  (the digest bench.py compares against: kernel sources this profile describes)
 
 
 def short(name):
@@ -54,6 +56,7 @@ def main():
                      "hbm_bytes_per_launch_uncorrected": (f + w) * 1024.0}
     data[wl] = rows
     data[wl + "_detail"] = detail
+    data["source_digest"] = source_digest()
     out_file.write_text(json.dumps(data, indent=1))
     print(json.dumps(rows, indent=1))
 

@@ -1,11 +1,29 @@
+# Regenerates everything under profiles/ for one round on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
+# then copy gpurun_out/<tag>/summary/* into profiles/ (tools/collect_profiles.py does that).
+# One rocprofv3 pass per kind: --kernel-trace --stats for durations, --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
+# passes (MI355X_MICROARCH.md: they do not fit one pass), never combined with other trace domains.
 set -e
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01h   # remove a previous local gpurun_out/r01h first: gpurun merges, it does not replace
-mkdir -p $O
-timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1 && tail -2 $O/gpu_tests.log
-python bench.py --steps 20 --warmup 3 > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $O/trace_bench.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 8 --warmup 2 --no-cpu > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 8 --warmup 2 --no-cpu > $O/pmc_write_bench.json 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ops -- python3 tools/profile_ops.py > $O/ops.log 2> $O/ops.err
-cat $O/ops.log
+O=gpurun_out/$TAG
+S=$O/summary
+mkdir -p $S
+python3 bench.py > $S/${TAG}_bench_default.json 2> $O/bench_default.err
+echo "default bench done"
+for c in c2 c3 c4 c5; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -- python3 bench.py --config $c --no-cpu > $S/${TAG}_${c}_trace_bench.json 2> $O/trace_$c.err
+  cp $(find $O/trace_$c -name "*kernel_stats.csv" | head -1) $S/${TAG}_${c}_kernel_stats.csv
+  echo "trace $c done"
+done
+for c in c2 c3 c4 c5; do
+  for k in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $k --kernel-trace --output-format csv -d $O/pmc_${c}_$k -- python3 bench.py --config $c --steps 6 --warmup 2 --no-cpu --no-exhaustive > $O/pmc_${c}_$k.json 2> $O/pmc_${c}_$k.err
+  done
+  python3 tools/pmc_to_json.py $TAG $c $O/pmc_${c}_FETCH_SIZE $O/pmc_${c}_WRITE_SIZE > $O/pmc_$c.log
+  echo "pmc $c done"
+done
+cp profiles/${TAG}_pmc_traffic.json $S/
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ops -- python3 tools/profile_ops.py > $S/${TAG}_ops_wallclock.txt 2> $O/ops.err
+cp $(find $O/ops -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_kernel_stats.csv
+cat $S/${TAG}_ops_wallclock.txt
