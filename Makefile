@@ -16,7 +16,7 @@ all: lib oracle hosttest cli
 lib: $(LIBDIR)/libpcc_nn.so
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu build/ubench_gather
-hosttest: build/test_host_mirror build/test_lane_ops
+hosttest: build/test_host_mirror build/test_lane_ops build/test_report
 cli: build/comparator build/ply_dump
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_order.hpp include/pcc_nn.h
@@ -48,6 +48,10 @@ build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.h
 	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 build/comparator: pointcloudcomparator_amd/host/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp pointcloudcomparator_amd/host/report.hpp include/pcc/multi_device.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+build/test_report: tests/cpp/test_report.cpp pointcloudcomparator_amd/host/report.hpp include/pcc/comparator_nn.hpp include/pcc/search.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
