@@ -9,8 +9,6 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 S=$O/summary
 mkdir -p $S
-python3 bench.py > $S/${TAG}_bench_default.json 2> $O/bench_default.err
-echo "default bench done"
 for c in c2 c3 c4 c5; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -- python3 bench.py --config $c --no-cpu > $S/${TAG}_${c}_trace_bench.json 2> $O/trace_$c.err
   cp $(find $O/trace_$c -name "*kernel_stats.csv" | head -1) $S/${TAG}_${c}_kernel_stats.csv
@@ -24,6 +22,9 @@ for c in c2 c3 c4 c5; do
   echo "pmc $c done"
 done
 cp profiles/${TAG}_pmc_traffic.json $S/
+# the unprofiled default run last: its roofline.traffic is read from the PMC file written just above
+python3 bench.py > $S/${TAG}_bench_default.json 2> $O/bench_default.err
+echo "default bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ops -- python3 tools/profile_ops.py > $S/${TAG}_ops_wallclock.txt 2> $O/ops.err
 cp $(find $O/ops -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_kernel_stats.csv
 cat $S/${TAG}_ops_wallclock.txt
