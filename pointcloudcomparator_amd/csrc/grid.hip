@@ -281,6 +281,57 @@ __device__ __forceinline__ unsigned long long scan_box(const float4* __restrict_
     return best;
 }
 
+// Phase 2: the cells the ball of the best distance touches OUTSIDE the cube [cx0..cx1] x [cy0..cy1] x [cz0..cz1] that
+// has been dealt with (what the clipped walk of phase 1 skipped inside the cube was farther than the best of that
+// moment, hence than today's).  Rows whose y/z gap exceeds the best distance are skipped, the others clipped to
+// the ball's chord; a row that runs through the cube contributes only what sticks out on either side.  Bounds of four
+// rows are fetched together, as scan_box does.
+template <int U>
+__device__ __forceinline__ unsigned long long scan_ball_outside(const float4* __restrict__ cell_refs,
+                                                                const unsigned int* __restrict__ cell_start,
+                                                                const GridParams& g, float slack, int x0, int x1, int y0,
+                                                                int y1, int z0, int z1, int cx0, int cx1, int cy0, int cy1,
+                                                                int cz0, int cz1, float qx, float qy, float qz,
+                                                                unsigned long long best) {
+    for (int z = z0; z <= z1; ++z) {
+        const float gz = fmaxf(fmaxf((z == 0 ? -__builtin_inff() : g.org[2] + z * g.h) - qz,
+                                     qz - (z == g.dim[2] - 1 ? __builtin_inff() : g.org[2] + (z + 1) * g.h)) - slack, 0.f);
+        for (int yb = y0; yb <= y1; yb += 4) {
+            unsigned int as[4], ae[4], bs[4], be[4];  // per row: the part left of the cube (or the whole chord), the part right of it
+            const float bd = __uint_as_float((unsigned int)(best >> 32));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = yb + i;
+                as[i] = ae[i] = bs[i] = be[i] = 0u;
+                if (y > y1) continue;
+                const float gy = fmaxf(fmaxf((y == 0 ? -__builtin_inff() : g.org[1] + y * g.h) - qy,
+                                             qy - (y == g.dim[1] - 1 ? __builtin_inff() : g.org[1] + (y + 1) * g.h)) - slack, 0.f);
+                const float rem = bd - (gy * gy + gz * gz) * 0.9999f;
+                if (!(rem >= 0.f)) continue;
+                int xa, xb;
+                cell_range(qx, sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
+                xa = max(xa, x0);
+                xb = min(xb, x1);
+                if (xa > xb) continue;
+                const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                if (y >= cy0 && y <= cy1 && z >= cz0 && z <= cz1) {  // through the cube: only what sticks out
+                    if (xa < cx0) { as[i] = cell_start[row + xa]; ae[i] = cell_start[row + cx0]; }
+                    if (xb > cx1) { bs[i] = cell_start[row + cx1 + 1]; be[i] = cell_start[row + xb + 1]; }
+                } else {
+                    as[i] = cell_start[row + xa];
+                    ae[i] = cell_start[row + xb + 1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                best = scan_span<U>(cell_refs, as[i], ae[i], qx, qy, qz, best);
+                best = scan_span<U>(cell_refs, bs[i], be[i], qx, qy, qz, best);
+            }
+        }
+    }
+    return best;
+}
+
 template <int U, bool CLIP>
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
@@ -302,21 +353,27 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
             bid = base + (in & 7u) * xcd_run + (in >> 3);
         }
     }
+    // open queries of the workgroup (phase 1 did not decide them), packed: finished by its first lanes (below)
+    __shared__ float4 open_q[256];               // x, y, z, bits(position in q)
+    __shared__ unsigned long long open_best[256];
+    __shared__ unsigned int open_count;
+    if (threadIdx.x == 0) open_count = 0;
+    __syncthreads();
     const unsigned int t = bid * blockDim.x + threadIdx.x;
     const unsigned int ns = n_sorted_ptr ? *n_sorted_ptr : n;
-    if (t >= ns) return;
-    const unsigned int qi = order ? order[t] : t;
-    const float4 qv = q[qi];
-    if (__float_as_int(qv.w) < 0) return;
-    const float qx = qv.x, qy = qv.y, qz = qv.z;
-    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    unsigned int qi = 0;
+    float4 qv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (t < ns) { qi = order ? order[t] : t; qv = q[qi]; }
+    const bool active = __float_as_int(qv.w) >= 0;
+    float qx = qv.x, qy = qv.y, qz = qv.z;
+    int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+    int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+    int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
     // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (18 independent loads, one
     // latency), then the rows are streamed.
-    {
+    if (active) {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
         unsigned int rs[9], re[9];
         uint4 r4[9];
@@ -376,9 +433,31 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
         if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
     }
-    if (!resolved) {
+    // The lanes phase 1 leaves open (about one in ten in sparse regions, spread over every wave) used to be finished
+    // in place: every wave then walked the ball cover for a handful of lanes -- 37 of the kernel's 120 us on the
+    // corridor scene.  They are packed through LDS instead and the workgroup's FIRST lanes finish them: one wave with
+    // (nearly) all lanes busy instead of four with a few each.  Still the same launch, so the occupancy that hides the
+    // walk's dependent loads is kept (a separate second kernel over a compacted list lost for lack of it).  Worth
+    // 3-4 % at 10M x 10M (1070 -> 1030 us), nothing at 1M x 1M: the walk's cost is the LINES its lanes touch, which
+    // packing does not change.  Letting the last wave to arrive finish them instead of a barrier lost (143 us at 1M).
+    if (active && resolved) out[qi] = best;
+    if (active && !resolved) {
+        const unsigned int slot = atomicAdd(&open_count, 1u);
+        open_q[slot] = make_float4(qx, qy, qz, __uint_as_float(qi));
+        open_best[slot] = best;
+    }
+    __syncthreads();
+    const unsigned int n_open = open_count;
+    for (unsigned int j = threadIdx.x; j < n_open; j += blockDim.x) {
+        const float4 oq = open_q[j];
+        qx = oq.x; qy = oq.y; qz = oq.z;
+        qi = __float_as_uint(oq.w);
+        best = open_best[j];
+        cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
         // ---- phase 1b: nothing within the 3x3x3 cube -> double the cube until a point shows up
-        bool give_up = false;
+        bool give_up = false, done = false;
         int k = 1;
         while (best == ~0ull) {
             if (k >= GRID_KMAX) { give_up = true; break; }
@@ -401,17 +480,19 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
             if (!(rb < __builtin_inff()) || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
                 give_up = true;  // the ball is too big for a cell walk: exhaustive fallback
             } else {
-                best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
-                resolved = true;
+                // the cube of half-width k around the query's cell is done (phase 1, or the last doubling)
+                best = scan_ball_outside<U>(cell_refs, cell_start, g, slack, x0, x1, y0, y1, z0, z1, max(cx - k, 0),
+                                            min(cx + k, g.dim[0] - 1), max(cy - k, 0), min(cy + k, g.dim[1] - 1),
+                                            max(cz - k, 0), min(cz + k, g.dim[2] - 1), qx, qy, qz, best);
+                done = true;
             }
         }
-    }
-    if (resolved) {
-        out[qi] = best;
-    } else {
-        out[qi] = ~0ull;  // the exhaustive pass merges into it with atomicMin
-        unsigned int slot = atomicAdd(fb_count, 1u);
-        fb_list[slot] = qi;
+        if (done) {
+            out[qi] = best;
+        } else {
+            out[qi] = ~0ull;  // the exhaustive pass merges into it with atomicMin
+            fb_list[atomicAdd(fb_count, 1u)] = qi;
+        }
     }
 }
 
@@ -541,7 +622,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
         ix->order_nsorted = n_sorted;
     }
     ev_mark(ix, EV_MAIN0);
-    const int BS = 256;
+    const int BS = 256;  // 128 and 512 measured 9-12 % slower (fewer lanes to pack / longer wait at the barrier)
     const unsigned int xcd_run = 16;  // consecutive workgroups per XCD (see k_grid_nn1)
     // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
     static const int clip = getenv("PCC_NN1_CLIP") ? atoi(getenv("PCC_NN1_CLIP")) : 1;  // 0: the plain 27-cell cube (for measurements)
