@@ -332,13 +332,62 @@ __device__ __forceinline__ unsigned long long scan_ball_outside(const float4* __
     return best;
 }
 
+// What phase 1 of k_grid_nn1 leaves open, for one query: `best` is its best key over the 3x3x3 cube (~0: empty).
+template <int U>
+__device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+                                           const GridParams& g, float slack, float qx, float qy, float qz, unsigned int qi,
+                                           unsigned long long best, unsigned long long* __restrict__ out,
+                                           unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count, bool ball) {
+    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    // ---- phase 1b: nothing within the 3x3x3 cube -> double the cube until a point shows up
+    bool give_up = false, done = false;
+    int k = 1;
+    while (best == ~0ull) {
+        if (k >= GRID_KMAX) { give_up = true; break; }
+        k = min(2 * k, GRID_KMAX);
+        const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+        const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+        const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+        best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
+    }
+    // ---- phase 2: cover the ball of radius sqrt(best) -- every cell a closer (or equal,
+    // lower-index) point could live in.  Usually one extra slab of cells on one or two sides,
+    // far fewer rows than the next bigger cube.  Exact by construction: no bound test after it.
+    if (!give_up) {
+        const float rb = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
+        int x0, x1, y0, y1, z0, z1;
+        cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
+        cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
+        cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
+        const int span = 2 * GRID_KMAX + 1;
+        if (!(rb < __builtin_inff()) || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
+            give_up = true;  // the ball is too big for a cell walk: exhaustive fallback
+        } else {
+            // the cube of half-width k around the query's cell is done (phase 1, or the last doubling)
+            if (ball) best = scan_ball_outside<U>(cell_refs, cell_start, g, slack, x0, x1, y0, y1, z0, z1, max(cx - k, 0),
+                                        min(cx + k, g.dim[0] - 1), max(cy - k, 0), min(cy + k, g.dim[1] - 1),
+                                        max(cz - k, 0), min(cz + k, g.dim[2] - 1), qx, qy, qz, best);
+            else best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
+            done = true;
+        }
+    }
+    if (done) {
+        out[qi] = best;
+    } else {
+        out[qi] = ~0ull;  // the exhaustive pass merges into it with atomicMin
+        fb_list[atomicAdd(fb_count, 1u)] = qi;
+    }
+}
+
 template <int U, bool CLIP>
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
            const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
            const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
            unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
-           unsigned int* __restrict__ fb_count, unsigned int xcd_run) {
+           unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Runs of `xcd_run` consecutive
@@ -453,46 +502,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         qx = oq.x; qy = oq.y; qz = oq.z;
         qi = __float_as_uint(oq.w);
         best = open_best[j];
-        cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-        cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-        cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
-        // ---- phase 1b: nothing within the 3x3x3 cube -> double the cube until a point shows up
-        bool give_up = false, done = false;
-        int k = 1;
-        while (best == ~0ull) {
-            if (k >= GRID_KMAX) { give_up = true; break; }
-            k = min(2 * k, GRID_KMAX);
-            const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
-            const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
-            const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
-            best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
-        }
-        // ---- phase 2: cover the ball of radius sqrt(best) -- every cell a closer (or equal,
-        // lower-index) point could live in.  Usually one extra slab of cells on one or two sides,
-        // far fewer rows than the next bigger cube.  Exact by construction: no bound test after it.
-        if (!give_up) {
-            const float rb = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
-            int x0, x1, y0, y1, z0, z1;
-            cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
-            cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
-            cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
-            const int span = 2 * GRID_KMAX + 1;
-            if (!(rb < __builtin_inff()) || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
-                give_up = true;  // the ball is too big for a cell walk: exhaustive fallback
-            } else {
-                // the cube of half-width k around the query's cell is done (phase 1, or the last doubling)
-                best = scan_ball_outside<U>(cell_refs, cell_start, g, slack, x0, x1, y0, y1, z0, z1, max(cx - k, 0),
-                                            min(cx + k, g.dim[0] - 1), max(cy - k, 0), min(cy + k, g.dim[1] - 1),
-                                            max(cz - k, 0), min(cz + k, g.dim[2] - 1), qx, qy, qz, best);
-                done = true;
-            }
-        }
-        if (done) {
-            out[qi] = best;
-        } else {
-            out[qi] = ~0ull;  // the exhaustive pass merges into it with atomicMin
-            fb_list[atomicAdd(fb_count, 1u)] = qi;
-        }
+        nn1_finish<U>(cell_refs, cell_start, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk);
     }
 }
 
@@ -626,14 +636,14 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     const unsigned int xcd_run = 16;  // consecutive workgroups per XCD (see k_grid_nn1)
     // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
     static const int clip = getenv("PCC_NN1_CLIP") ? atoi(getenv("PCC_NN1_CLIP")) : 1;  // 0: the plain 27-cell cube (for measurements)
-    if (clip)
-        hipLaunchKernelGGL((k_grid_nn1<4, true>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
-                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,
-                           fb_list, fb_count, xcd_run);
-    else
-        hipLaunchKernelGGL((k_grid_nn1<4, false>), dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
-                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out,
-                           fb_list, fb_count, xcd_run);
+    // phase 2 as the ball outside the finished cube, except in ICP passes: while the source is still misaligned the
+    // balls are several cells wide and the per-row chord arithmetic costs more than the rows it drops
+    // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us)
+    const bool ball_walk = !ix->keep_order;
+    auto kern = clip ? k_grid_nn1<4, true> : k_grid_nn1<4, false>;
+    hipLaunchKernelGGL(kern, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
+                       fb_count, xcd_run, ball_walk);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     // queries the cell walk could not resolve.  When an earlier search on this index had such
