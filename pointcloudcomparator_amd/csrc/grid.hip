@@ -381,7 +381,7 @@ __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs,
     }
 }
 
-template <int U, bool CLIP>
+template <int U>
 __global__ void __launch_bounds__(256)
 k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
            const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
@@ -420,62 +420,58 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
-    // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (18 independent loads, one
-    // latency), then the rows are streamed.
+    // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (9 independent 16-byte loads, one latency), then the
+    // rows are streamed.  The kernel is VALU-issue bound (PMC: 3000 VALU instructions per wave, the SIMDs 70 % busy),
+    // so everything per row is kept to a handful of instructions.
     if (active) {
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-        unsigned int rs[9], re[9];
-        uint4 r4[9];
+        const int x0 = max(cx - 1, 0);
+        const bool shifted = cx == 0;                // the 16-byte load then starts at the own cell, not at its left neighbour
+        const bool has_right = cx + 1 < g.dim[0];
+        // per row the four bounds L <= A <= B <= R: [L,A) left cell, [A,B) own cell, [B,R) right cell
+        unsigned int rL[9], rA[9], rB[9], rR[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
             const bool ok = z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
             const unsigned int row = ((unsigned int)(ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
-            // both bounds with ONE gather: x1 + 1 - x0 <= 3, so they sit in one (unaligned) 16-byte load
-            // (cell_start is padded by 4 entries); halves the bound-fetch instructions of sparse queries
+            // all bounds of the row with ONE gather: <= 3 cells, so they sit in one (unaligned) 16-byte load
+            // (cell_start is padded by 4 entries)
             uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
             if (ok) b4 = *reinterpret_cast<const uint4*>(cell_start + row + x0);
-            const int w = x1 + 1 - x0;
-            rs[i] = b4.x;
-            re[i] = w == 3 ? b4.w : (w == 2 ? b4.z : b4.y);
-            r4[i] = b4;
+            rL[i] = b4.x;
+            rA[i] = shifted ? b4.x : b4.y;
+            rB[i] = shifted ? b4.y : b4.z;
+            const unsigned int r3 = shifted ? b4.z : b4.w;
+            rR[i] = has_right ? r3 : rB[i];
         }
-        if (CLIP) {
-            // own row first; every other row only where the ball of the best distance so far reaches it: rows whose
-            // y/z gap already exceeds it are skipped, the others are clipped to the cells the ball's chord touches.
-            // All lanes still walk the rows in the same order (lines stay shared); a lane inside a dense region looks
-            // at ~60 candidates instead of 230, and so does a lane NEXT to one once its first full row has given it a
-            // bound.  C2 140 -> 121 us, C3 1290 -> 1070 us; uniform clouds unchanged.
-            best = scan_span<U>(cell_refs, rs[4], re[4], qx, qy, qz, best);
+        // Own row first; every other row only where the ball of the best distance so far reaches it: rows whose
+        // y/z gap already exceeds it are skipped, and the left / right cell of a row is dropped when the gap to the own
+        // cell's face plus the row's gap exceeds it (squared gaps against the squared distance: no square root, no cell
+        // arithmetic -- ~8 instructions per row).  Gaps are shrunk by the slack and by 1e-4 relative, as the cube bound is;
+        // with nothing found yet the best distance is NaN and every comparison below keeps the row whole.
+        // All lanes still walk the rows in the same order (lines stay shared); a lane inside a dense region looks
+        // at ~60 candidates instead of 230, and so does a lane NEXT to one once its first full row has given it a
+        // bound.  C2 140 -> 121 us, C3 1290 -> 1070 us; uniform clouds unchanged.
+        const float fx = g.org[0] + cx * g.h, fy = g.org[1] + cy * g.h, fz = g.org[2] + cz * g.h;
+        const float gxl = fmaxf((qx - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - qx) - slack, 0.f);
+        const float gyl = fmaxf((qy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - qy) - slack, 0.f);
+        const float gzl = fmaxf((qz - fz) - slack, 0.f), gzr = fmaxf(((fz + g.h) - qz) - slack, 0.f);
+        const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
+        const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
+        const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
+        best = scan_span<U>(cell_refs, rL[4], rR[4], qx, qy, qz, best);
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                constexpr int order8[8] = {3, 5, 1, 7, 0, 2, 6, 8};  // face neighbours of the own row first, then the diagonal ones
-                const int i = order8[o];
-                const int dz = i / 3 - 1, dy = i % 3 - 1;
-                if (rs[i] == re[i]) continue;
-                unsigned int s0 = rs[i], e0 = re[i];
-                if (best != ~0ull) {
-                    // distance from q to the row's slab along y and z (0 for its own coordinate), shrunk by the slack
-                    const float gy = dy == 0 ? 0.f : fmaxf((dy < 0 ? qy - (g.org[1] + cy * g.h) : (g.org[1] + (cy + 1) * g.h) - qy) - slack, 0.f);
-                    const float gz = dz == 0 ? 0.f : fmaxf((dz < 0 ? qz - (g.org[2] + cz * g.h) : (g.org[2] + (cz + 1) * g.h) - qz) - slack, 0.f);
-                    const float bd = __uint_as_float((unsigned int)(best >> 32));
-                    const float rem = bd - (gy * gy + gz * gz) * 0.9999f;
-                    if (!(rem >= 0.f)) continue;  // every point of the row is strictly farther than the best
-                    const float rb = sqrtf(rem) * 1.00001f + slack;
-                    int xa, xb;
-                    cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], xa, xb);
-                    xa = max(xa, x0);
-                    xb = min(xb, x1);
-                    const int ia = xa - x0, ib = xb + 1 - x0;  // entries of the row's 16-byte load
-                    s0 = ia == 0 ? r4[i].x : (ia == 1 ? r4[i].y : r4[i].z);
-                    e0 = ib == 1 ? r4[i].y : (ib == 2 ? r4[i].z : r4[i].w);
-                }
-                best = scan_span<U>(cell_refs, s0, e0, qx, qy, qz, best);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) best = scan_span<U>(cell_refs, rs[i], re[i], qx, qy, qz, best);
+        for (int o = 0; o < 8; ++o) {
+            constexpr int order8[8] = {3, 5, 1, 7, 0, 2, 6, 8};  // face neighbours of the own row first, then the diagonal ones
+            const int i = order8[o];
+            if (rL[i] == rR[i]) continue;
+            const float bd = __uint_as_float((unsigned int)(best >> 32));
+            const float rem = bd - (gy2[i % 3] + gz2[i / 3]);
+            if (rem < 0.f) continue;  // every point of the row is strictly farther than the best
+            const unsigned int s0 = gxl2 > rem ? rA[i] : rL[i], e0 = gxr2 > rem ? rB[i] : rR[i];
+            best = scan_span<U>(cell_refs, s0, e0, qx, qy, qz, best);
         }
+        const int x1 = min(cx + 1, g.dim[0] - 1);
         const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
         const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
         const float bd = __uint_as_float((unsigned int)(best >> 32));
@@ -635,13 +631,11 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     const int BS = 256;  // 128 and 512 measured 9-12 % slower (fewer lanes to pack / longer wait at the barrier)
     const unsigned int xcd_run = 16;  // consecutive workgroups per XCD (see k_grid_nn1)
     // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
-    static const int clip = getenv("PCC_NN1_CLIP") ? atoi(getenv("PCC_NN1_CLIP")) : 1;  // 0: the plain 27-cell cube (for measurements)
     // phase 2 as the ball outside the finished cube, except in ICP passes: while the source is still misaligned the
     // balls are several cells wide and the per-row chord arithmetic costs more than the rows it drops
     // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us)
     const bool ball_walk = !ix->keep_order;
-    auto kern = clip ? k_grid_nn1<4, true> : k_grid_nn1<4, false>;
-    hipLaunchKernelGGL(kern, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
+    hipLaunchKernelGGL(k_grid_nn1<4>, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
                        ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
                        fb_count, xcd_run, ball_walk);
     PCC_HIP(hipGetLastError());
