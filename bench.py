@@ -253,8 +253,9 @@ def main():
             r["roofline"] = {"kernel": "k_grid_nn1", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale, "kernel_ms": tm[0],
                              "algorithmic_bytes": alg,
-                             "note": "pruned exact search, bound by L1 line lookups and L2->L1 fills of per-lane 16-byte "
-                                     "gathers (DESIGN.md 4.2); compulsory HBM bytes are a few % of the roof by construction"}
+                             "note": "pruned exact search: VALU-issue bound at 20 of 64 lanes active (VALU 68 % busy at C3, "
+                                     "profiles/r02_nn1_counters.json, DESIGN.md 4.2); compulsory HBM bytes are a few % of the "
+                                     "roof by construction"}
         else:
             ach = float(M) * N * OPS_PER_PAIR / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else 0.0
             traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
