@@ -1034,15 +1034,17 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     int it = 0;
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
+    static const int warm_env = getenv("PCC_ICP_WARM") ? atoi(getenv("PCC_ICP_WARM")) : 1;  // 0: every pass from scratch (measurements)
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
         pcc_index* ix;
-        explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; }
-        ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; }
+        explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }
+        ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; ix->warm_start = false; }
     } keep_order_guard(ix);
     while (it < max_iter) {
         ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)
         ev_mark(ix, EV_CALL0);
         PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
+        ix->warm_start = warm_env != 0;  // from now on out_packed holds the last pass's keys of these same points
         double sums[17];
         PCC_TRY(icp_reduce(ix, n, sums));
         float Ti[16];

@@ -376,7 +376,7 @@ __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs,
     if (done) {
         out[qi] = best;
     } else {
-        out[qi] = ~0ull;  // the exhaustive pass merges into it with atomicMin
+        out[qi] = best;  // a real point if there is one (~0 otherwise): the far walk starts from it, the passes merge with atomicMin
         fb_list[atomicAdd(fb_count, 1u)] = qi;
     }
 }
@@ -387,7 +387,8 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
            const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
            const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
            unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
-           unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk) {
+           unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk,
+           const float4* __restrict__ warm_refs) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Runs of `xcd_run` consecutive
@@ -420,6 +421,14 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
+    // Warm start (ICP passes after the first): out[] still holds every query's neighbour of the previous pass.  The
+    // query has moved a little since, that reference is most likely still its neighbour or next to it: its distance
+    // NOW is an upper bound held by a real point, so the clipping below bites from the first row on, and a query
+    // beyond the cube walk takes the bound with it to the far walk instead of needing the seed scan.
+    if (warm_refs && active) {
+        const unsigned long long pk = out[qi];
+        if (pk != ~0ull) best = fold(best, qx, qy, qz, warm_refs[(unsigned int)pk]);
+    }
     // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (9 independent 16-byte loads, one latency), then the
     // rows are streamed.  The kernel is VALU-issue bound (PMC: 3000 VALU instructions per wave, the SIMDs 70 % busy),
     // so everything per row is kept to a handful of instructions.
@@ -459,7 +468,11 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
         const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
         const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
-        best = scan_span<U>(cell_refs, rL[4], rR[4], qx, qy, qz, best);
+        {
+            // (without a warm start the best distance is still NaN here and the own row is scanned whole)
+            const float bd = __uint_as_float((unsigned int)(best >> 32));
+            best = scan_span<U>(cell_refs, gxl2 > bd ? rA[4] : rL[4], gxr2 > bd ? rB[4] : rR[4], qx, qy, qz, best);
+        }
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             constexpr int order8[8] = {3, 5, 1, 7, 0, 2, 6, 8};  // face neighbours of the own row first, then the diagonal ones
@@ -635,9 +648,10 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     // balls are several cells wide and the per-row chord arithmetic costs more than the rows it drops
     // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us)
     const bool ball_walk = !ix->keep_order;
+    const bool warm = ix->warm_start && ix->keep_order;  // out[] holds the previous pass's keys of the SAME queries (pcc_icp_align)
     hipLaunchKernelGGL(k_grid_nn1<4>, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
                        ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
-                       fb_count, xcd_run, ball_walk);
+                       fb_count, xcd_run, ball_walk, warm ? ix->refs.as<float4>() : nullptr);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     // queries the cell walk could not resolve.  When an earlier search on this index had such
@@ -654,7 +668,8 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
         unsigned int* fb2_count = ix->small.as<unsigned int>() + 33;
         PCC_HIP(hipMemsetAsync(fb2_count, 0, 4, s));
         const size_t n_seeds = (ix->n_orig + SEED_STRIDE - 1) / SEED_STRIDE;
-        PCC_TRY(launch_nn1_brute(s, ix->seeds.as<float4>(), n_seeds, q, n, out, fb_list, fb_count, n, true));
+        // (a warm-started query brings its bound along: no seed scan)
+        if (!warm) PCC_TRY(launch_nn1_brute(s, ix->seeds.as<float4>(), n_seeds, q, n, out, fb_list, fb_count, n, true));
         unsigned int gfar = (n + 3) / 4;  // one wave per listed query, 4 waves per workgroup
         if (gfar > 2048) gfar = 2048;
         hipLaunchKernelGGL((k_grid_far<4>), dim3(gfar), dim3(256), 0, s, ix->cell_refs.as<float4>(),

@@ -108,6 +108,7 @@ struct pcc_index {
     // ICP moves the same source cloud rigidly from pass to pass: the lane order of its first pass keeps
     // neighbouring lanes on neighbouring points, so later passes skip the query sort
     bool keep_order = false, order_valid = false;
+    bool warm_start = false;  // ICP passes after the first: out_packed holds the previous pass's keys (grid_nn1 starts from them)
     size_t order_nq = 0;
     unsigned int* order_ptr = nullptr;
     unsigned int* order_nsorted = nullptr;
