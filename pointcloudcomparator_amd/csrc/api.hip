@@ -3,6 +3,7 @@
 // no CPU compute fallback: without a HIP device every entry point fails with
 // PCC_ERR_DEVICE.
 #include "pcc_internal.hpp"
+#include "rigid_solve.hpp"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -262,7 +263,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -872,87 +873,6 @@ static int icp_reduce(pcc_index* ix, size_t n, double sums[17]) {
     return PCC_OK;
 }
 
-// largest eigenvector of a symmetric 4x4 (cyclic Jacobi), for Horn's closed-form absolute orientation
-static void sym4_max_eigvec(double A[4][4], double v[4]) {
-    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < 4; ++p)
-            for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 4; ++p)
-            for (int q = p + 1; q < 4; ++q) {
-                if (std::fabs(A[p][q]) < 1e-300) continue;
-                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < 4; ++k) {
-                    double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 4; ++k) {
-                    double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 4; ++k) {
-                    double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-    int best = 0;
-    for (int i = 1; i < 4; ++i)
-        if (A[i][i] > A[best][best]) best = i;
-    for (int k = 0; k < 4; ++k) v[k] = V[k][best];
-}
-
-// rigid transform (rotation + translation, no scale) minimising sum |R p + t - q|^2 from the sums:
-// the same optimum TransformationEstimationSVD / Eigen::umeyama(src, tgt, false) returns, obtained
-// with Horn's unit-quaternion method in double.  Returns 0, or -1 with < 3 correspondences.
-static int rigid_from_sums(const double sums[17], float T[16]) {
-    const double n = sums[16];
-    if (n < 3) return -1;  // min_number_correspondences_
-    double pm[3], qm[3], S[3][3];
-    for (int a = 0; a < 3; ++a) { pm[a] = sums[a] / n; qm[a] = sums[3 + a] / n; }
-    for (int a = 0; a < 3; ++a)      // S[a][b] = sum (p_a - pm_a)(q_b - qm_b)
-        for (int b = 0; b < 3; ++b) S[a][b] = sums[6 + b * 3 + a] - n * pm[a] * qm[b];
-    double N[4][4] = {
-        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
-        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
-        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
-        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
-    double qv[4];
-    sym4_max_eigvec(N, qv);
-    double nrm = std::sqrt(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3]);
-    if (!(nrm > 0)) return -1;
-    const double w = qv[0] / nrm, x = qv[1] / nrm, y = qv[2] / nrm, z = qv[3] / nrm;
-    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
-                            {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
-                            {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
-    for (int r = 0; r < 3; ++r) {
-        double t = qm[r];
-        for (int c = 0; c < 3; ++c) { T[r * 4 + c] = (float)R[r][c]; t -= R[r][c] * pm[c]; }
-        T[r * 4 + 3] = (float)t;
-    }
-    T[12] = T[13] = T[14] = 0.f;
-    T[15] = 1.f;
-    return 0;
-}
-
-static void mat4_mul_f(const float A[16], const float B[16], float C[16]) {
-    float R[16];
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            float acc = 0;
-            for (int k = 0; k < 4; ++k) acc += A[r * 4 + k] * B[k * 4 + c];
-            R[r * 4 + c] = acc;
-        }
-    memcpy(C, R, sizeof(R));
-}
-
 int pcc_rigid_from_sums(const double sums[17], float T[16]) {
     if (!sums || !T) { set_error("null argument"); return PCC_ERR_INVALID; }
     if (rigid_from_sums(sums, T) != 0) { set_error("fewer than 3 correspondences"); return PCC_ERR_INVALID; }
@@ -1035,11 +955,44 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
     static const int warm_env = getenv("PCC_ICP_WARM") ? atoi(getenv("PCC_ICP_WARM")) : 1;  // 0: every pass from scratch (measurements)
+    static const int loop_env = getenv("PCC_ICP_DEVICE_LOOP") ? atoi(getenv("PCC_ICP_DEVICE_LOOP")) : 1;  // 0: host loop also for fixed counts
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
         pcc_index* ix;
         explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }
         ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; ix->warm_start = false; }
     } keep_order_guard(ix);
+    if (fixed && ix->engine == PCC_ENGINE_GRID && loop_env) {
+        // A fixed number of iterations needs no decision on the host: every pass is NN -> sums -> solve (one wave,
+        // k_icp_solve) -> transform with the matrix the solver left in device memory, enqueued back to back.  The host
+        // loop below costs a stream synchronisation, a read-back and a launch gap per pass (~55 us of 0.44 ms).
+        PCC_TRY(ix->icp_state.reserve(sizeof(IcpState)));
+        PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
+        IcpState h0{};
+        memcpy(h0.Ti, I, sizeof(I));
+        memcpy(h0.T, I, sizeof(I));
+        PCC_HIP(hipMemcpyAsync(ix->icp_state.p, &h0, sizeof(h0), hipMemcpyHostToDevice, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));  // (h0 lives on this stack frame)
+        IcpState* st = ix->icp_state.as<IcpState>();
+        for (int pass = 0; pass < max_iter; ++pass) {
+            ev_next(ix);
+            ev_mark(ix, EV_CALL0);
+            PCC_TRY(nn1_packed(ix, n));
+            ix->warm_start = warm_env != 0;
+            int nb = 0;
+            PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
+                                    ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
+                                    ix->small.as<unsigned int>() + 32, static_cast<unsigned int*>(ix->pinned) + 40));
+            PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st));
+            PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
+            ev_mark(ix, EV_CALL1);
+        }
+        IcpState h1;
+        PCC_HIP(hipMemcpyAsync(&h1, ix->icp_state.p, sizeof(h1), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        memcpy(T, h1.T, sizeof(h1.T));
+        it = h1.failed ? h1.ok : max_iter;
+        conv = !h1.failed;  // DefaultConvergenceCriteria: the iteration cap counts as converged
+    } else
     while (it < max_iter) {
         ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)
         ev_mark(ix, EV_CALL0);

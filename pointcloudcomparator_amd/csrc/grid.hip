@@ -662,7 +662,8 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     const unsigned int seen = static_cast<volatile unsigned int*>(ix->pinned)[40];
     if (seen > ix->last_fallback_seen) ix->last_fallback_seen = seen;
     static const int far_mode = getenv("PCC_GRID_FAR") ? atoi(getenv("PCC_GRID_FAR")) : -1;  // -1 auto, 0 off, 1 on
-    const bool far = far_mode == 1 || (far_mode == -1 && ix->last_fallback_seen >= 64);
+    // (ICP passes always take it: their loop may be enqueued as a whole before the first count comes back)
+    const bool far = far_mode == 1 || (far_mode == -1 && (ix->last_fallback_seen >= 64 || ix->keep_order));
     if (far) {
         unsigned int* fb2_list = fb_list + n + 64;
         unsigned int* fb2_count = ix->small.as<unsigned int>() + 33;

@@ -8,6 +8,7 @@
 // SURVEY hard part 6) as one partial row per workgroup, reduced on the host in a fixed
 // order -> bitwise reproducible run to run (no float atomics).
 #include "pcc_internal.hpp"
+#include "rigid_solve.hpp"
 
 namespace pcc {
 
@@ -44,6 +45,66 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
     if (threadIdx.x < 17)
         partials[(size_t)blockIdx.x * 17 + threadIdx.x] =
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// The device-resident loop's solver: one workgroup.  Lanes 0..16 add the per-workgroup partial sums in workgroup order (the
+// order the host loop uses, so the sums have the same bits), lane 0 then runs Horn's closed form (rigid_solve.hpp) and
+// composes the running transform.  With fewer than 3 correspondences the state is frozen: this and every later pass
+// applies the identity, as if the host loop had stopped here.
+__global__ void __launch_bounds__(1024)
+k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st) {
+    __shared__ double sums[17];
+    extern __shared__ double part[];  // all partial rows, staged with coalesced loads (the rows come from other XCDs'
+                                      // write-backs: read one by one in a dependent loop they cost 120 us)
+    const int total = n_blocks * 17;
+    {
+        double v[8];  // 1024 threads x 8 loads, all in flight at once: one round trip for the whole table
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (int)threadIdx.x + u * 1024 < total ? partials[threadIdx.x + u * 1024] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if ((int)threadIdx.x + u * 1024 < total) part[threadIdx.x + u * 1024] = v[u];
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        double a = 0;
+        int b = 0;
+        for (; b + 16 <= n_blocks; b += 16) {  // 16 LDS reads in flight, added in workgroup order
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(b + u) * 17 + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
+        }
+        for (; b < n_blocks; ++b) a += part[b * 17 + threadIdx.x];
+        sums[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float Ti[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (!st->failed) {
+        double sm[17];
+        for (int k = 0; k < 17; ++k) sm[k] = sums[k];
+        float Tn[16];
+        if (rigid_from_sums(sm, Tn) != 0) {
+            st->failed = 1;
+        } else {
+            for (int k = 0; k < 16; ++k) Ti[k] = Tn[k];
+            float Tt[16];
+            for (int k = 0; k < 16; ++k) Tt[k] = st->T[k];
+            mat4_mul_f(Ti, Tt, Tt);  // final = T_i * final
+            for (int k = 0; k < 16; ++k) st->T[k] = Tt[k];
+            st->mse = sm[15] / sm[16];
+            st->ok += 1;
+        }
+    }
+    for (int k = 0; k < 16; ++k) st->Ti[k] = Ti[k];
+}
+
+int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state) {
+    hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1024), (size_t)n_blocks * 17 * sizeof(double), s, partials, n_blocks, state);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
 }
 
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,

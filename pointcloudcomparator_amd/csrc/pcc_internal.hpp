@@ -115,7 +115,7 @@ struct pcc_index {
     unsigned int last_fallback_seen = 0;  // fallback count of an earlier search (heuristic only, may be stale)
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
-        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, vox_a, vox_b, vox_c,
+        scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, icp_state, vox_a, vox_b, vox_c,
         mp_a, mp_b, mp_c;  // cellsort_mp.hip: two intermediate point buffers, bucket counters
     // PCC_TIES_FLANN (flann_order.hpp): host-side kd-tree in FLANN's shape, built on first use after every set_input
     int tie_mode = PCC_TIES_LOWEST_INDEX;
@@ -234,6 +234,15 @@ int launch_tie_flags(pcc_index* ix, const float4* q, const unsigned long long* k
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
                     const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev = nullptr,
                     unsigned int* mirror_host = nullptr);
-constexpr int ICP_MAX_BLOCKS = 512;
+constexpr int ICP_MAX_BLOCKS = 480;  // (480 rows of 17 doubles fit the 64 KB of LDS k_icp_solve stages them in)
+// state of the device-resident ICP loop (pcc_icp_align with a fixed iteration count): no host round trip per pass
+struct IcpState {
+    float Ti[16];  // transform of the pass just solved (identity once the loop is frozen)
+    float T[16];   // running product T_i * ... * T_1
+    double mse;    // sum d2 / count of the last solved pass
+    int ok;        // passes solved
+    int failed;    // a pass had fewer than 3 correspondences: the loop is frozen from there on
+};
+int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state);
 
 }  // namespace pcc
