@@ -184,7 +184,8 @@ int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
  * pcc_transform: dst = T * src with PCL's transformPointCloud rounding
  *   ((m0*x + m1*y) + m2*z) + m3; T row-major 4x4 (host); dst may alias src.
  * pcc_icp_align: the whole loop on the device (source stays resident):
- *   max_iter iterations (early exit on |mse-prev| < 1e-12 unless fixed != 0),
+ *   max_iter iterations (early exit on |mse-prev| < 1e-12 unless fixed != 0; with fixed != 0 the transform of
+ *   every pass is also solved on the device and the passes are enqueued without a host round trip),
  *   final transform T (host, row-major), *fitness = mean squared NN distance of
  *   the finally transformed source, *converged as PCL's hasConverged(). */
 int pcc_rigid_from_sums(const double sums[17], float T[16]);
