@@ -955,43 +955,51 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
     static const int warm_env = getenv("PCC_ICP_WARM") ? atoi(getenv("PCC_ICP_WARM")) : 1;  // 0: every pass from scratch (measurements)
-    static const int loop_env = getenv("PCC_ICP_DEVICE_LOOP") ? atoi(getenv("PCC_ICP_DEVICE_LOOP")) : 1;  // 0: host loop also for fixed counts
+    static const int loop_env = getenv("PCC_ICP_DEVICE_LOOP") ? atoi(getenv("PCC_ICP_DEVICE_LOOP")) : 1;  // 0: the host-driven loop (kept for comparison: same bits)
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
         pcc_index* ix;
         explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }
         ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; ix->warm_start = false; }
     } keep_order_guard(ix);
-    if (fixed && ix->engine == PCC_ENGINE_GRID && loop_env) {
-        // A fixed number of iterations needs no decision on the host: every pass is NN -> sums -> solve (one wave,
-        // k_icp_solve) -> transform with the matrix the solver left in device memory, enqueued back to back.  The host
-        // loop below costs a stream synchronisation, a read-back and a launch gap per pass (~55 us of 0.44 ms).
+    if (loop_env) {
+        // The loop lives on the device: every pass is NN -> sums -> k_icp_solve (one workgroup: the transform, the running
+        // product and the convergence criteria) -> transform with the matrix the solver left in device memory.  Passes
+        // are enqueued in chunks without a host round trip (the host loop below pays a stream synchronisation, a
+        // read-back and a launch gap per pass, ~65 us of 0.44 ms); after each chunk the host looks whether the loop
+        // has stopped.  Passes enqueued past the stop are no-ops on the state (identity transform), so a chunk costs at
+        // most its own length in wasted searches -- none with a fixed count, where the whole loop is one chunk.
         PCC_TRY(ix->icp_state.reserve(sizeof(IcpState)));
         PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
         IcpState h0{};
         memcpy(h0.Ti, I, sizeof(I));
         memcpy(h0.T, I, sizeof(I));
+        h0.prev_mse = 1.79769313486231570e308;
         PCC_HIP(hipMemcpyAsync(ix->icp_state.p, &h0, sizeof(h0), hipMemcpyHostToDevice, ix->stream));
         PCC_HIP(hipStreamSynchronize(ix->stream));  // (h0 lives on this stack frame)
         IcpState* st = ix->icp_state.as<IcpState>();
-        for (int pass = 0; pass < max_iter; ++pass) {
-            ev_next(ix);
-            ev_mark(ix, EV_CALL0);
-            PCC_TRY(nn1_packed(ix, n));
-            ix->warm_start = warm_env != 0;
-            int nb = 0;
-            PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
-                                    ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
-                                    ix->small.as<unsigned int>() + 32, static_cast<unsigned int*>(ix->pinned) + 40));
-            PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st));
-            PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
-            ev_mark(ix, EV_CALL1);
+        IcpState h1 = h0;
+        const int chunk = fixed ? max_iter : 5;
+        for (int pass = 0; pass < max_iter && !h1.stopped;) {
+            for (int c = 0; c < chunk && pass < max_iter; ++c, ++pass) {
+                ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)
+                ev_mark(ix, EV_CALL0);
+                PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
+                ix->warm_start = warm_env != 0;  // from now on out_packed holds the last pass's keys of these same points
+                int nb = 0;
+                PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
+                                        ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
+                                        ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
+                                        static_cast<unsigned int*>(ix->pinned) + 40));
+                PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed));
+                PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
+                ev_mark(ix, EV_CALL1);
+            }
+            PCC_HIP(hipMemcpyAsync(&h1, ix->icp_state.p, sizeof(h1), hipMemcpyDeviceToHost, ix->stream));
+            PCC_HIP(hipStreamSynchronize(ix->stream));
         }
-        IcpState h1;
-        PCC_HIP(hipMemcpyAsync(&h1, ix->icp_state.p, sizeof(h1), hipMemcpyDeviceToHost, ix->stream));
-        PCC_HIP(hipStreamSynchronize(ix->stream));
         memcpy(T, h1.T, sizeof(h1.T));
-        it = h1.failed ? h1.ok : max_iter;
-        conv = !h1.failed;  // DefaultConvergenceCriteria: the iteration cap counts as converged
+        it = h1.it;
+        conv = h1.converged != 0;
     } else
     while (it < max_iter) {
         ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)

@@ -47,12 +47,14 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// The device-resident loop's solver: one workgroup.  Lanes 0..16 add the per-workgroup partial sums in workgroup order (the
-// order the host loop uses, so the sums have the same bits), lane 0 then runs Horn's closed form (rigid_solve.hpp) and
-// composes the running transform.  With fewer than 3 correspondences the state is frozen: this and every later pass
-// applies the identity, as if the host loop had stopped here.
+// The device-resident loop's solver and judge: one workgroup.  Lanes 0..16 add the per-workgroup partial sums in
+// workgroup order (the order the host loop uses, so the sums have the same bits), lane 0 then runs Horn's closed form
+// (rigid_solve.hpp), composes the running transform and applies the loop's criteria exactly as the host loop does
+// (SURVEY 9.5): fewer than 3 correspondences -> stop, not converged; iteration cap -> stop, converged; |mse - previous|
+// < 1e-12 (unless `fixed`) -> stop, converged.  Once stopped the state is frozen and every later pass that was already
+// enqueued applies the identity.
 __global__ void __launch_bounds__(1024)
-k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st) {
+k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st, int max_iter, int fixed) {
     __shared__ double sums[17];
     extern __shared__ double part[];  // all partial rows, staged with coalesced loads (the rows come from other XCDs'
                                       // write-backs: read one by one in a dependent loop they cost 120 us)
@@ -82,27 +84,35 @@ k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restr
     __syncthreads();
     if (threadIdx.x != 0) return;
     float Ti[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    if (!st->failed) {
+    if (!st->stopped) {
         double sm[17];
         for (int k = 0; k < 17; ++k) sm[k] = sums[k];
         float Tn[16];
         if (rigid_from_sums(sm, Tn) != 0) {
-            st->failed = 1;
+            st->stopped = 1;  // min_number_correspondences_: not converged
+            st->converged = 0;
         } else {
             for (int k = 0; k < 16; ++k) Ti[k] = Tn[k];
             float Tt[16];
             for (int k = 0; k < 16; ++k) Tt[k] = st->T[k];
             mat4_mul_f(Ti, Tt, Tt);  // final = T_i * final
             for (int k = 0; k < 16; ++k) st->T[k] = Tt[k];
-            st->mse = sm[15] / sm[16];
-            st->ok += 1;
+            const double mse = sm[15] / sm[16];
+            const int it = st->it + 1;
+            st->it = it;
+            if (it >= max_iter || (!fixed && fabs(mse - st->prev_mse) < 1e-12)) {
+                st->stopped = 1;  // DefaultConvergenceCriteria: the iteration cap counts as converged
+                st->converged = 1;
+            }
+            st->prev_mse = mse;
         }
     }
     for (int k = 0; k < 16; ++k) st->Ti[k] = Ti[k];
 }
 
-int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state) {
-    hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1024), (size_t)n_blocks * 17 * sizeof(double), s, partials, n_blocks, state);
+int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed) {
+    hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1024), (size_t)n_blocks * 17 * sizeof(double), s, partials, n_blocks, state,
+                       max_iter, fixed);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

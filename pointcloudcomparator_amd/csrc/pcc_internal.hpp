@@ -235,14 +235,15 @@ int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned l
                     const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev = nullptr,
                     unsigned int* mirror_host = nullptr);
 constexpr int ICP_MAX_BLOCKS = 480;  // (480 rows of 17 doubles fit the 64 KB of LDS k_icp_solve stages them in)
-// state of the device-resident ICP loop (pcc_icp_align with a fixed iteration count): no host round trip per pass
+// state of the device-resident ICP loop (pcc_icp_align): no host round trip per pass
 struct IcpState {
-    float Ti[16];  // transform of the pass just solved (identity once the loop is frozen)
-    float T[16];   // running product T_i * ... * T_1
-    double mse;    // sum d2 / count of the last solved pass
-    int ok;        // passes solved
-    int failed;    // a pass had fewer than 3 correspondences: the loop is frozen from there on
+    float Ti[16];     // transform of the pass just solved (identity once the loop has stopped)
+    float T[16];      // running product T_i * ... * T_1
+    double prev_mse;  // mean squared distance of the previous pass (convergence test)
+    int it;           // iterations completed
+    int stopped;      // the loop has ended (criteria met, iteration cap, or too few correspondences): later passes are no-ops
+    int converged;    // pcl::DefaultConvergenceCriteria's verdict at the stop
 };
-int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state);
+int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed);
 
 }  // namespace pcc

@@ -154,6 +154,36 @@ def test_icp_align_recovers_offset(gpu):
     assert fit < 1e-5
 
 
+def test_icp_align_criteria_run_on_the_device(gpu):
+    """the loop, its running transform and DefaultConvergenceCriteria live on the device (k_icp_solve), passes are enqueued
+    in chunks of 5: iteration count, verdict and transform follow the oracle's host loop -- stop on the first chunk's
+    second pass (identical clouds), in a later chunk (slow convergence), at the cap, and on too few correspondences"""
+    base = _scene(30000)
+    with capi.Index(base) as ix:
+        # identical clouds: mse is 0 from the first pass, |mse - previous| < 1e-12 at the second
+        T, fit, it, conv = ix.icp_align(base[:9000], max_iter=20)
+        oT, ofit, oit, _, _ = oracle.icp(base[:9000], base, max_iter=20)
+        assert conv and it == oit == 2 and fit == 0.0
+        assert np.allclose(T, np.eye(4), atol=1e-7)
+        # mm-quantised clouds settle on fixed correspondences: the criteria fire somewhere past the first chunk
+        q = (np.round(base * 1000) / 1000).astype(np.float32)
+        with capi.Index(q) as iq:
+            src = synth.rigid_offset(q[:6000], jitter=0.0)
+            T, fit, it, conv = iq.icp_align(src, max_iter=100)
+            oT, ofit, oit, _, _ = oracle.icp(src, q, max_iter=100)
+            assert conv and it == oit and 2 < it < 100, (it, oit)
+            assert np.allclose(T, oT, atol=2e-5)
+            # the cap: same clouds, fewer iterations than they need
+            cap = max(3, it - 2)
+            T2, _, it2, conv2 = iq.icp_align(src, max_iter=cap)
+            oT2, _, oit2, _, _ = oracle.icp(src, q, max_iter=cap)
+            assert conv2 and it2 == oit2 == cap
+            assert np.allclose(T2, oT2, atol=2e-5)
+        # two source points: min_number_correspondences_ = 3 is never met
+        T, fit, it, conv = ix.icp_align(base[:2], max_iter=10)
+        assert not conv and it == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))
+
+
 def test_match_knn_mirrors_reference_quirks(gpu):
     rng = np.random.default_rng(2)
     des1 = np.zeros((600, 32), np.float32)     # RIFT32 = pcl::Histogram<32>, 128-byte stride

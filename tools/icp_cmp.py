@@ -9,7 +9,9 @@ c, s_ = np.cos(np.radians(2.0)), np.sin(np.radians(2.0))
 R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=np.float32)
 src = (src @ R.T + np.array([0.03, -0.02, 0.01], dtype=np.float32)).astype(np.float32)
 ix = capi.Index(torch.from_numpy(ref).cuda())
-r = ix.icp_align(torch.from_numpy(src).cuda(), max_iter=20, fixed=1)
+fixed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+r = ix.icp_align(torch.from_numpy(src).cuda(), max_iter=iters, fixed=fixed)
 T, fit, it, conv = r
 print(it, conv, repr(fit))
 print(T.view(np.uint32).ravel().tolist())
