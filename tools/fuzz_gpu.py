@@ -1,0 +1,190 @@
+"""Randomised parity campaign of the HIP path against the oracle (test infrastructure, like tests/): scene families
+the unit tests only touch one at a time -- scales from 1e-4 to 1e4, large offsets (coordinates ~1e5 with a small
+spread), planes, lines, duplicate piles, two clusters a long way apart, stray outliers, non-finite points, queries
+inside / around / far from the cloud -- through nn1 (both engines), k-NN, radius search, first-within, clustering and
+SOR.  Every comparison is bit-exact (d2 bits, lowest-index ties).
+
+    python tools/fuzz_gpu.py --seconds 600 [--seed 1]
+
+Prints one line per 50 cases and a summary; the first failing case of every operation is saved under gpurun_out/fuzz/.
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import oracle  # noqa: E402
+from pointcloudcomparator_amd import capi  # noqa: E402
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+def make_cloud(rng, n):
+    fam = rng.integers(0, 9)
+    scale = np.float32(10.0 ** rng.uniform(-4, 4)) if rng.random() < 0.3 else np.float32(rng.choice([0.5, 1.0, 5.0, 30.0]))
+    if fam == 0:      # uniform box, anisotropic
+        p = rng.random((n, 3), dtype=np.float32) * np.asarray(rng.choice([0.01, 0.3, 1.0], 3), np.float32)
+    elif fam == 1:    # gaussian blobs
+        c = rng.random((int(rng.integers(1, 8)), 3), dtype=np.float32)
+        p = c[rng.integers(0, len(c), n)] + rng.normal(0, 0.02, (n, 3)).astype(np.float32)
+    elif fam == 2:    # lattice with duplicates (exact ties)
+        p = rng.integers(-8, 9, (n, 3)).astype(np.float32) * np.float32(0.125)
+    elif fam == 3:    # plane
+        p = rng.random((n, 3), dtype=np.float32)
+        p[:, int(rng.integers(0, 3))] = np.float32(rng.random())
+    elif fam == 4:    # line
+        t = rng.random(n, dtype=np.float32)
+        p = np.stack([t, t * np.float32(0.5), np.full(n, 0.25, np.float32)], 1)
+        p = p[:, rng.permutation(3)]
+    elif fam == 5:    # a pile of copies of few points
+        base = rng.random((int(rng.integers(1, 6)), 3), dtype=np.float32)
+        p = base[rng.integers(0, len(base), n)]
+    elif fam == 6:    # two clusters a long way apart
+        p = rng.random((n, 3), dtype=np.float32) * np.float32(0.2)
+        p[rng.random(n) < 0.5] += np.float32(rng.choice([50.0, 1000.0]))
+    elif fam == 7:    # mm-quantised scan
+        p = np.round(rng.random((n, 3), dtype=np.float32) * 3000) / np.float32(1000)
+        p = p.astype(np.float32)
+    else:             # surface: sphere shell
+        v = rng.normal(0, 1, (n, 3)).astype(np.float32)
+        p = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6).astype(np.float32)
+    p = (p * scale).astype(np.float32)
+    if rng.random() < 0.25:   # large offset: few mantissa bits left for the spread
+        p = (p + np.asarray(rng.choice([1e3, 1e5, -3e4], 3), np.float32)).astype(np.float32)
+    if rng.random() < 0.3 and n > 20:   # stray outliers
+        k = int(rng.integers(1, 4))
+        p[rng.integers(0, n, k)] = (rng.choice([-1.0, 1.0], (k, 3)) * 10.0 ** rng.uniform(2, 6)).astype(np.float32)
+    if rng.random() < 0.3:   # non-finite references
+        k = int(rng.integers(1, max(2, n // 10)))
+        idx = rng.integers(0, n, k)
+        p[idx, rng.integers(0, 3, k)] = rng.choice([np.nan, np.inf, -np.inf], k).astype(np.float32)
+    return np.ascontiguousarray(p)
+
+
+def make_queries(rng, cloud, n):
+    fin = cloud[np.isfinite(cloud).all(1)]
+    if len(fin) == 0:
+        fin = np.zeros((1, 3), np.float32)
+    lo, hi = fin.min(0), fin.max(0)
+    ext = np.maximum(hi - lo, np.float32(1e-6))
+    mode = rng.integers(0, 5)
+    if mode == 0:      # the cloud's own points
+        q = fin[rng.integers(0, len(fin), n)].copy()
+    elif mode == 1:    # jittered
+        q = fin[rng.integers(0, len(fin), n)] + (rng.normal(0, 1, (n, 3)) * ext * 0.01).astype(np.float32)
+    elif mode == 2:    # box around the cloud
+        q = lo - ext * np.float32(0.5) + rng.random((n, 3), dtype=np.float32) * ext * np.float32(2.0)
+    elif mode == 3:    # far away
+        q = hi + ext * np.float32(rng.choice([3.0, 50.0, 1e4])) * rng.random((n, 3), dtype=np.float32)
+    else:              # mixed with non-finite queries
+        q = lo + rng.random((n, 3), dtype=np.float32) * ext
+        k = max(1, n // 8)
+        q[rng.integers(0, n, k), rng.integers(0, 3, k)] = np.nan
+    return np.ascontiguousarray(q.astype(np.float32))
+
+
+def scene_radius(rng, cloud):
+    fin = cloud[np.isfinite(cloud).all(1)]
+    if len(fin) < 2:
+        return 0.1
+    ext = float(np.median(np.maximum(fin.max(0) - fin.min(0), 1e-9)))
+    return float(np.float32(ext * 10.0 ** rng.uniform(-2.5, -0.3)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-refs", type=int, default=30000)
+    args = ap.parse_args()
+    out = ROOT / "gpurun_out" / "fuzz"
+    out.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    n_cases = 0
+    fails = {}
+    counts = {}
+
+    def check(op, ok, **dump):
+        counts[op] = counts.get(op, 0) + 1
+        if not ok:
+            if op not in fails:
+                np.savez(out / f"fail_{op}_{n_cases}.npz", **dump)
+                print(f"FAIL {op} case {n_cases}", flush=True)
+            fails[op] = fails.get(op, 0) + 1
+
+    while time.time() < t_end:
+        n_cases += 1
+        m = int(rng.choice([1, 2, 3, 14, 15, 16, 17, 63, 64, 65])) if rng.random() < 0.15 else int(10 ** rng.uniform(1, np.log10(args.max_refs)))
+        nq = int(10 ** rng.uniform(0, 3.7))
+        a = make_cloud(rng, m)
+        q = make_queries(rng, a, nq)
+        n_valid = int(np.isfinite(a).all(1).sum())
+        engine = capi.ENGINE_GRID if rng.random() < 0.8 else capi.ENGINE_BRUTE
+        try:
+            with capi.Index(a, engine=engine) as ix:
+                idx, d2 = ix.nn1(q)
+                oi, od = oracle.nn1_exhaustive(a, q)
+                check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
+                op = rng.integers(0, 6)
+                if op == 0 and n_valid >= 1:
+                    k = int(rng.integers(1, min(n_valid, 80) + 1))
+                    qs = q[:min(nq, 400)]
+                    ki, kd = ix.knn(qs, k)
+                    oki, okd = oracle.knn_exhaustive(a, qs, k)
+                    check("knn", (ki == oki).all() and (bits(kd) == bits(okd)).all(), a=a, q=qs, k=k)
+                elif op == 1:
+                    r = scene_radius(rng, a)
+                    qs = q[:min(nq, 300)]
+                    cnt = ix.radius_count(qs, r)
+                    ocnt = oracle.radius_count_exhaustive(a, qs, r)
+                    ok = (cnt == ocnt).all()
+                    if ok and int(ocnt.sum()) < 2_000_000:
+                        offs, ri, rd = ix.radius_search(qs, r, sorted=True)
+                        tree = oracle.KdTree(a)
+                        for j in range(min(len(qs), 40)):
+                            if not np.isfinite(qs[j]).all():
+                                continue
+                            oi2, od2 = tree.radius(qs[j], r)
+                            if not ((ri[offs[j]:offs[j + 1]] == oi2).all() and (bits(rd[offs[j]:offs[j + 1]]) == bits(od2)).all()):
+                                ok = False
+                                break
+                    check("radius", ok, a=a, q=qs, r=r)
+                elif op == 2 and np.isfinite(q).all():
+                    r = scene_radius(rng, a)
+                    fw = ix.first_within(q, r)
+                    ofw = oracle.first_within(a, q, r)
+                    check("first_within", (fw == ofw).all(), a=a, q=q, r=r)
+                elif op == 3 and m <= 12000:
+                    tol = scene_radius(rng, a)
+                    mn = int(rng.integers(1, 6))
+                    labels, ncl, sizes = ix.euclidean_clusters(tol, mn, 100000)
+                    ol, on, osz = oracle.euclidean_clusters(a, tol, mn, 100000)
+                    check("clusters", ncl == on and (sizes == osz).all() and (labels == ol).all(), a=a, tol=tol, mn=mn)
+                elif op == 4 and 60 <= n_valid and m <= 8000:
+                    mk = int(rng.integers(2, 51))
+                    md, inl, thr, kept = ix.sor(mean_k=mk, stddev_mult=1.5)
+                    omd, oinl, othr, okept = oracle.sor(a, mk, 1.5)
+                    check("sor", (bits(md) == bits(omd)).all() and (np.asarray(inl) == oinl).all() and thr == othr and kept == okept,
+                          a=a, mk=mk)
+                elif op == 5 and n_valid >= 3 and np.isfinite(q).all():
+                    i2, dd, sums = ix.icp_step(q)
+                    check("icp_step", (i2 == oi).all() and (bits(dd) == bits(od)).all(), a=a, q=q)
+        except capi.PccError as e:
+            # only the documented refusals are acceptable
+            msg = str(e)
+            check("status", ("empty" in msg) or ("no valid" in msg) or ("non-finite" in msg), a=a, q=q, msg=np.array(msg))
+        if n_cases % 50 == 0:
+            print(f"{n_cases} cases, {sum(counts.values())} checks, failures {fails}", flush=True)
+    print(f"DONE {n_cases} cases; checks {counts}; failures {fails}", flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
