@@ -627,6 +627,62 @@ __device__ __forceinline__ void sort_row(unsigned long long* __restrict__ row, u
         if ((unsigned int)(r * 64) + lane < len) row[r * 64 + lane] = v[r];
 }
 
+// ---- rows longer than the registers hold ---------------------------------------------------------------------
+// A bitonic network over the row in global memory, in place, by the row's wave: O(len log^2 len) against the O(len^2)
+// moves of the one-lane insertion sort this replaces (a query whose ball holds 150k references -- a radius as large
+// as the cloud -- did not come back within minutes; tools/fuzz_gpu.py found it).  The all-ascending form of the
+// network (every merge level starts with a MIRRORED compare, i against block_end - i, then plain half-cleaners) lets a
+// row of any length be treated as padded with +inf up to a power of two without storing the padding: a compare whose
+// upper index lies beyond the row is skipped.  Steps with a stride below 512 work inside aligned chunks of 512 keys, where
+// the register network sorts the chunk outright.  Accesses bypass the L1 (agent-scope relaxed atomics), a fence
+// separates the steps: lanes exchange data through memory.
+__device__ __forceinline__ unsigned long long row_ld(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void row_st(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void row_cx(unsigned long long* row, unsigned int i, unsigned int p) {
+    const unsigned long long a = row_ld(row + i), b = row_ld(row + p);
+    if (b < a) { row_st(row + i, b); row_st(row + p, a); }
+}
+__device__ __forceinline__ void sort_chunks_512(unsigned long long* row, unsigned int len, unsigned int lane) {
+    for (unsigned int c0 = 0; c0 < len; c0 += 512) {
+        const unsigned int cl = min(512u, len - c0);
+        unsigned long long v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (unsigned int)(r * 64) + lane < cl ? row_ld(row + c0 + r * 64 + lane) : ~0ull;
+        bitonic_sort_regs<8>(v, lane);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if ((unsigned int)(r * 64) + lane < cl) row_st(row + c0 + r * 64 + lane, v[r]);
+    }
+    __threadfence();
+}
+__device__ __noinline__ void sort_long_row(unsigned long long* row, unsigned int len, unsigned int lane) {
+    unsigned long long n2 = 1024;
+    while (n2 < len) n2 <<= 1;
+    __threadfence();  // (the fill kernel's keys are in memory; start from L2)
+    sort_chunks_512(row, len, lane);
+    for (unsigned long long k = 1024; k <= n2; k <<= 1) {
+        const unsigned long long half = k >> 1;
+        for (unsigned long long t = lane; t < n2 / 2; t += 64) {  // mirrored compare across the two halves of a block
+            const unsigned long long blk = t / half, o = t - blk * half;
+            const unsigned long long i = blk * k + o, p = blk * k + (k - 1 - o);
+            if (p < len) row_cx(row, (unsigned int)i, (unsigned int)p);
+        }
+        __threadfence();
+        for (unsigned long long j = k >> 2; j >= 512; j >>= 1) {  // half-cleaners down to the chunk size
+            for (unsigned long long t = lane; t < n2 / 2; t += 64) {
+                const unsigned long long i = (t / j) * 2 * j + (t % j), p = i + j;
+                if (p < len) row_cx(row, (unsigned int)i, (unsigned int)p);
+            }
+            __threadfence();
+        }
+        sort_chunks_512(row, len, lane);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_sort_rows(const int64_t* __restrict__ offsets, unsigned int nq, unsigned long long* __restrict__ keys) {
     const unsigned int lane = threadIdx.x & 63;
@@ -636,17 +692,7 @@ k_sort_rows(const int64_t* __restrict__ offsets, unsigned int nq, unsigned long 
         const unsigned int len = (unsigned int)(offsets[i + 1] - beg);
         unsigned long long* row = keys + beg;
         if (len <= 1) continue;
-        if (len > ROW_SORT_MAX) {
-            // longer than the registers hold (rare): in place, one lane
-            if (lane == 0)
-                for (unsigned int a = 1; a < len; ++a) {
-                    const unsigned long long key = row[a];
-                    unsigned int b = a;
-                    while (b > 0 && row[b - 1] > key) { row[b] = row[b - 1]; --b; }
-                    row[b] = key;
-                }
-            continue;
-        }
+        if (len > ROW_SORT_MAX) { sort_long_row(row, len, lane); continue; }
         if (len <= 64) sort_row<1>(row, len, lane);
         else if (len <= 128) sort_row<2>(row, len, lane);
         else if (len <= 256) sort_row<4>(row, len, lane);

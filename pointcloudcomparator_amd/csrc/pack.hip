@@ -382,10 +382,14 @@ k_sor_mean_staged(const unsigned long long* __restrict__ keys, size_t n, int K, 
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
                     float* mean_dist) {
     if (n == 0) return PCC_OK;
-    const size_t lds = (size_t)4 * 64 * (K + 1) * sizeof(unsigned int);
-    if (lds <= 48 * 1024) {
-        const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_sor_mean_staged, dim3(blocks), dim3(256), lds, s, keys, n, K, mean_dist);
+    // four waves per workgroup while their tiles fit 64 KB of LDS (K <= 62; PCL's default mean_k = 50 gives K = 51:
+    // 53 KB), two up to K = 126
+    const int waves = (size_t)4 * 64 * (K + 1) * sizeof(unsigned int) <= 64 * 1024 ? 4 : 2;
+    const size_t lds = (size_t)waves * 64 * (K + 1) * sizeof(unsigned int);
+    if (lds <= 64 * 1024) {
+        const int bs = waves * 64;
+        const int blocks = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
+        hipLaunchKernelGGL(k_sor_mean_staged, dim3(blocks), dim3(bs), lds, s, keys, n, K, mean_dist);
     } else {
         hipLaunchKernelGGL(k_sor_mean, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, refs, n, K, mean_dist);
     }

@@ -154,6 +154,25 @@ def test_icp_align_recovers_offset(gpu):
     assert fit < 1e-5
 
 
+@pytest.mark.parametrize("m", [513, 1024, 1025, 3000, 70000])
+def test_sorted_rows_longer_than_the_register_sort(gpu, m):
+    """rows of more than 512 neighbours are sorted by a bitonic network over global memory (any length, +inf padding
+    implied): a radius that swallows the whole cloud, keys with many equal distances (lattice) -- against the oracle's
+    kd-tree rows, which are sorted by (d2, index)"""
+    rng = np.random.default_rng(m)
+    a = (rng.integers(-20, 21, (m, 3)) * 0.01).astype(np.float32)      # lattice: plenty of exact ties
+    a[: m // 2] += rng.random((m // 2, 3), dtype=np.float32) * np.float32(0.003)
+    q = np.concatenate([a[:3], np.array([[0.05, -0.02, 0.01]], np.float32)])
+    r = 1.0
+    with capi.Index(a) as ix:
+        offs, idx, d2 = ix.radius_search(q, r, sorted=True)
+    assert (np.diff(offs) == m).all()
+    tree = oracle.KdTree(a)
+    for j in range(len(q)):
+        oi, od = tree.radius(q[j], r)
+        assert (idx[offs[j]:offs[j + 1]] == oi).all() and (_bits(d2[offs[j]:offs[j + 1]]) == _bits(od)).all()
+
+
 def test_icp_align_criteria_run_on_the_device(gpu):
     """the loop, its running transform and DefaultConvergenceCriteria live on the device (k_icp_solve), passes are enqueued
     in chunks of 5: iteration count, verdict and transform follow the oracle's host loop -- stop on the first chunk's

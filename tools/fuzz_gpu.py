@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-refs", type=int, default=30000)
+    ap.add_argument("--trace", default=None, help="append one line per case BEFORE it runs (to find a case that hangs)")
     args = ap.parse_args()
     out = ROOT / "gpurun_out" / "fuzz"
     out.mkdir(parents=True, exist_ok=True)
@@ -127,12 +128,18 @@ def main():
         q = make_queries(rng, a, nq)
         n_valid = int(np.isfinite(a).all(1).sum())
         engine = capi.ENGINE_GRID if rng.random() < 0.8 else capi.ENGINE_BRUTE
+        if args.trace:
+            with open(args.trace, "a") as f:
+                f.write(f"case {n_cases} m {m} nq {nq} valid {n_valid} engine {engine} t {time.time() - (t_end - args.seconds):.1f}\n")
         try:
             with capi.Index(a, engine=engine) as ix:
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
                 check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
                 op = rng.integers(0, 6)
+                if args.trace:
+                    with open(args.trace, "a") as f:
+                        f.write(f"  nn1 done, op {op}\n")
                 if op == 0 and n_valid >= 1:
                     k = int(rng.integers(1, min(n_valid, 80) + 1))
                     qs = q[:min(nq, 400)]
