@@ -136,7 +136,7 @@ def main():
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
                 check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
-                op = rng.integers(0, 6)
+                op = rng.integers(0, 9)
                 if args.trace:
                     with open(args.trace, "a") as f:
                         f.write(f"  nn1 done, op {op}\n")
@@ -180,6 +180,38 @@ def main():
                     omd, oinl, othr, okept = oracle.sor(a, mk, 1.5)
                     check("sor", (bits(md) == bits(omd)).all() and (np.asarray(inl) == oinl).all() and thr == othr and kept == okept,
                           a=a, mk=mk)
+                elif op == 6 and 10 <= n_valid and m <= 15000 and n_valid == m:
+                    # region growing on the library's own normals and neighbour rows (both checked elsewhere): labels
+                    # must equal the oracle's sequential walk exactly
+                    k = int(rng.integers(3, min(m, 60)))
+                    nrm = ix.normals(min(k, 50))
+                    if np.isfinite(nrm).all():
+                        th = float(rng.choice([3.0, 6.0, 20.0])) / 180.0 * np.pi
+                        ct = float(rng.choice([0.02, 0.1, 1.0]))
+                        mn = int(rng.integers(1, 30))
+                        labels, ncl = ix.region_growing(nrm, k=k, smoothness=th, curvature_threshold=ct, min_size=mn, max_size=1000000)
+                        nbr, _ = ix.knn(a, k)
+                        want, want_n = oracle.region_growing(nrm, nbr, th, ct, mn, 1000000)
+                        check("region_growing", ncl == want_n and (labels == want).all(), a=a, k=k, th=th, ct=ct, mn=mn)
+                elif op == 7 and m <= 20000 and n_valid == m and m >= 3:
+                    thr = scene_radius(rng, a) * 0.2
+                    opt = bool(rng.integers(0, 2))
+                    mi = int(rng.choice([1, 20, 100]))
+                    inl, coeff, its = ix.sac_plane(a, max_iterations=mi, threshold=thr, optimize=opt)
+                    winl, wc, wits = oracle.sac_plane(a, max_iterations=mi, threshold=thr, optimize=opt)
+                    check("sac", its == wits and len(inl) == len(winl) and (np.asarray(inl) == winl).all() and
+                          (np.asarray(coeff, np.float32).view(np.uint32) == wc.view(np.uint32)).all(), a=a, thr=thr, opt=opt, mi=mi)
+                elif op == 8 and m <= 20000 and n_valid >= 1:
+                    leaf = scene_radius(rng, a) * 2.0
+                    fin = a[np.isfinite(a).all(1)]
+                    if (np.ceil((fin.max(0) - fin.min(0)) / leaf) + 1).prod() < 5e6:
+                        got = ix.voxel_grid(a, leaf)
+                        vg, nv = oracle.voxel_grid(a, leaf)
+                        # PCL adds a voxel's points in FLOAT (the oracle does too), the library in double: they differ by up to
+                        # (points per voxel) x 2^-24 x |coordinate| (a pile of 12 757 copies at x = -3e4 is 2.8 apart)
+                        tol = max(1e-5, 1.2e-7 * len(fin)) * max(1.0, float(np.abs(fin).max()))
+                        ok = nv < 0 or (len(got) == nv and np.allclose(got[:, :3], vg[:, :3], rtol=0, atol=tol))
+                        check("voxel", ok, a=a, leaf=leaf)
                 elif op == 5 and n_valid >= 3 and np.isfinite(q).all():
                     i2, dd, sums = ix.icp_step(q)
                     check("icp_step", (i2 == oi).all() and (bits(dd) == bits(od)).all(), a=a, q=q)
