@@ -436,23 +436,20 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const int x0 = max(cx - 1, 0);
         const bool shifted = cx == 0;                // the 16-byte load then starts at the own cell, not at its left neighbour
         const bool has_right = cx + 1 < g.dim[0];
-        // per row the four bounds L <= A <= B <= R: [L,A) left cell, [A,B) own cell, [B,R) right cell
-        unsigned int rL[9], rA[9], rB[9], rR[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        // per row the four bounds L <= A <= B <= R: [L,A) left cell, [A,B) own cell, [B,R) right cell -- all of them with
+        // ONE gather: <= 3 cells, so they sit in one (unaligned) 16-byte load (cell_start is padded by 4 entries)
+        auto row_bounds = [&](int i, bool wanted, unsigned int& L, unsigned int& A, unsigned int& B, unsigned int& R) {
             const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
-            const bool ok = z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+            const bool ok = wanted && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
             const unsigned int row = ((unsigned int)(ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
-            // all bounds of the row with ONE gather: <= 3 cells, so they sit in one (unaligned) 16-byte load
-            // (cell_start is padded by 4 entries)
             uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
             if (ok) b4 = *reinterpret_cast<const uint4*>(cell_start + row + x0);
-            rL[i] = b4.x;
-            rA[i] = shifted ? b4.x : b4.y;
-            rB[i] = shifted ? b4.y : b4.z;
+            L = b4.x;
+            A = shifted ? b4.x : b4.y;
+            B = shifted ? b4.y : b4.z;
             const unsigned int r3 = shifted ? b4.z : b4.w;
-            rR[i] = has_right ? r3 : rB[i];
-        }
+            R = has_right ? r3 : B;
+        };
         // Own row first; every other row only where the ball of the best distance so far reaches it: rows whose
         // y/z gap already exceeds it are skipped, and the left / right cell of a row is dropped when the gap to the own
         // cell's face plus the row's gap exceeds it (squared gaps against the squared distance: no square root, no cell
@@ -468,21 +465,32 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
         const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
         const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
-        {
-            // (without a warm start the best distance is still NaN here and the own row is scanned whole)
-            const float bd = __uint_as_float((unsigned int)(best >> 32));
-            best = scan_span<U>(cell_refs, gxl2 > bd ? rA[4] : rL[4], gxr2 > bd ? rB[4] : rR[4], qx, qy, qz, best);
-        }
+        // Two rounds of bound gathers: the own row and its four face neighbours, then the four diagonal rows -- by then
+        // the best distance is tight and a lane fetches the bounds of a diagonal row only if its ball reaches it.  20
+        // bound registers live instead of 36: 8 waves per SIMD instead of 7.
+        constexpr int round_rows[2][5] = {{4, 3, 5, 1, 7}, {0, 2, 6, 8, -1}};
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            constexpr int order8[8] = {3, 5, 1, 7, 0, 2, 6, 8};  // face neighbours of the own row first, then the diagonal ones
-            const int i = order8[o];
-            if (rL[i] == rR[i]) continue;
-            const float bd = __uint_as_float((unsigned int)(best >> 32));
-            const float rem = bd - (gy2[i % 3] + gz2[i / 3]);
-            if (rem < 0.f) continue;  // every point of the row is strictly farther than the best
-            const unsigned int s0 = gxl2 > rem ? rA[i] : rL[i], e0 = gxr2 > rem ? rB[i] : rR[i];
-            best = scan_span<U>(cell_refs, s0, e0, qx, qy, qz, best);
+        for (int rd = 0; rd < 2; ++rd) {
+            unsigned int rL[5], rA[5], rB[5], rR[5];
+            const float bd0 = __uint_as_float((unsigned int)(best >> 32));
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                const int i = round_rows[rd][o];
+                if (i < 0) continue;
+                const bool wanted = rd == 0 || !(bd0 - (gy2[i % 3] + gz2[i / 3]) < 0.f);
+                row_bounds(i, wanted, rL[o], rA[o], rB[o], rR[o]);
+            }
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                const int i = round_rows[rd][o];
+                if (i < 0) continue;
+                if (rL[o] == rR[o]) continue;
+                const float bd = __uint_as_float((unsigned int)(best >> 32));
+                const float rem = bd - (gy2[i % 3] + gz2[i / 3]);  // (own row: the gaps are 0; a NaN distance keeps the row whole)
+                if (rem < 0.f) continue;  // every point of the row is strictly farther than the best
+                const unsigned int s0 = gxl2 > rem ? rA[o] : rL[o], e0 = gxr2 > rem ? rB[o] : rR[o];
+                best = scan_span<U>(cell_refs, s0, e0, qx, qy, qz, best);
+            }
         }
         const int x1 = min(cx + 1, g.dim[0] - 1);
         const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
@@ -511,7 +519,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         qx = oq.x; qy = oq.y; qz = oq.z;
         qi = __float_as_uint(oq.w);
         best = open_best[j];
-        nn1_finish<U>(cell_refs, cell_start, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk);
+        nn1_finish<2>(cell_refs, cell_start, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk);
     }
 }
 
