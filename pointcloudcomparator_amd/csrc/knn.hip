@@ -54,7 +54,7 @@ __device__ __forceinline__ void knn_scan_span(const float4* __restrict__ cell_re
 __global__ void __launch_bounds__(256)
 k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
            const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-           const unsigned int* __restrict__ n_sorted_ptr, unsigned int n, int K,
+           const unsigned int* __restrict__ n_sorted_ptr, unsigned int /*n*/, int K,
            unsigned long long* __restrict__ keys) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
@@ -406,9 +406,9 @@ template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_grid_radius(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
               const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-              const unsigned int* __restrict__ n_sorted_ptr, unsigned int n, float r, float r2,
+              const unsigned int* __restrict__ n_sorted_ptr, unsigned int /*n*/, float r, float r2,
               int32_t* __restrict__ counts, const int64_t* __restrict__ offsets,
-              unsigned long long* __restrict__ keys, int sorted) {
+              unsigned long long* __restrict__ keys, int /*sorted*/) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -338,7 +338,7 @@ int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n) {
 // pcl::StatisticalOutlierRemoval::applyFilterIndices inner loop: neighbour 0 is the
 // point itself; dist_sum (double) += sqrt(d2_j) for j = 1..mean_k; distances[i] = float(dist_sum / mean_k)
 __global__ void __launch_bounds__(256)
-k_sor_mean(const unsigned long long* __restrict__ keys, const float4* __restrict__ refs, size_t n, int K,
+k_sor_mean(const unsigned long long* __restrict__ keys, const float4* __restrict__ /*refs*/, size_t n, int K,
            float* __restrict__ mean_dist) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned long long* row = keys + i * (size_t)K;

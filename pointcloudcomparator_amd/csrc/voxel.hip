@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256)
 k_vox_centroids(const float4* __restrict__ pts, const char* __restrict__ raw, size_t stride, int has_rgb,
                 const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted,
                 const GridDev* __restrict__ gd, const unsigned int* __restrict__ pos /* scanned flags */,
-                char* __restrict__ out, size_t out_stride, unsigned int n) {
+                char* __restrict__ out, size_t out_stride, unsigned int /*n*/) {
     const GridParams g = gd->g;
     const unsigned int ns = *n_sorted;
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < ns; t += gridDim.x * blockDim.x) {
