@@ -90,6 +90,7 @@ def make_queries(rng, cloud, n):
 
 
 def scene_radius(rng, cloud):
+    cloud = cloud[:, :3]
     fin = cloud[np.isfinite(cloud).all(1)]
     if len(fin) < 2:
         return 0.1
@@ -126,7 +127,19 @@ def main():
         nq = int(10 ** rng.uniform(0, 3.7))
         a = make_cloud(rng, m)
         q = make_queries(rng, a, nq)
-        n_valid = int(np.isfinite(a).all(1).sum())
+        # point layouts of the boundary: 12-, 16- (PointXYZ), 32- (PointXYZRGB) and 128-byte (Histogram<32>) strides;
+        # whatever sits beside x, y, z -- NaN included -- must not matter
+        def widen(p):
+            w = int(rng.choice([3, 3, 4, 8, 32]))
+            if w == 3:
+                return p
+            o = rng.random((len(p), w), dtype=np.float32)
+            if rng.random() < 0.5:
+                o[:, 3:] = np.nan
+            o[:, :3] = p
+            return o
+        a, q = widen(a), widen(q)
+        n_valid = int(np.isfinite(a[:, :3]).all(1).sum())
         engine = capi.ENGINE_GRID if rng.random() < 0.8 else capi.ENGINE_BRUTE
         if args.trace:
             with open(args.trace, "a") as f:
@@ -156,14 +169,14 @@ def main():
                         offs, ri, rd = ix.radius_search(qs, r, sorted=True)
                         tree = oracle.KdTree(a)
                         for j in range(min(len(qs), 40)):
-                            if not np.isfinite(qs[j]).all():
+                            if not np.isfinite(qs[j, :3]).all():
                                 continue
-                            oi2, od2 = tree.radius(qs[j], r)
+                            oi2, od2 = tree.radius(qs[j, :3], r)
                             if not ((ri[offs[j]:offs[j + 1]] == oi2).all() and (bits(rd[offs[j]:offs[j + 1]]) == bits(od2)).all()):
                                 ok = False
                                 break
                     check("radius", ok, a=a, q=qs, r=r)
-                elif op == 2 and np.isfinite(q).all():
+                elif op == 2 and np.isfinite(q[:, :3]).all():
                     r = scene_radius(rng, a)
                     fw = ix.first_within(q, r)
                     ofw = oracle.first_within(a, q, r)
@@ -203,7 +216,7 @@ def main():
                           (np.asarray(coeff, np.float32).view(np.uint32) == wc.view(np.uint32)).all(), a=a, thr=thr, opt=opt, mi=mi)
                 elif op == 8 and m <= 20000 and n_valid >= 1:
                     leaf = scene_radius(rng, a) * 2.0
-                    fin = a[np.isfinite(a).all(1)]
+                    fin = a[:, :3][np.isfinite(a[:, :3]).all(1)]
                     if (np.ceil((fin.max(0) - fin.min(0)) / leaf) + 1).prod() < 5e6:
                         got = ix.voxel_grid(a, leaf)
                         vg, nv = oracle.voxel_grid(a, leaf)
@@ -212,7 +225,7 @@ def main():
                         tol = max(1e-5, 1.2e-7 * len(fin)) * max(1.0, float(np.abs(fin).max()))
                         ok = nv < 0 or (len(got) == nv and np.allclose(got[:, :3], vg[:, :3], rtol=0, atol=tol))
                         check("voxel", ok, a=a, leaf=leaf)
-                elif op == 5 and n_valid >= 3 and np.isfinite(q).all():
+                elif op == 5 and n_valid >= 3 and np.isfinite(q[:, :3]).all():
                     i2, dd, sums = ix.icp_step(q)
                     check("icp_step", (i2 == oi).all() and (bits(dd) == bits(od)).all(), a=a, q=q)
         except capi.PccError as e:
