@@ -149,7 +149,7 @@ def main():
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
                 check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
-                op = rng.integers(0, 9)
+                op = rng.integers(0, 10)
                 if args.trace:
                     with open(args.trace, "a") as f:
                         f.write(f"  nn1 done, op {op}\n")
@@ -225,6 +225,14 @@ def main():
                         tol = max(1e-5, 1.2e-7 * len(fin)) * max(1.0, float(np.abs(fin).max()))
                         ok = nv < 0 or (len(got) == nv and np.allclose(got[:, :3], vg[:, :3], rtol=0, atol=tol))
                         check("voxel", ok, a=a, leaf=leaf)
+                elif op == 9 and n_valid >= 1 and np.isfinite(q[:, :3]).all():
+                    # PCC_TIES_FLANN: among equally near references the one FLANN's tree walk meets first -- the oracle's
+                    # kd-tree restatement decides (lattices and piles of copies are full of ties)
+                    ix.set_tie_order(capi.TIES_FLANN)
+                    fi, fd = ix.nn1(q)
+                    ix.set_tie_order(capi.TIES_LOWEST_INDEX)
+                    ti, td = oracle.KdTree(a).nn1_batch(q)
+                    check("ties_flann", (fi == ti).all() and (bits(fd) == bits(td)).all(), a=a, q=q, engine=engine)
                 elif op == 5 and n_valid >= 3 and np.isfinite(q[:, :3]).all():
                     i2, dd, sums = ix.icp_step(q)
                     check("icp_step", (i2 == oi).all() and (bits(dd) == bits(od)).all(), a=a, q=q)
