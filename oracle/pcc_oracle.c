@@ -41,17 +41,18 @@ void orc_nn1_exhaustive(const void *ref, size_t m, size_t rstride,
     for (size_t i = 0; i < n; ++i) {
         const float *q = pt_at(qry, qstride, i);
         int32_t bi = -1;
-        float bd = INFINITY;
+        float bd = FLT_MAX; /* KNNSimpleResultSet: worst_distance_ starts at max() and dist >= worst is rejected, so a
+                               squared distance that overflowed (or equals FLT_MAX) is no neighbour */
         if (finite3(q)) {
             for (size_t j = 0; j < m; ++j) {
                 const float *r = pt_at(ref, rstride, j);
                 if (!finite3(r)) continue;
                 float d = l2_simple(q, r);
-                if (bi < 0 || d < bd) { bd = d; bi = (int32_t)j; } /* strict <: lowest index wins */
+                if (d < bd) { bd = d; bi = (int32_t)j; } /* strict <: lowest index wins */
             }
         }
         idx[i] = bi;
-        d2[i] = bd;
+        d2[i] = bi < 0 ? INFINITY : bd;
     }
 }
 
@@ -77,7 +78,7 @@ int orc_knn_exhaustive(const void *ref, size_t m, size_t rstride,
                 if (!finite3(r)) continue;
                 all[c].d = l2_simple(q, r);
                 all[c].i = (int32_t)j;
-                ++c;
+                if (all[c].d < FLT_MAX) ++c; /* dist >= worst_distance_ (FLT_MAX at the start) is never inserted */
             }
             qsort(all, c, sizeof(di_t), di_cmp);
         }

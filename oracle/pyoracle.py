@@ -106,9 +106,11 @@ def nn1_numpy(ref: np.ndarray, qry: np.ndarray, chunk: int = 256):
         dz = q[:, None, 2] - r[None, :, 2]
         d = d + dz * dz
         a = np.argmin(d, axis=1)  # first occurrence = lowest index
-        ok = np.isfinite(q).all(1)
+        dm = d[np.arange(len(q)), a]
+        # FLANN's result set starts with worst = FLT_MAX and rejects dist >= worst: an overflowed distance is no neighbour
+        ok = np.isfinite(q).all(1) & (dm < np.finfo(np.float32).max)
         idx[s:s + chunk] = np.where(ok, vidx[a], -1)
-        d2[s:s + chunk] = np.where(ok, d[np.arange(len(q)), a], np.inf)
+        d2[s:s + chunk] = np.where(ok, dm, np.inf)
     return idx, d2
 
 

@@ -197,7 +197,7 @@ k_tie_flags_grid(const float4* __restrict__ cell_refs, const unsigned int* __res
     const GridParams g = gd->g;
     const float4 qv = q[i];
     const unsigned long long key = keys[i];
-    if (__float_as_int(qv.w) < 0 || key == ~0ull) { flags[i] = 0; return; }
+    if (__float_as_int(qv.w) < 0 || key_none(key)) { flags[i] = 0; return; }
     const float bd = __uint_as_float((unsigned int)(key >> 32));
     const unsigned int bi = (unsigned int)key;
     const float rb = sqrtf(bd) * 1.00001f + gd->slack;
@@ -227,7 +227,7 @@ k_tie_flags_brute(const float4* __restrict__ refs, unsigned int m, const float4*
     if (i >= n) return;
     const float4 qv = q[i];
     const unsigned long long key = keys[i];
-    if (__float_as_int(qv.w) < 0 || key == ~0ull) { flags[i] = 0; return; }
+    if (__float_as_int(qv.w) < 0 || key_none(key)) { flags[i] = 0; return; }
     const float bd = __uint_as_float((unsigned int)(key >> 32));
     const unsigned int bi = (unsigned int)key;
     bool tie = false;

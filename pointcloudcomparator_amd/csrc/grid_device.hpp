@@ -54,8 +54,12 @@ __device__ __forceinline__ float outside_bound2(float qx, float qy, float qz, in
     if (y1 < g.dim[1] - 1) lb = fminf(lb, (g.org[1] + (y1 + 1) * g.h) - qy);
     if (z0 > 0) lb = fminf(lb, qz - (g.org[2] + z0 * g.h));
     if (z1 < g.dim[2] - 1) lb = fminf(lb, (g.org[2] + (z1 + 1) * g.h) - qz);
+    if (lb == __builtin_inff()) return lb;  // no face left: the cube is the whole grid
     lb = fmaxf(lb - slack, 0.f);      // absolute slack: cell-boundary rounding
-    return lb * lb * 0.9999f;         // relative slack: rounding of the fp32 distances
+    // relative slack: rounding of the fp32 distances.  Kept FINITE: with coordinates around 1e20 the square overflows,
+    // and +inf means "nothing outside the cube" to the callers -- while the distances it stands for overflow as well
+    // and tie with a lower index out there (found by tools/fuzz_gpu.py)
+    return fminf(lb * lb * 0.9999f, 3.4028234664e38f);
 }
 
 

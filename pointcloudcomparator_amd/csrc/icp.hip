@@ -23,7 +23,7 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long key = keys[i];
         const float4 p = src[i];
-        if (key == ~0ull || __float_as_int(p.w) < 0) continue;  // no correspondence
+        if (key_none(key) || __float_as_int(p.w) < 0) continue;  // no correspondence
         const float4 t = refs[(unsigned int)(key & 0xffffffffull)];
         const double px = p.x, py = p.y, pz = p.z, qx = t.x, qy = t.y, qz = t.z;
         acc[0] += px; acc[1] += py; acc[2] += pz;

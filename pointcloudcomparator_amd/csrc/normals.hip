@@ -51,7 +51,7 @@ k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict_
                 const size_t row = (size_t)(unsigned int)__float_as_int(cell_refs[rr].w);
                 if ((int)lane < kc) {
                     const unsigned long long key = keys[row * (size_t)K + c0 + lane];
-                    tile[r][lane] = key == ~0ull ? 0xffffffffu : (unsigned int)key;
+                    tile[r][lane] = key_none(key) ? 0xffffffffu : (unsigned int)key;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

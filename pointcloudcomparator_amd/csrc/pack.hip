@@ -264,7 +264,7 @@ k_unpack(const unsigned long long* __restrict__ packed, const float4* __restrict
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         unsigned long long p = packed[i];
-        bool ok = (!q || __float_as_int(q[i].w) >= 0) && p != ~0ull;
+        bool ok = (!q || __float_as_int(q[i].w) >= 0) && !key_none(p);
         if (idx) idx[i] = ok ? (int32_t)(unsigned int)(p & 0xffffffffull) : -1;
         if (d2) d2[i] = ok ? __uint_as_float((unsigned int)(p >> 32)) : __builtin_inff();
     }
@@ -342,7 +342,7 @@ k_sor_mean(const unsigned long long* __restrict__ keys, const float4* __restrict
            float* __restrict__ mean_dist) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned long long* row = keys + i * (size_t)K;
-        if (row[K - 1] == ~0ull) continue;  // invalid point or fewer than K neighbours: distance stays 0
+        if (key_none(row[K - 1])) continue;  // invalid point or fewer than K neighbours: distance stays 0
         double s = 0.0;
         for (int j = 1; j < K; ++j) s += sqrt((double)__uint_as_float((unsigned int)(row[j] >> 32)));
         mean_dist[i] = (float)(s / (double)(K - 1));
@@ -370,7 +370,7 @@ k_sor_mean_staged(const unsigned long long* __restrict__ keys, size_t n, int K, 
         __builtin_amdgcn_wave_barrier();
         if (lane < rows) {
             const unsigned int* row = tile + lane * (K + 1);
-            if (row[K - 1] != 0xffffffffu) {  // else: invalid point or fewer than K neighbours, distance stays 0
+            if (row[K - 1] < 0x7f7fffffu) {  // else: invalid point or fewer than K neighbours (key_none), distance stays 0
                 double s = 0.0;
                 for (int j = 1; j < K; ++j) s += sqrt((double)__uint_as_float(row[j]));
                 mean_dist[base + lane] = (float)(s / (double)(K - 1));

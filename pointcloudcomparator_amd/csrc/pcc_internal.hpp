@@ -136,6 +136,15 @@ struct pcc_index {
 
 namespace pcc {
 
+// A search key is (d2 bits << 32 | position); ~0 means "nothing found".  FLANN starts every result set with a worst
+// distance of FLT_MAX and rejects dist >= worst (KNNSimpleResultSet), so a candidate whose squared distance
+// overflowed -- coordinates around 1e19 -- is no neighbour either: every consumer of a key treats d2 >= FLT_MAX like ~0.
+// (The searches themselves keep such candidates: they only matter when nothing finite exists.)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool key_none(unsigned long long key) { return (unsigned int)(key >> 32) >= 0x7f7fffffu; }
+
 enum { EV_MAIN0 = 0, EV_MAIN1, EV_FB0, EV_FB1, EV_CALL0, EV_CALL1, EV_BUILD0, EV_BUILD1, EV_SORT0, EV_SORT1 };
 inline void ev_mark(pcc_index* ix, int id) {
     if (!ix->timing || (ix->timing == 1 && id > EV_MAIN1)) return;

@@ -101,7 +101,7 @@ k_rg_link(const unsigned long long* __restrict__ keys, const float4* __restrict_
     for (int base = 0; base < K; base += 64) {
         const int j = base + (int)lane;
         const unsigned long long key = j < K ? row[j] : ~0ull;
-        if (key == ~0ull) continue;
+        if (key_none(key)) continue;
         const unsigned int v = (unsigned int)key;
         if (v >= u) continue;  // every mutual pair is seen from both ends: the higher one links
         const float4 nv = normals[v];
@@ -142,7 +142,7 @@ k_rg_sweep(const unsigned long long* __restrict__ keys, const float4* __restrict
     for (int base = 0; base < K; base += 64) {
         const int j = base + (int)lane;
         const unsigned long long key = j < K ? row[j] : ~0ull;
-        if (key == ~0ull) continue;
+        if (key_none(key)) continue;
         const unsigned int v = (unsigned int)key;
         const unsigned int rv = parent[v];
         if (rv == ru) continue;
@@ -182,7 +182,7 @@ k_rg_sweep_general(const unsigned long long* __restrict__ keys, const float4* __
     for (int base = 0; base < K; base += 64) {
         const int j = base + (int)lane;
         const unsigned long long key = j < K ? row[j] : ~0ull;
-        if (key == ~0ull) continue;
+        if (key_none(key)) continue;
         const unsigned int v = (unsigned int)key;
         const unsigned int rv = parent[v];
         if (rv == ru) continue;

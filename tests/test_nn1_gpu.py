@@ -202,3 +202,37 @@ def test_ties_flann_device_buffers_and_match_knn(gpu):
         got = ix.match_knn(d2_, 0.05)
     assert len(low) == len(want) and (low != want).any()
     assert (got == want).all()
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_overflowed_distances_are_no_neighbours(gpu, engine):
+    """coordinates around 1e19-1e21: every squared distance of the far queries overflows.  FLANN rejects dist >= FLT_MAX
+    (its initial worst distance), so nearestKSearch finds nothing: idx -1, d2 +inf, in both engines and tie orders, in
+    k-NN rows and in the ICP sums -- and the cube bound of the grid walk must not mistake its own overflow for "the cube
+    is the whole grid" (tools/fuzz_gpu.py found that one)."""
+    rng = np.random.default_rng(3)
+    ref = (rng.random((20000, 3), dtype=np.float32) * np.float32(2e18)).astype(np.float32)
+    ref[:, 2] = np.float32(3e17)                                  # a plane: one layer of cells
+    far = (rng.random((300, 3), dtype=np.float32) * np.float32(1e21) + np.float32(5e20)).astype(np.float32)
+    far[:, 2] = np.float32(3e17)
+    near = (ref[:300] * np.float32(1.0001)).astype(np.float32)
+    q = np.concatenate([far, near])
+    oi, od = oracle.nn1_exhaustive(ref, q)
+    assert (oi[:300] == -1).all() and (oi[300:] >= 0).all()
+    with capi.Index(ref, engine=engine) as ix:
+        for ties in (capi.TIES_LOWEST_INDEX, capi.TIES_FLANN):
+            ix.set_tie_order(ties)
+            idx, d2 = ix.nn1(q)
+            assert (idx[:300] == -1).all() and np.isinf(d2[:300]).all()
+            if ties == capi.TIES_LOWEST_INDEX:
+                assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+            else:
+                ti, td = oracle.KdTree(ref).nn1_batch(q)
+                assert (idx == ti).all() and (_bits(d2) == _bits(td)).all()
+        ix.set_tie_order(capi.TIES_LOWEST_INDEX)
+        ki, kd = ix.knn(q, 7)
+        oki, okd = oracle.knn_exhaustive(ref, q, 7)
+        assert (ki == oki).all() and (_bits(kd) == _bits(okd)).all()
+        _, _, sums = ix.icp_step(q)
+        assert sums[16] == 300          # only the near points have a correspondence
+

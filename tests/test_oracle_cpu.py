@@ -350,3 +350,23 @@ def test_region_growing_restatement_equals_components_when_edges_are_symmetric()
     # same partition: labels are a relabelling of the components
     pairs = set(zip(lab.tolist(), comp.tolist()))
     assert len(pairs) == nc
+
+
+def test_overflowed_distances_are_no_neighbours():
+    """FLANN's result sets start with worst_distance_ = FLT_MAX and reject dist >= worst: with coordinates
+    around 1e19-1e21 every squared distance overflows and nearestKSearch finds nothing.  The kd-tree restatement, the C
+    exhaustive scan and the numpy definition agree on that, and on the finite cases beside it."""
+    rng = np.random.default_rng(3)
+    ref = (rng.random((500, 3), dtype=np.float32) * np.float32(2e18)).astype(np.float32)
+    far = (rng.random((40, 3), dtype=np.float32) * np.float32(1e21) + np.float32(5e20)).astype(np.float32)   # all d2 = inf
+    near = (ref[:40] * np.float32(1.0001)).astype(np.float32)                                                # finite d2
+    for q, none in ((far, True), (near, False)):
+        ti, td = oracle.KdTree(ref).nn1_batch(q)
+        ei, ed = oracle.nn1_exhaustive(ref, q)
+        ni, nd = oracle.nn1_numpy(ref, q)
+        assert (ti == ei).all() and (ei == ni).all()
+        assert (td.view(np.uint32) == ed.view(np.uint32)).all() and (ed.view(np.uint32) == nd.view(np.uint32)).all()
+        assert ((ei < 0) == none).all() and (np.isinf(ed) == none).all()
+    ki, kd = oracle.knn_exhaustive(ref, far, 5)
+    assert (ki == -1).all() and np.isinf(kd).all()
+
