@@ -27,6 +27,8 @@
  *     (FLANN L2_Simple<float>); distances are SQUARED;
  *   - exact-distance ties resolve to the LOWEST original index;
  *   - a non-finite query never aborts: idx = -1, d2 = +inf, count = 0.
+ *   - a squared distance that overflows float (>= FLT_MAX) is no neighbour, as in FLANN (its result sets start
+ *     with worst_distance = FLT_MAX and reject dist >= worst): idx = -1, d2 = +inf.
  */
 #ifndef PCC_NN_H
 #define PCC_NN_H
