@@ -189,7 +189,9 @@ def main():
                     labels, ncl, sizes = ix.euclidean_clusters(tol, mn, 100000)
                     ol, on, osz = oracle.euclidean_clusters(a, tol, mn, 100000)
                     check("clusters", ncl == on and (sizes == osz).all() and (labels == ol).all(), a=a, tol=tol, mn=mn)
-                elif op == 4 and 60 <= n_valid and m <= 8000:
+                elif op == 4 and 60 <= n_valid and m <= 8000 and float(np.nanmax(np.abs(np.where(np.isfinite(a[:, :3]), a[:, :3], 0)))) < 1e15:
+                    # (with overflowing distances a neighbour row comes back shorter than mean_k + 1, a case PCL's filter
+                    # does not define -- it reads the row to its full length regardless)
                     mk = int(rng.integers(2, 51))
                     md, inl, thr, kept = ix.sor(mean_k=mk, stddev_mult=1.5)
                     omd, oinl, othr, okept = oracle.sor(a, mk, 1.5)
