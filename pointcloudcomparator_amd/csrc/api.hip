@@ -857,13 +857,13 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
 
 // ---- ICP ------------------------------------------------------------------------------------
 // reduce the per-workgroup partial rows in a fixed order
-static int icp_reduce(pcc_index* ix, size_t n, double sums[17]) {
+static int icp_reduce(pcc_index* ix, size_t n, double sums[17], const double* center = nullptr) {
     PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
     int nb = 0;
     PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
                             ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
                             ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
-                            static_cast<unsigned int*>(ix->pinned) + 40));
+                            static_cast<unsigned int*>(ix->pinned) + 40, center));
     std::vector<double> h((size_t)nb * 17);
     PCC_HIP(hipMemcpyAsync(h.data(), ix->scratch_a.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
     PCC_HIP(hipStreamSynchronize(ix->stream));
@@ -954,6 +954,11 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     int it = 0;
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
+    // the sums of every pass are taken about a point of the source cloud (k_icp_center: no cancellation in the
+    // covariance for clouds far from the origin); it sits behind the loop state in device memory
+    PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + 3 * sizeof(double)));
+    double* center_dev = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
+    PCC_TRY(launch_icp_center(ix->stream, ix->q_packed.as<float4>(), n, center_dev));
     static const int warm_env = getenv("PCC_ICP_WARM") ? atoi(getenv("PCC_ICP_WARM")) : 1;  // 0: every pass from scratch (measurements)
     static const int loop_env = getenv("PCC_ICP_DEVICE_LOOP") ? atoi(getenv("PCC_ICP_DEVICE_LOOP")) : 1;  // 0: the host-driven loop (kept for comparison: same bits)
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
@@ -968,7 +973,6 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         // read-back and a launch gap per pass, ~65 us of 0.44 ms); after each chunk the host looks whether the loop
         // has stopped.  Passes enqueued past the stop are no-ops on the state (identity transform), so a chunk costs at
         // most its own length in wasted searches -- none with a fixed count, where the whole loop is one chunk.
-        PCC_TRY(ix->icp_state.reserve(sizeof(IcpState)));
         PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
         IcpState h0{};
         memcpy(h0.Ti, I, sizeof(I));
@@ -989,8 +993,8 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
                 PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
                                         ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
                                         ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
-                                        static_cast<unsigned int*>(ix->pinned) + 40));
-                PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed));
+                                        static_cast<unsigned int*>(ix->pinned) + 40, center_dev));
+                PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed, center_dev));
                 PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
                 ev_mark(ix, EV_CALL1);
             }
@@ -1000,16 +1004,23 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         memcpy(T, h1.T, sizeof(h1.T));
         it = h1.it;
         conv = h1.converged != 0;
-    } else
+    } else {
+    double center[3] = {0, 0, 0};
+    bool have_center = false;
     while (it < max_iter) {
         ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)
         ev_mark(ix, EV_CALL0);
         PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
         ix->warm_start = warm_env != 0;  // from now on out_packed holds the last pass's keys of these same points
         double sums[17];
-        PCC_TRY(icp_reduce(ix, n, sums));
+        PCC_TRY(icp_reduce(ix, n, sums, center_dev));
+        if (!have_center) {
+            PCC_HIP(hipMemcpyAsync(center, center_dev, sizeof(center), hipMemcpyDeviceToHost, ix->stream));
+            PCC_HIP(hipStreamSynchronize(ix->stream));
+            have_center = true;
+        }
         float Ti[16];
-        if (rigid_from_sums(sums, Ti) != 0) { conv = false; break; }  // < 3 correspondences: not converged
+        if (rigid_from_sums(sums, Ti, center) != 0) { conv = false; break; }  // < 3 correspondences: not converged
         PCC_TRY(launch_transform(ix->stream, nullptr, Ti, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
         ev_mark(ix, EV_CALL1);
         mat4_mul_f(Ti, T, T);  // final = T_i * final
@@ -1018,6 +1029,7 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         if (it >= max_iter) { conv = true; break; }  // DefaultConvergenceCriteria: iteration cap counts as converged
         if (!fixed && std::fabs(mse - prev_mse) < 1e-12) { conv = true; break; }
         prev_mse = mse;
+    }
     }
     if (iterations) *iterations = it;
     if (converged) *converged = conv ? 1 : 0;

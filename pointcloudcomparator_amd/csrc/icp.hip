@@ -15,7 +15,8 @@ namespace pcc {
 __global__ void __launch_bounds__(256)
 k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long long* __restrict__ keys,
            const float4* __restrict__ refs, double* __restrict__ partials, const unsigned int* __restrict__ mirror_dev,
-           unsigned int* __restrict__ mirror_host) {
+           unsigned int* __restrict__ mirror_host, const double* __restrict__ center) {
+    const double cx = center ? center[0] : 0.0, cy = center ? center[1] : 0.0, cz = center ? center[2] : 0.0;
     if (mirror_dev && blockIdx.x == 0 && threadIdx.x == 0) *mirror_host = *mirror_dev;  // fallback count for the far-query heuristic
     double acc[17];
 #pragma unroll
@@ -25,7 +26,9 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
         const float4 p = src[i];
         if (key_none(key) || __float_as_int(p.w) < 0) continue;  // no correspondence
         const float4 t = refs[(unsigned int)(key & 0xffffffffull)];
-        const double px = p.x, py = p.y, pz = p.z, qx = t.x, qy = t.y, qz = t.z;
+        // (about the caller's centre: see rigid_from_sums; exact in double, a float difference would not be)
+        const double px = (double)p.x - cx, py = (double)p.y - cy, pz = (double)p.z - cz;
+        const double qx = (double)t.x - cx, qy = (double)t.y - cy, qz = (double)t.z - cz;
         acc[0] += px; acc[1] += py; acc[2] += pz;
         acc[3] += qx; acc[4] += qy; acc[5] += qz;
         acc[6] += qx * px; acc[7] += qx * py; acc[8] += qx * pz;
@@ -54,7 +57,8 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
 // < 1e-12 (unless `fixed`) -> stop, converged.  Once stopped the state is frozen and every later pass that was already
 // enqueued applies the identity.
 __global__ void __launch_bounds__(1024)
-k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st, int max_iter, int fixed) {
+k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st, int max_iter, int fixed,
+            const double* __restrict__ center_dev) {
     __shared__ double sums[17];
     extern __shared__ double part[];  // all partial rows, staged with coalesced loads (the rows come from other XCDs'
                                       // write-backs: read one by one in a dependent loop they cost 120 us)
@@ -88,7 +92,8 @@ k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restr
         double sm[17];
         for (int k = 0; k < 17; ++k) sm[k] = sums[k];
         float Tn[16];
-        if (rigid_from_sums(sm, Tn) != 0) {
+        const double center[3] = {center_dev[0], center_dev[1], center_dev[2]};
+        if (rigid_from_sums(sm, Tn, center) != 0) {
             st->stopped = 1;  // min_number_correspondences_: not converged
             st->converged = 0;
         } else {
@@ -110,21 +115,45 @@ k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restr
     for (int k = 0; k < 16; ++k) st->Ti[k] = Ti[k];
 }
 
-int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed) {
+int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed,
+                     const double* center_dev) {
     hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1024), (size_t)n_blocks * 17 * sizeof(double), s, partials, n_blocks, state,
-                       max_iter, fixed);
+                       max_iter, fixed, center_dev);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+// The point the ICP sums are taken about: the first valid source point (any point OF the cloud keeps sum q p^T - n pm qm^T
+// within a small factor of the covariance it is meant to be; the centre of a bounding box does not when stray points
+// stretch the box).  Zero for an all-invalid cloud.
+__global__ void __launch_bounds__(64)
+k_icp_center(const float4* __restrict__ src, unsigned int n, double* __restrict__ center) {
+    const unsigned int lane = threadIdx.x;
+    for (unsigned int base = 0; base < n; base += 64) {  // wave-uniform
+        const unsigned int i = base + lane;
+        const float4 v = i < n ? src[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        const unsigned long long ok = __ballot(__float_as_int(v.w) >= 0);
+        if (ok) {
+            if (lane == (unsigned int)__builtin_ctzll(ok)) { center[0] = v.x; center[1] = v.y; center[2] = v.z; }
+            return;
+        }
+    }
+    if (lane == 0) center[0] = center[1] = center[2] = 0.0;
+}
+int launch_icp_center(hipStream_t s, const float4* src, size_t n, double* center_dev) {
+    hipLaunchKernelGGL(k_icp_center, dim3(1), dim3(64), 0, s, src, (unsigned int)n, center_dev);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }
 
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
                     const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev,
-                    unsigned int* mirror_host) {
+                    unsigned int* mirror_host, const double* center) {
     size_t b = (n + 256 * 8 - 1) / (256 * 8);
     if (b < 1) b = 1;
     if (b > ICP_MAX_BLOCKS) b = ICP_MAX_BLOCKS;
     *n_blocks = (int)b;
-    hipLaunchKernelGGL(k_icp_sums, dim3((unsigned)b), dim3(256), 0, s, src, (unsigned int)n, keys, refs, partials, mirror_dev, mirror_host);
+    hipLaunchKernelGGL(k_icp_sums, dim3((unsigned)b), dim3(256), 0, s, src, (unsigned int)n, keys, refs, partials, mirror_dev, mirror_host, center);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

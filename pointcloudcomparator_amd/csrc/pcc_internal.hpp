@@ -242,7 +242,7 @@ int launch_tie_flags(pcc_index* ix, const float4* q, const unsigned long long* k
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
                     const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev = nullptr,
-                    unsigned int* mirror_host = nullptr);
+                    unsigned int* mirror_host = nullptr, const double* center_dev = nullptr);  // sums of p - center, q - center (device pointer)
 constexpr int ICP_MAX_BLOCKS = 480;  // (480 rows of 17 doubles fit the 64 KB of LDS k_icp_solve stages them in)
 // state of the device-resident ICP loop (pcc_icp_align): no host round trip per pass
 struct IcpState {
@@ -253,6 +253,8 @@ struct IcpState {
     int stopped;      // the loop has ended (criteria met, iteration cap, or too few correspondences): later passes are no-ops
     int converged;    // pcl::DefaultConvergenceCriteria's verdict at the stop
 };
-int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed);
+int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed,
+                     const double* center_dev);
+int launch_icp_center(hipStream_t s, const float4* src, size_t n, double* center_dev);  // first valid point of src
 
 }  // namespace pcc

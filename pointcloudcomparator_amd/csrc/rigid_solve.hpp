@@ -78,7 +78,11 @@ PCC_HD void sym4_max_eigvec(double A[4][4], double v[4]) {
 // rigid transform (rotation + translation, no scale) minimising sum |R p + t - q|^2 from the sums:
 // the same optimum TransformationEstimationSVD / Eigen::umeyama(src, tgt, false) returns, obtained
 // with Horn's unit-quaternion method in double.  Returns 0, or -1 with < 3 correspondences.
-PCC_HD int rigid_from_sums(const double sums[17], float T[16]) {
+// `center` (nullable): the sums were accumulated over p - center and q - center.  S = sum q p^T - n pm qm^T cancels
+// catastrophically for a small cloud far from the origin (43 points 8 cm across at (1e3, 1e5, 1e5): sums of 4e11 for
+// a covariance of 0.3 -- the rotation came out 3e-5 rad off, 7 mm on that cloud); the ICP loop therefore sums about the
+// centre of the target's bounding box.  The translation is formed with the true means.
+PCC_HD int rigid_from_sums(const double sums[17], float T[16], const double* center = nullptr) {
     const double n = sums[16];
     if (n < 3) return -1;  // min_number_correspondences_
     double pm[3], qm[3], S[3][3];
@@ -98,6 +102,8 @@ PCC_HD int rigid_from_sums(const double sums[17], float T[16]) {
     const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
                             {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
                             {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    if (center)
+        for (int a = 0; a < 3; ++a) { pm[a] += center[a]; qm[a] += center[a]; }
     for (int r = 0; r < 3; ++r) {
         double t = qm[r];
         for (int c = 0; c < 3; ++c) { T[r * 4 + c] = (float)R[r][c]; t -= R[r][c] * pm[c]; }

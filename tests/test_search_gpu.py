@@ -203,6 +203,35 @@ def test_icp_align_criteria_run_on_the_device(gpu):
         assert not conv and it == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))
 
 
+def test_icp_align_far_from_the_origin(gpu):
+    """a small cloud at geo-referenced coordinates (8 cm across at (1e3, 1e5, 1e5)): the rotation comes from sum q p^T
+    - n pm qm^T, 4e11 against 0.3 -- summed about the origin it lost five digits and an exact copy of the cloud came out
+    7 mm off (tools/fuzz_seq_gpu.py found it).  The loop sums about the centre of the target's bounding box."""
+    rng = np.random.default_rng(5)
+    base = (np.array([1000.0, 100000.0, 100000.0]) + rng.random((43, 3)) * 0.08).astype(np.float32)
+    with capi.Index(base) as ix:
+        T, fit, it, conv = ix.icp_align(base, max_iter=6)
+        assert conv and it == 2 and fit == 0.0
+        assert np.allclose(T[:3, :3], np.eye(3), atol=1e-9) and np.abs(T[:3, 3]).max() < 1e-4
+        # and a real offset on a larger cloud out there: against the oracle's loop
+        big = (np.array([1000.0, 100000.0, 100000.0]) + rng.random((4000, 3)) * 2.0).astype(np.float32)
+        ix.set_input(big)
+        c, s_ = np.cos(0.02), np.sin(0.02)
+        R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+        ctr = big.mean(0).astype(np.float64)
+        src = ((big[:1500].astype(np.float64) - ctr) @ R.T + ctr + np.array([0.01, -0.02, 0.015])).astype(np.float32)
+        T, fit, it, conv = ix.icp_align(src, max_iter=15)
+        oT, ofit, oit, _, _ = oracle.icp(src, big, max_iter=15)
+        assert it == oit
+        truth = big[:1500].astype(np.float64)       # the source is a moved copy of these
+        moved = (src.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64))
+        omoved = (src.astype(np.float64) @ oT[:3, :3].astype(np.float64).T + oT[:3, 3].astype(np.float64))
+        err, oerr = np.abs(moved - truth).max(), np.abs(omoved - truth).max()
+        # float positions out there resolve 0.008: both loops end ~0.015 from the truth, in their own directions
+        assert err < 0.03 and err <= oerr + 0.005
+        assert fit < 2 * ofit + 1e-6
+
+
 def test_match_knn_mirrors_reference_quirks(gpu):
     rng = np.random.default_rng(2)
     des1 = np.zeros((600, 32), np.float32)     # RIFT32 = pcl::Histogram<32>, 128-byte stride

@@ -238,7 +238,12 @@ def main():
                     fi, fd = ix.nn1(q)
                     ix.set_tie_order(capi.TIES_LOWEST_INDEX)
                     ti, td = oracle.KdTree(a).nn1_batch(q)
-                    check("ties_flann", (fi == ti).all() and (bits(fd) == bits(td)).all(), a=a, q=q, engine=engine)
+                    # (FLANN's walk is not always exact in float: its branch bounds round, and far from a tight cluster it
+                    # can settle one ulp above the true minimum.  The library returns the minimum; the replay only decides
+                    # among references AT the minimum, so compare indices where FLANN found it.)
+                    xi, xd = oracle.nn1_exhaustive(a, q)
+                    at_min = bits(td) == bits(xd)
+                    check("ties_flann", (bits(fd) == bits(xd)).all() and (fi[at_min] == ti[at_min]).all(), a=a, q=q, engine=engine)
                 elif op == 5 and n_valid >= 3 and np.isfinite(q[:, :3]).all():
                     i2, dd, sums = ix.icp_step(q)
                     check("icp_step", (i2 == oi).all() and (bits(dd) == bits(od)).all(), a=a, q=q)
