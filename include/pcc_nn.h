@@ -182,7 +182,9 @@ int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
  *   the Umeyama/Kabsch solution, solved in double, returned as a row-major float 4x4) those sums determine.
  *   Pure host arithmetic, needs no handle: a caller that shards the SOURCE cloud over several GPUs adds up the
  *   sums of all shards (one all-reduce of 17 doubles per iteration) and gets the same transform on every rank.
- *   Returns PCC_ERR_INVALID when fewer than 3 correspondences contributed.
+ *   Returns PCC_ERR_INVALID when fewer than 3 correspondences contributed.  The sums are about the ORIGIN: for a small
+ *   cloud at large coordinates (geo-referenced scans) sum q p^T - n pm qm^T cancels -- shift both clouds by a common
+ *   offset first.  pcc_icp_align does the equivalent itself (it sums about a point of the source cloud).
  * pcc_transform: dst = T * src with PCL's transformPointCloud rounding
  *   ((m0*x + m1*y) + m2*z) + m3; T row-major 4x4 (host); dst may alias src.
  * pcc_icp_align: the whole loop on the device (source stays resident):
