@@ -9,10 +9,19 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_fuzz_campaign_short_leg(gpu, monkeypatch):
-    path = Path(__file__).resolve().parent.parent / "tools" / "fuzz_gpu.py"
-    spec = importlib.util.spec_from_file_location("fuzz_gpu", path)
+def _run(tool, argv, monkeypatch):
+    path = Path(__file__).resolve().parent.parent / "tools" / tool
+    spec = importlib.util.spec_from_file_location(tool[:-3], path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "--seconds", "20", "--seed", "7", "--max-refs", "20000"])
-    assert mod.main() == 0
+    monkeypatch.setattr(sys, "argv", [tool] + argv)
+    return mod.main()
+
+
+def test_fuzz_campaign_short_leg(gpu, monkeypatch):
+    assert _run("fuzz_gpu.py", ["--seconds", "20", "--seed", "7", "--max-refs", "20000"], monkeypatch) == 0
+
+
+def test_fuzz_sequences_short_leg(gpu, monkeypatch):
+    """one long-lived handle, random rebuilds and searches of every kind in turn (tools/fuzz_seq_gpu.py)"""
+    assert _run("fuzz_seq_gpu.py", ["--seconds", "15", "--seed", "11", "--max-refs", "20000"], monkeypatch) == 0
