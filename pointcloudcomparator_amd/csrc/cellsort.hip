@@ -26,6 +26,7 @@ constexpr unsigned int CS_SLICE = 4096;    // points per workgroup in passes 1 a
 constexpr unsigned int CS_MAX_G = 512;     // workgroups (slices grow beyond 2M points; measured best at 10M)
 constexpr unsigned int CS_BUCKETS = 2048;  // coarse buckets aimed for
 constexpr unsigned int CS_MAX_F = 24576;   // cells per bucket: up to 96 KiB of LDS counters (10M+ points)
+constexpr unsigned int CS_FINE_STAGE = 1024;  // points a pass-3 bucket places in LDS before writing them out in whole lines
 
 struct CsPlan {
     unsigned int F, B, G, slice;
@@ -146,6 +147,9 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
         run += c;                                                      // [ncells] receives the total
     }
     __syncthreads();
+    // a bucket of up to CS_FINE_STAGE points (the usual case) is placed in LDS and leaves in whole lines
+    const bool staged = out_pts && end - beg <= CS_FINE_STAGE;
+    float4* st_pts = reinterpret_cast<float4*>(lds + ((F + 4 + 3) & ~3u));
     for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * CS_T) {
         uint2 kv[4];
         float4 v[4];
@@ -162,10 +166,15 @@ k_cs_fine(const GridDev* __restrict__ gd, unsigned int F, unsigned int G, const 
             const unsigned int pos = atomicAdd(&cnt[kv[u].x - cell0], 1u);
             if (out_pts) {
                 v[u].w = __int_as_float((int)kv[u].y);  // cell-sorted copies carry the packed position
-                out_pts[pos] = v[u];
+                if (staged) st_pts[pos - beg] = v[u];
+                else out_pts[pos] = v[u];
             }
             if (out_order) out_order[pos] = kv[u].y;
         }
+    }
+    if (staged) {
+        __syncthreads();
+        for (unsigned int i = threadIdx.x; i < end - beg; i += CS_T) out_pts[beg + i] = st_pts[i];
     }
 }
 
@@ -202,7 +211,7 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
     if (n_sorted_dev) *n_sorted_dev = H + h_elems - 1;  // grand total == number of valid points
-    const size_t lds3 = ((size_t)p.F + 4) * sizeof(unsigned int);
+    const size_t lds3 = (((size_t)p.F + 4 + 3) & ~(size_t)3) * sizeof(unsigned int) + (out_pts ? (size_t)CS_FINE_STAGE * sizeof(float4) : 0);
     hipLaunchKernelGGL(k_cs_scatter, dim3(p.G), dim3(CS_T), 0, s, n, p.F, p.slice, key_rank, H, tmp_kv);
     if (refs)
         hipLaunchKernelGGL((k_cs_fine<true>), dim3(p.B), dim3(CS_T), lds3, s, gd, p.F, p.G, H, pts,

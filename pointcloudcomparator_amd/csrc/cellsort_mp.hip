@@ -29,6 +29,7 @@ constexpr unsigned int MP_MAX_G = 512;    // level-1 workgroups
 constexpr unsigned int MP_SLICE2 = 8192;  // points per level-2 workgroup (counting form)
 constexpr unsigned int MP_STAGE_BYTES = 32768;  // LDS the placing form stages its slice in (2048 points or 4096 pairs)
 constexpr unsigned int MP_WIN = 8;        // level-1 buckets a level-2 slice keeps LDS counters for
+constexpr unsigned int MP_FINE_STAGE = 1536;  // points a level-3 bucket places in LDS before writing them out in whole lines
 
 struct MpPlan {
     unsigned int F1, F2, B1, G1, slice1;
@@ -215,6 +216,11 @@ k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ ends /* cur
         run += c;
     }
     __syncthreads();
+    // A bucket of up to MP_FINE_STAGE points (the usual case) is placed in LDS and leaves in whole lines; bigger ones
+    // scatter their 16-byte (or 4-byte) pieces straight to memory.
+    const bool staged = end - beg <= MP_FINE_STAGE;
+    float4* st_pts = reinterpret_cast<float4*>(lds + ((F2 + 4 + 3) & ~3u));
+    unsigned int* st_ord = reinterpret_cast<unsigned int*>(st_pts + (out_pts ? MP_FINE_STAGE : 0));
     for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * MP_T) {
         E v[4];
 #pragma unroll
@@ -224,8 +230,20 @@ k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ ends /* cur
         for (int u = 0; u < 4; ++u) {
             if (j0 + u * MP_T >= end) break;
             const unsigned int pos = atomicAdd(&cnt[mp_cell(v[u], g, voxel) - cell0], 1u);
-            mp_store_point(out_pts, pos, v[u]);  // .w still carries the packed position (the original index)
-            if (out_order) out_order[pos] = mp_position(v[u]);
+            if (staged) {
+                mp_store_point(out_pts ? st_pts : nullptr, pos - beg, v[u]);
+                if (out_order) st_ord[pos - beg] = mp_position(v[u]);
+            } else {
+                mp_store_point(out_pts, pos, v[u]);  // .w still carries the packed position (the original index)
+                if (out_order) out_order[pos] = mp_position(v[u]);
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (unsigned int i = threadIdx.x; i < end - beg; i += MP_T) {
+            if (out_pts) out_pts[beg + i] = st_pts[i];
+            if (out_order) out_order[beg + i] = st_ord[i];
         }
     }
 }
@@ -256,7 +274,9 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
     PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
     unsigned int* n_valid = H + h_elems - 1;  // grand total == number of valid points
     if (n_sorted_dev) *n_sorted_dev = n_valid;
-    const size_t lds3 = ((size_t)p.F2 + 4) * sizeof(unsigned int);
+    // counters + scan words, then the staged output (points and / or order words)
+    const size_t lds3 = (((size_t)p.F2 + 4 + 3) & ~(size_t)3) * sizeof(unsigned int) +
+                        (size_t)MP_FINE_STAGE * ((out_pts ? sizeof(float4) : 0) + (out_order ? sizeof(unsigned int) : 0));
     PCC_HIP(hipMemsetAsync(C, 0, (size_t)np * sizeof(unsigned int), s));
     const unsigned int g2c = (n + MP_SLICE2 - 1) / MP_SLICE2;
     if (out_pts) {  // the points travel (reference clouds)
