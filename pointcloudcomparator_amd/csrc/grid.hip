@@ -337,7 +337,18 @@ template <int U>
 __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                                            const GridParams& g, float slack, float qx, float qy, float qz, unsigned int qi,
                                            unsigned long long best, unsigned long long* __restrict__ out,
-                                           unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count, bool ball) {
+                                           unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count, bool ball,
+                                           const float4* __restrict__ warm_refs) {
+    // Warm start (ICP passes after the first): out[] still holds every query's neighbour of the previous pass.  A query
+    // with nothing in its cube has moved a little since, that reference is most likely still its neighbour or next to
+    // it: its distance NOW is an upper bound held by a real point -- no cube doubling, and a query beyond the cell walk
+    // takes the bound along to the far walk instead of needing the seed scan.  (Folding it in before phase 1, for every
+    // lane, bought nothing there -- at 0.5 references per cell a tight ball still touches most of the cube -- and cost
+    // a 16-byte gather per query.)
+    if (warm_refs && best == ~0ull) {
+        const unsigned long long pk = out[qi];
+        if (pk != ~0ull) best = fold(best, qx, qy, qz, warm_refs[(unsigned int)pk]);
+    }
     const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
     const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
     const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
@@ -519,7 +530,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         qx = oq.x; qy = oq.y; qz = oq.z;
         qi = __float_as_uint(oq.w);
         best = open_best[j];
-        nn1_finish<2>(cell_refs, cell_start, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk);
+        nn1_finish<2>(cell_refs, cell_start, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk, warm_refs);
     }
 }
 
