@@ -135,7 +135,10 @@ def main():
                         fit_ok = abs(fit - ofit) <= 2e-3 * max(abs(ofit), 1e-30) + 1e-10 * scale * scale
                         # (with criteria the stop hinges on two consecutive mean squared errors being EQUAL to 1e-12; at
                         # the quantisation floor of large coordinates the two solvers reach that a pass apart)
-                        coarse = float(np.abs(a[:, :3]).max()) > 1e3 * ext     # float positions quantised to > 1e-4 of the extent
+                        # float positions quantised to > 1e-4 of the extent of what is being aligned (there the oracle's own
+                        # Umeyama, which sums about the origin, is the less exact of the two)
+                        ext_q = float(np.linalg.norm(Q.max(0) - Q.min(0)))
+                        coarse = float(np.abs(Q).max()) > 1e3 * max(ext_q, 1e-30) or float(np.abs(a[:, :3]).max()) > 1e3 * ext
                         ok = coarse or (it == oit and fit_ok) or (not fixed and abs(it - oit) <= 1 and abs(fit - ofit) <= 0.1 * max(abs(ofit), 1e-30))   # (coarse: the loops only chase quantisation noise)
                         check("icp_align", ok, a=a, q=q, it_max=it_max, fixed=fixed, T=T, oT=oT, fit=fit, ofit=ofit, it=it, oit=oit)
                 elif op == 7 and len(a) <= 12000:
