@@ -432,14 +432,6 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
-    // Warm start (ICP passes after the first): out[] still holds every query's neighbour of the previous pass.  The
-    // query has moved a little since, that reference is most likely still its neighbour or next to it: its distance
-    // NOW is an upper bound held by a real point, so the clipping below bites from the first row on, and a query
-    // beyond the cube walk takes the bound with it to the far walk instead of needing the seed scan.
-    if (warm_refs && active) {
-        const unsigned long long pk = out[qi];
-        if (pk != ~0ull) best = fold(best, qx, qy, qz, warm_refs[(unsigned int)pk]);
-    }
     // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (9 independent 16-byte loads, one latency), then the
     // rows are streamed.  The kernel is VALU-issue bound (PMC: 3000 VALU instructions per wave, the SIMDs 70 % busy),
     // so everything per row is kept to a handful of instructions.
