@@ -1111,6 +1111,9 @@ static double det3(const double M[9]) {
            M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
+/* rotation and translation from the covariance sigma = (1/n) sum (q - qm)(p - pm)^T and the two means */
+static void umeyama_core(const double S[9], const double pm[3], const double qm[3], float T[16]);
+
 int orc_umeyama_from_sums(const double sums[17], float T[16]) {
     double n = sums[16];
     if (n < 3) return -1; /* min_number_correspondences_ = 3 (9.5) */
@@ -1119,6 +1122,11 @@ int orc_umeyama_from_sums(const double sums[17], float T[16]) {
     /* sigma = (1/n) sum (q - qm)(p - pm)^T = (1/n) sum q p^T - qm pm^T */
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) S[r * 3 + c] = sums[6 + r * 3 + c] / n - qm[r] * pm[c];
+    umeyama_core(S, pm, qm, T);
+    return 0;
+}
+
+static void umeyama_core(const double S[9], const double pm[3], const double qm[3], float T[16]) {
     double U[9], V[9], sv[3];
     svd3(S, U, sv, V);
     double d[3] = {1, 1, 1};
@@ -1140,7 +1148,6 @@ int orc_umeyama_from_sums(const double sums[17], float T[16]) {
     }
     T[12] = T[13] = T[14] = 0.0f;
     T[15] = 1.0f;
-    return 0;
 }
 
 static void mat4_mul(const float A[16], const float B[16], float C[16]) {
@@ -1170,7 +1177,26 @@ int orc_icp(const void *src, size_t n, size_t sstride, const void *tgt, size_t m
         double sums[17];
         orc_icp_step_sums(tree, tgt, tstride, cur, n, 12, idx, d2, sums);
         float Ti[16];
-        if (orc_umeyama_from_sums(sums, Ti) != 0) break;
+        if (sums[16] < 3) break; /* min_number_correspondences_ */
+        {
+            /* Eigen::umeyama demeans the matched pairs before it forms the covariance (two passes); the one-pass
+               sum q p^T - n qm pm^T of orc_umeyama_from_sums cancels for a small cloud far from the origin */
+            double pm[3] = {0, 0, 0}, qm[3] = {0, 0, 0}, S[9] = {0};
+            for (size_t i = 0; i < n; ++i) {
+                if (idx[i] < 0) continue;
+                const float *q = pt_at(tgt, tstride, (size_t)idx[i]);
+                for (int a = 0; a < 3; ++a) { pm[a] += cur[3 * i + a]; qm[a] += q[a]; }
+            }
+            for (int a = 0; a < 3; ++a) { pm[a] /= sums[16]; qm[a] /= sums[16]; }
+            for (size_t i = 0; i < n; ++i) {
+                if (idx[i] < 0) continue;
+                const float *q = pt_at(tgt, tstride, (size_t)idx[i]);
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) S[r * 3 + c] += ((double)q[r] - qm[r]) * ((double)cur[3 * i + c] - pm[c]);
+            }
+            for (int k = 0; k < 9; ++k) S[k] /= sums[16];
+            umeyama_core(S, pm, qm, Ti);
+        }
         orc_transform(Ti, cur, n, 12, cur);
         mat4_mul(Ti, T, T); /* final = T * final */
         double mse = sums[15] / sums[16];
