@@ -135,8 +135,8 @@ def main():
                         fit_ok = abs(fit - ofit) <= 2e-3 * max(abs(ofit), 1e-30) + 1e-10 * scale * scale
                         # (with criteria the stop hinges on two consecutive mean squared errors being EQUAL to 1e-12; at
                         # the quantisation floor of large coordinates the two solvers reach that a pass apart)
-                        # float positions quantised to > 1e-4 of the extent of what is being aligned (there the oracle's own
-                        # Umeyama, which sums about the origin, is the less exact of the two)
+                        # float positions quantised to > 1e-4 of the extent of what is being aligned: both loops chase
+                        # quantisation noise there
                         ext_q = float(np.linalg.norm(Q.max(0) - Q.min(0)))
                         coarse = float(np.abs(Q).max()) > 1e3 * max(ext_q, 1e-30) or float(np.abs(a[:, :3]).max()) > 1e3 * ext
                         ok = coarse or (it == oit and fit_ok) or (not fixed and abs(it - oit) <= 1 and abs(fit - ofit) <= 0.1 * max(abs(ofit), 1e-30))   # (coarse: the loops only chase quantisation noise)
