@@ -195,6 +195,12 @@ int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
 int pcc_rigid_from_sums(const double sums[17], float T[16]);
 int pcc_icp_step(pcc_index *target, const void *src, size_t n, size_t stride_bytes,
                  int mem, int32_t *idx, float *d2, double sums[17]);
+/* The same two with the sums taken about `center` (sum (p - c), sum (q - c), sum (q - c)(p - c)^T; NULL = origin):
+ * what a multi-GPU ICP loop over a geo-referenced cloud should use -- every rank passes the SAME center (any point of
+ * the cloud, e.g. its first), adds up the sums of all ranks and solves with that center. */
+int pcc_rigid_from_sums_about(const double sums[17], const double center[3], float T[16]);
+int pcc_icp_step_about(pcc_index *target, const void *src, size_t n, size_t stride_bytes, int mem,
+                       const double center[3], int32_t *idx, float *d2, double sums[17]);
 int pcc_transform(pcc_index *ctx, const float T[16], const void *src, size_t n,
                   size_t src_stride, void *dst, size_t dst_stride, int mem);
 int pcc_icp_align(pcc_index *target, const void *src, size_t n, size_t stride_bytes,

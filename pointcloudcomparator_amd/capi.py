@@ -30,6 +30,7 @@ SYMBOLS = [
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
+    "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
 ]
 
@@ -84,6 +85,8 @@ def _load() -> C.CDLL:
     lib.pcc_radius_count.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_first_within.argtypes = [vp, vp, sz, sz, i32, C.c_double, vp]
     lib.pcc_rigid_from_sums.argtypes = [vp, vp]
+    lib.pcc_rigid_from_sums_about.argtypes = [vp, vp, vp]
+    lib.pcc_icp_step_about.argtypes = [vp, vp, sz, sz, i32, vp, vp, vp, C.POINTER(C.c_double)]
     lib.pcc_sac_plane.argtypes = [vp, vp, sz, sz, i32, i32, C.c_double, C.c_double, i32, vp, C.POINTER(sz), vp, vp]
     lib.pcc_normals.argtypes = [vp, i32, vp, i32, vp]
     lib.pcc_normals_radius.argtypes = [vp, C.c_double, vp, i32, vp]
@@ -150,12 +153,18 @@ def _out(like, shape, dtype):
     return a, a.ctypes.data
 
 
-def rigid_from_sums(sums):
-    """4x4 float32 rigid transform from the 17 ICP sums (pcc_rigid_from_sums; host arithmetic, no handle)."""
+def rigid_from_sums(sums, center=None):
+    """4x4 float32 rigid transform from the 17 ICP sums (pcc_rigid_from_sums[_about]; host arithmetic, no handle).
+    center: the point the sums were taken about (Index.icp_step(..., center=...)); None = the origin."""
     sm = np.ascontiguousarray(sums, dtype=np.float64)
     assert sm.shape == (17,)
     T = np.zeros(16, dtype=np.float32)
-    _check(LIB.pcc_rigid_from_sums(sm.ctypes.data, T.ctypes.data))
+    if center is None:
+        _check(LIB.pcc_rigid_from_sums(sm.ctypes.data, T.ctypes.data))
+    else:
+        cc = np.ascontiguousarray(center, dtype=np.float64)
+        assert cc.shape == (3,)
+        _check(LIB.pcc_rigid_from_sums_about(sm.ctypes.data, cc.ctypes.data, T.ctypes.data))
     return T.reshape(4, 4)
 
 
@@ -438,7 +447,9 @@ class Index:
                                       C.byref(ncl)))
         return labels, ncl.value
 
-    def icp_step(self, src, want_corr: bool = True):
+    def icp_step(self, src, want_corr: bool = True, center=None):
+        """correspondences of `src` against the index + the 17 Umeyama sums; center: take the sums about this point
+        (every rank of a sharded loop the SAME one) -- needed for small clouds at large coordinates"""
         ptr, n, stride, mem = _points(src)
         sums = (C.c_double * 17)()
         if want_corr:
@@ -448,7 +459,12 @@ class Index:
             idx = d2 = None
             pi = pd = None
         st = self._before(src)
-        _check(LIB.pcc_icp_step(self._h, ptr, n, stride, mem, pi, pd, sums))
+        if center is None:
+            _check(LIB.pcc_icp_step(self._h, ptr, n, stride, mem, pi, pd, sums))
+        else:
+            cc = np.ascontiguousarray(center, dtype=np.float64)
+            assert cc.shape == (3,)
+            _check(LIB.pcc_icp_step_about(self._h, ptr, n, stride, mem, cc.ctypes.data, pi, pd, sums))
         self._after(st)
         return idx, d2, np.array(list(sums), dtype=np.float64)
 

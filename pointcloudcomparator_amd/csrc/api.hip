@@ -873,16 +873,27 @@ static int icp_reduce(pcc_index* ix, size_t n, double sums[17], const double* ce
     return PCC_OK;
 }
 
-int pcc_rigid_from_sums(const double sums[17], float T[16]) {
+int pcc_rigid_from_sums(const double sums[17], float T[16]) { return pcc_rigid_from_sums_about(sums, nullptr, T); }
+
+int pcc_rigid_from_sums_about(const double sums[17], const double center[3], float T[16]) {
     if (!sums || !T) { set_error("null argument"); return PCC_ERR_INVALID; }
-    if (rigid_from_sums(sums, T) != 0) { set_error("fewer than 3 correspondences"); return PCC_ERR_INVALID; }
+    if (rigid_from_sums(sums, T, center) != 0) { set_error("fewer than 3 correspondences"); return PCC_ERR_INVALID; }
     return PCC_OK;
 }
 
 int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int mem, int32_t* idx, float* d2,
                  double sums[17]) {
+    return pcc_icp_step_about(ix, src, n, stride, mem, nullptr, idx, d2, sums);
+}
+
+int pcc_icp_step_about(pcc_index* ix, const void* src, size_t n, size_t stride, int mem, const double center[3],
+                       int32_t* idx, float* d2, double sums[17]) {
     PCC_ENTER(ix);
     PCC_TRY(check_points(src, n, stride, mem));
+    if (center && !(std::isfinite(center[0]) && std::isfinite(center[1]) && std::isfinite(center[2]))) {
+        set_error("non-finite center");
+        return PCC_ERR_INVALID;
+    }
     if (!sums) { set_error("null sums"); return PCC_ERR_INVALID; }
     for (int k = 0; k < 17; ++k) sums[k] = 0;
     if (n == 0) return PCC_OK;
@@ -891,7 +902,15 @@ int pcc_icp_step(pcc_index* ix, const void* src, size_t n, size_t stride, int me
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, src, n, stride, mem));
     PCC_TRY(nn1_packed(ix, n));
-    PCC_TRY(icp_reduce(ix, n, sums));
+    const double* center_dev = nullptr;
+    if (center) {  // the sums are taken about it (device copy behind the ICP loop state)
+        PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + 3 * sizeof(double)));
+        double* cd = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
+        PCC_HIP(hipMemcpyAsync(cd, center, 3 * sizeof(double), hipMemcpyHostToDevice, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));  // (center is the caller's memory)
+        center_dev = cd;
+    }
+    PCC_TRY(icp_reduce(ix, n, sums, center_dev));
     ev_mark(ix, EV_CALL1);
     if (idx || d2) {
         int32_t* didx = idx;

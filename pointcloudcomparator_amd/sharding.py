@@ -69,6 +69,8 @@ def icp_align_sharded(step, transform, solve, src_shard, max_iter: int, dist=Non
 
     step(points) -> sums[17] (numpy float64; capi.Index.icp_step(points, want_corr=False)[2]),
     transform(T, points) -> points (capi.Index.transform), solve(sums) -> 4x4 (capi.rigid_from_sums).
+    For a cloud at large coordinates bind the SAME centre on every rank in both callables
+    (icp_step(..., center=c) and rigid_from_sums(sums, center=c)): sums about the origin cancel there.
     Returns (T_total 4x4 float32, iterations, mean squared distance of the last pass over ALL shards)."""
     import numpy as np
     import torch

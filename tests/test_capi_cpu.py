@@ -78,3 +78,34 @@ def test_product_never_imports_the_oracle():
     for f in (ROOT / "include").rglob("*"):
         if f.is_file():
             assert "orc_" not in f.read_text(), f
+
+
+def test_rigid_from_sums_about_a_centre():
+    """pcc_rigid_from_sums_about (host arithmetic, no GPU): a small cloud at geo-referenced coordinates, rotated by 2
+    degrees about its own centre.  Sums about the origin lose the rotation in cancellation (4e11 against 0.3), sums
+    about a point of the cloud give it back; the two agree for a cloud at the origin."""
+    from pointcloudcomparator_amd import capi
+    rng = np.random.default_rng(4)
+    local = rng.random((200, 3)) * 0.1
+    c_, s_ = np.cos(np.radians(2.0)), np.sin(np.radians(2.0))
+    R = np.array([[c_, -s_, 0], [s_, c_, 0], [0, 0, 1]])
+    t = np.array([0.01, -0.02, 0.005])
+
+    def sums_of(p, q, c):
+        P, Q = p - c, q - c
+        return np.concatenate([P.sum(0), Q.sum(0), (Q.T @ P).ravel(), [((p - q) ** 2).sum()], [len(p)]])
+
+    for offset in (np.zeros(3), np.array([1000.0, 100000.0, 100000.0])):
+        p = local + offset
+        q = (local - local.mean(0)) @ R.T + local.mean(0) + t + offset
+        ctr = p[0]
+        T = capi.rigid_from_sums(sums_of(p, q, ctr), center=ctr)
+        assert np.allclose(T[:3, :3], R, atol=2e-6)
+        moved = p @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64)
+        assert np.abs(moved - q).max() < (1e-6 if offset[1] == 0 else 2e-2)   # (the float translation resolves 0.008 out there)
+        T0 = capi.rigid_from_sums(sums_of(p, q, np.zeros(3)))
+        if offset[1] == 0:
+            assert np.allclose(T0, T, atol=1e-6)
+        else:
+            assert not np.allclose(T0[:3, :3], R, atol=2e-6)                  # the origin-centred sums lost it
+

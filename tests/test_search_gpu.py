@@ -232,6 +232,21 @@ def test_icp_align_far_from_the_origin(gpu):
         assert fit < 2 * ofit + 1e-6
 
 
+def test_icp_step_about_a_centre(gpu):
+    """pcc_icp_step_about / pcc_rigid_from_sums_about: the stepwise (sharded-loop) route with the sums taken about a
+    point of the cloud reproduces pcc_icp_align's first pass bit for bit at geo-referenced coordinates"""
+    rng = np.random.default_rng(6)
+    big = (np.array([1000.0, 100000.0, 100000.0]) + rng.random((3000, 3)) * 1.0).astype(np.float32)
+    src = (big[:1000] + np.float32(0.02)).astype(np.float32)
+    with capi.Index(big) as ix:
+        T1, _, it, _ = ix.icp_align(src, max_iter=1, fixed=True)
+        idx, d2, sums = ix.icp_step(src, center=src[0].astype(np.float64))
+        oi, od = oracle.nn1_exhaustive(big, src)
+        assert (idx == oi).all() and (_bits(d2) == _bits(od)).all() and sums[16] == 1000
+        Ts = capi.rigid_from_sums(sums, center=src[0].astype(np.float64))
+    assert it == 1 and (np.asarray(T1, np.float32).view(np.uint32) == Ts.view(np.uint32)).all()
+
+
 def test_match_knn_mirrors_reference_quirks(gpu):
     rng = np.random.default_rng(2)
     des1 = np.zeros((600, 32), np.float32)     # RIFT32 = pcl::Histogram<32>, 128-byte stride
