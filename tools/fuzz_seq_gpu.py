@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-refs", type=int, default=40000)
     ap.add_argument("--trace", default=None)
+    ap.add_argument("--no-icp-align", action="store_true",
+                    help="run whole ICP loops but do not compare them with the oracle's (the comparison is statistical: "
+                         "two solvers on noisy data; the GPU suite's short leg wants none of that)")
     args = ap.parse_args()
     import torch
     out = ROOT / "gpurun_out" / "fuzz"
@@ -129,7 +132,7 @@ def main():
                     # their neighbours (far-off starts are chaotic -- the float Umeyama and the double Horn part ways)
                     ext = float(np.linalg.norm(a[:, :3].max(0) - a[:, :3].min(0)))
                     close = float(np.mean(np.sum((P - Q) ** 2, axis=1))) < (0.05 * ext) ** 2
-                    if close and sv[0] > 0 and sv[1] > 1e-3 * sv[0] and sv[2] > 1e-6 * sv[0]:   # (full rank: the oracle's Umeyama restatement is not reliable on planar correspondences)
+                    if not args.no_icp_align and close and sv[0] > 0 and sv[1] > 1e-3 * sv[0] and sv[2] > 1e-6 * sv[0]:   # (full rank: the oracle's Umeyama restatement is not reliable on planar correspondences)
                         oT, ofit, oit, _, _ = oracle.icp(q, a, max_iter=it_max, fixed=fixed)
                         scale = max(1.0, float(np.abs(a).max()))
                         fit_ok = abs(fit - ofit) <= 2e-3 * max(abs(ofit), 1e-30) + 1e-10 * scale * scale
