@@ -119,6 +119,28 @@ int pcc_index_set_engine(pcc_index *index, int engine);
 
 int pcc_index_set_tie_order(pcc_index *index, int ties);
 
+/* Tuning knobs of one handle.  None of them changes a result bit (every mode is exact); they select between
+ * implementations that the tests compare with each other and that measurements are taken with.  The PCC_*
+ * environment variables of the same names give the DEFAULTS a new handle starts with; the library does not read
+ * the environment anywhere else.  Options that shape the index (GRID_PPC, GRID_TRIM, GRID_OCCUPANCY, SORT_MP_MIN)
+ * take effect at the next pcc_index_set_input.  (The reference has no such surface -- PCL's KdTreeFLANN exposes
+ * only setEpsilon / setSortedResults, src/comparator.cpp:564 uses neither.) */
+enum pcc_option {
+    PCC_OPT_GRID_PPC = 1,        /* mean references per cell the grid aims for (default 0.5) */
+    PCC_OPT_GRID_TRIM = 2,       /* k of the trimmed bounding box the grid is laid over (default 3; 0 = plain box) */
+    PCC_OPT_FAR_MODE = 3,        /* queries the cell walk leaves: -1 auto, 0 exhaustive kernel, 1 seed scan + ball walk */
+    PCC_OPT_ICP_WARM = 4,        /* pcc_icp_align: passes start from the previous pass's neighbours (default 1) */
+    PCC_OPT_ICP_DEVICE_LOOP = 5, /* pcc_icp_align: loop resident on the device (default 1; 0 = host-driven, same bits) */
+    PCC_OPT_EC_CELLS = 6,        /* clustering over the clique-cell grid (default 1; 0 = per-point ball scan) */
+    PCC_OPT_SORT_MP_MIN = 7,     /* reference clouds from this size take the three-level cell sort */
+    PCC_OPT_SORT_MP_MIN_Q = 8,   /* the same for query clouds */
+    PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query, 1 dense rows drained with lanes over candidates */
+    PCC_OPT_GRID_OCCUPANCY = 10, /* cell edge from the occupied-cell statistics instead of the bounding-box volume (default 1) */
+    PCC_OPT_FLANN_SPLIT = 11     /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
+};
+int pcc_index_set_option(pcc_index *index, int option, double value);
+int pcc_index_get_option(pcc_index *index, int option, double *value);
+
 /* ---- k = 1 nearest neighbour ------------------------------------------------
  * replaces: N calls of KdTreeFLANN::nearestKSearch(pt, 1, idx, d2)
  *           (src/comparator.cpp:571-577; ICP determineCorrespondences and

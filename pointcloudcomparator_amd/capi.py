@@ -16,6 +16,9 @@ MEM_HOST, MEM_DEVICE = 0, 1
 TIES_LOWEST_INDEX, TIES_FLANN = 0, 1
 ENGINE_AUTO, ENGINE_BRUTE, ENGINE_GRID = 0, 1, 2
 KNN_MAX_K = 65536
+# enum pcc_option
+(OPT_GRID_PPC, OPT_GRID_TRIM, OPT_FAR_MODE, OPT_ICP_WARM, OPT_ICP_DEVICE_LOOP, OPT_EC_CELLS, OPT_SORT_MP_MIN,
+ OPT_SORT_MP_MIN_Q, OPT_NN1_KERNEL, OPT_GRID_OCCUPANCY, OPT_FLANN_SPLIT) = range(1, 12)
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PCC_LIB", _HERE / "lib" / "libpcc_nn.so"))
@@ -32,6 +35,7 @@ SYMBOLS = [
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
     "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
+    "pcc_index_set_option", "pcc_index_get_option",
 ]
 
 
@@ -74,6 +78,8 @@ def _load() -> C.CDLL:
     lib.pcc_index_sync.argtypes = [vp]
     lib.pcc_index_set_tie_order.argtypes = [vp, i32]
     lib.pcc_index_clone_to_device.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.pcc_index_set_option.argtypes = [vp, i32, C.c_double]
+    lib.pcc_index_get_option.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.pcc_index_wait_stream.argtypes = [vp, vp]
     lib.pcc_stream_wait_index.argtypes = [vp, vp]
     lib.pcc_index_engine.argtypes = [vp, C.POINTER(i32)]
@@ -220,9 +226,21 @@ class Index:
         """pcl::KdTreeFLANN::setInputCloud on an existing object: rebuild over a new cloud,
         reusing the device allocations."""
         ptr, n, stride, mem = _points(points)
-        self._before(points)
+        st = self._before(points)
         _check(LIB.pcc_index_set_input(self._h, ptr, n, stride, 3, mem))
+        # the pack kernel reads the caller's tensor on the library's stream after this returns: torch work issued
+        # from here on (an overwrite, the allocator reusing the block) waits for it
+        self._after(st)
         self.n_original = n
+
+    def set_option(self, option: int, value: float):
+        """pcc_index_set_option (OPT_*): implementation choices of this handle; no result bit depends on them"""
+        _check(LIB.pcc_index_set_option(self._h, option, float(value)))
+
+    def get_option(self, option: int) -> float:
+        v = C.c_double(0)
+        _check(LIB.pcc_index_get_option(self._h, option, C.byref(v)))
+        return v.value
 
     def enable_timing(self, level=2):
         """0/False off, 1 main kernel only (cheap enough for a timed region), 2/True full breakdown"""

@@ -23,6 +23,22 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+void Options::from_env() {
+    auto num = [](const char* name, double dflt) { const char* v = getenv(name); return v && *v ? atof(v) : dflt; };
+    grid_ppc = num("PCC_GRID_PPC", grid_ppc);
+    if (!(grid_ppc > 0)) grid_ppc = 0.5;
+    grid_trim = (int)num("PCC_GRID_TRIM", grid_trim);
+    far_mode = (int)num("PCC_GRID_FAR", far_mode);
+    icp_warm = (int)num("PCC_ICP_WARM", icp_warm);
+    icp_device_loop = (int)num("PCC_ICP_DEVICE_LOOP", icp_device_loop);
+    ec_cells = (int)num("PCC_EC_CELLS", ec_cells);
+    sort_mp_min = num("PCC_SORT_MP_MIN", sort_mp_min);
+    sort_mp_min_q = num("PCC_SORT_MP_MIN_Q", sort_mp_min_q);
+    nn1_kernel = (int)num("PCC_NN1_KERNEL", nn1_kernel);
+    grid_occupancy = (int)num("PCC_GRID_OCCUPANCY", grid_occupancy);
+    flann_split = (int)num("PCC_FLANN_SPLIT", flann_split);
+}
+
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap && p) return PCC_OK;
     if (bytes == 0) bytes = 256;
@@ -282,6 +298,7 @@ int pcc_index_destroy(pcc_index* ix) {
 static int new_handle(int device, int engine, pcc_index** out) {
     pcc_index* ix = new pcc_index();
     ix->device = device;
+    ix->opt.from_env();
     DeviceGuard g(device);
     int st = PCC_OK;
     auto fail = [&](int s) { pcc_index_destroy(ix); return s; };
@@ -465,6 +482,53 @@ int pcc_index_set_tie_order(pcc_index* ix, int ties) {
     PCC_ENTER(ix);
     if (ties != PCC_TIES_LOWEST_INDEX && ties != PCC_TIES_FLANN) { set_error("bad tie order %d", ties); return PCC_ERR_INVALID; }
     ix->tie_mode = ties;
+    return PCC_OK;
+}
+static double* option_slot(pcc_index* ix, int option, int** as_int) {
+    *as_int = nullptr;
+    Options& o = ix->opt;
+    switch (option) {
+        case PCC_OPT_GRID_PPC: return &o.grid_ppc;
+        case PCC_OPT_SORT_MP_MIN: return &o.sort_mp_min;
+        case PCC_OPT_SORT_MP_MIN_Q: return &o.sort_mp_min_q;
+        case PCC_OPT_GRID_TRIM: *as_int = &o.grid_trim; return nullptr;
+        case PCC_OPT_FAR_MODE: *as_int = &o.far_mode; return nullptr;
+        case PCC_OPT_ICP_WARM: *as_int = &o.icp_warm; return nullptr;
+        case PCC_OPT_ICP_DEVICE_LOOP: *as_int = &o.icp_device_loop; return nullptr;
+        case PCC_OPT_EC_CELLS: *as_int = &o.ec_cells; return nullptr;
+        case PCC_OPT_NN1_KERNEL: *as_int = &o.nn1_kernel; return nullptr;
+        case PCC_OPT_GRID_OCCUPANCY: *as_int = &o.grid_occupancy; return nullptr;
+        case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
+        default: return nullptr;
+    }
+}
+int pcc_index_set_option(pcc_index* ix, int option, double value) {
+    PCC_ENTER(ix);
+    int* pi = nullptr;
+    double* pd = option_slot(ix, option, &pi);
+    if (!pd && !pi) { set_error("unknown option %d", option); return PCC_ERR_INVALID; }
+    if (!std::isfinite(value)) { set_error("option %d: non-finite value", option); return PCC_ERR_INVALID; }
+    bool ok = true;
+    switch (option) {
+        case PCC_OPT_GRID_PPC: ok = value > 0 && value <= 1024; break;
+        case PCC_OPT_GRID_TRIM: ok = value >= 0 && value <= 8; break;
+        case PCC_OPT_FAR_MODE: ok = value >= -1 && value <= 1; break;
+        case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
+        case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 7; break;  // (2, 3: other batch sizes of the flat drain -- measurements)
+        default: ok = value == 0 || value == 1; break;
+    }
+    if (!ok) { set_error("option %d: value %g out of range", option, value); return PCC_ERR_INVALID; }
+    if (pd) *pd = value; else *pi = (int)value;
+    if (option == PCC_OPT_FLANN_SPLIT) ix->flann_valid = false;  // the replayed tree has to be rebuilt with the other rule
+    return PCC_OK;
+}
+int pcc_index_get_option(pcc_index* ix, int option, double* value) {
+    PCC_ENTER(ix);
+    if (!value) { set_error("null value"); return PCC_ERR_INVALID; }
+    int* pi = nullptr;
+    double* pd = option_slot(ix, option, &pi);
+    if (!pd && !pi) { set_error("unknown option %d", option); return PCC_ERR_INVALID; }
+    *value = pd ? *pd : (double)*pi;
     return PCC_OK;
 }
 int pcc_index_stats(const pcc_index* cix, uint64_t stats[8]) {
@@ -978,8 +1042,8 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + 3 * sizeof(double)));
     double* center_dev = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
     PCC_TRY(launch_icp_center(ix->stream, ix->q_packed.as<float4>(), n, center_dev));
-    static const int warm_env = getenv("PCC_ICP_WARM") ? atoi(getenv("PCC_ICP_WARM")) : 1;  // 0: every pass from scratch (measurements)
-    static const int loop_env = getenv("PCC_ICP_DEVICE_LOOP") ? atoi(getenv("PCC_ICP_DEVICE_LOOP")) : 1;  // 0: the host-driven loop (kept for comparison: same bits)
+    const int warm_env = ix->opt.icp_warm;         // 0: every pass from scratch (measurements)
+    const int loop_env = ix->opt.icp_device_loop;  // 0: the host-driven loop (kept for comparison: same bits)
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
         pcc_index* ix;
         explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }

@@ -187,8 +187,7 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     // clouds past the L2s: three coalesced levels with the payload carried along (cellsort_mp.hip)
     // measured crossovers (MI355X, corridor scene; us, this file vs cellsort_mp): reference clouds 1M 106 / 138,
     // 2M 176 / 152, 4M 322 / 214, 10M 779 / 495; query clouds (order only) 2M 85 / 103, 4M 136 / 133, 10M 340 / 262
-    static const size_t mp_min = getenv("PCC_SORT_MP_MIN") ? (size_t)atof(getenv("PCC_SORT_MP_MIN")) : (size_t)1500000;
-    static const size_t mp_min_q = getenv("PCC_SORT_MP_MIN_Q") ? (size_t)atof(getenv("PCC_SORT_MP_MIN_Q")) : (size_t)5000000;
+    const size_t mp_min = (size_t)ix->opt.sort_mp_min, mp_min_q = (size_t)ix->opt.sort_mp_min_q;
     if (n_pts >= (refs ? mp_min : mp_min_q)) return cell_sort_mp(ix, pts, n_pts, refs, out_pts, out_order, cell_start, n_sorted_dev, gd_override, nc_cap_override);
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)n_pts;

@@ -183,7 +183,7 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
     // (built first: the cell sort uses the scratch buffers the union-find arrays live in afterwards)
     // clustering grid: cell edge 0.57 r (diagonal 0.987 r < r), over the bounding box of the valid points
     bool cells_ok = false;
-    static const bool no_cells = getenv("PCC_EC_CELLS") && atoi(getenv("PCC_EC_CELLS")) == 0;
+    const bool no_cells = ix->opt.ec_cells == 0;
     if (!no_cells && r > 0.f && n >= 4096) {
         PCC_TRY(sync_info(ix));
         GridDev hd;

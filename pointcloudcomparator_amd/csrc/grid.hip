@@ -16,9 +16,11 @@
 // as nn1_brute.hip (-ffp-contract=off), so both engines return identical bits.
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
+#include "lane_ops.hpp"
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <type_traits>
 
 namespace pcc {
 
@@ -26,9 +28,8 @@ constexpr float GRID_TARGET_PPC = 0.5f; // mean points per cell (over the boundi
                                          // measured optimum on the corridor scene at 1M and 10M points
 constexpr unsigned int GRID_MAX_CELLS = 1u << 26;
 
-unsigned int grid_nc_cap(size_t n) {
+unsigned int grid_nc_cap(size_t n, double ppc) {
     // cells the grid may use: twice the target (thin clouds round up a lot per dimension)
-    static const double ppc = (getenv("PCC_GRID_PPC") && atof(getenv("PCC_GRID_PPC")) > 0) ? atof(getenv("PCC_GRID_PPC")) : GRID_TARGET_PPC;
     double c = 2.0 * (double)n / ppc + 4096.0;
     if (c > (double)GRID_MAX_CELLS) c = (double)GRID_MAX_CELLS;
     return (unsigned int)c;
@@ -186,10 +187,10 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
 }
 
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
-    static const float ppc = (getenv("PCC_GRID_PPC") && atof(getenv("PCC_GRID_PPC")) > 0) ? (float)atof(getenv("PCC_GRID_PPC")) : GRID_TARGET_PPC;
-    static const int trim = getenv("PCC_GRID_TRIM") ? atoi(getenv("PCC_GRID_TRIM")) : 3;
+    const float ppc = (float)ix->opt.grid_ppc;
+    const int trim = ix->opt.grid_trim;
     PCC_TRY(ix->d_grid.reserve(sizeof(GridDev)));
-    ix->nc_cap = grid_nc_cap(ix->n_orig);
+    ix->nc_cap = grid_nc_cap(ix->n_orig, ix->opt.grid_ppc);
     // (trimming needs enough rows to tell an outlier from the scene: 128 pack workgroups = 64k points)
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1024), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
                        ppc, ix->nc_cap, n_blocks >= 128 ? trim : 0, ix->d_grid.as<GridDev>(), ix->h_grid);
@@ -526,6 +527,245 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
+// ---- k_grid_nn1_flat: the rows drained with lanes over CANDIDATES -------------------------------------------
+// k_grid_nn1 gives every query a lane, and a wave's walk over a row of cells lasts as long as the LONGEST of its 64
+// spans: 20 of 64 lanes active per VALU instruction at 10M x 10M (profiles/r02_nn1_counters.json) -- a row of three
+// cells holds 1.5 references on average in sparse regions, and in dense ones the rows are clipped to the ball of the
+// best distance, so most lanes skip most rows while the wave still walks all nine at full length.
+// Here the rows of a pass (own row / the four face rows / the four diagonal rows -- the same rows, bounds, clipping and
+// slack as k_grid_nn1, so the candidate set and every result bit are the same) are DRAINED FLAT: the lanes' spans are
+// laid end to end in (row, lane) order and the wave takes the candidates 64 at a time across span boundaries.
+// Consecutive lanes read consecutive cell_refs entries (neighbouring lanes' spans overlap or adjoin: few lines per
+// load), fetch their query from LDS and fold (d2 bits, index) into the query's LDS slot with one ds_min_u64 -- order
+// free, hence exact.  Which span a candidate belongs to: one bit per span END over the flat index space; the rank of a
+// candidate's span = ends before it = ends of earlier windows (a scalar count) + v_mbcnt of its window's bits.  The bits
+// are stored TRANSPOSED -- word (p mod 64) of plane (p / 2048) holds flat position p at bit (p / 64) mod 32 -- so the
+// ends of one row, which are a few positions apart, go to different words (the atomic ORs that set them do not collide),
+// lane l's word serves 32 consecutive windows, and a window's mask is a ballot of one bit test.
+constexpr int FLAT_PLANES = 4;
+constexpr int FLAT_CAP = FLAT_PLANES * 2048;  // candidates one flat pass can hold; larger passes fall back to the lane walk
+struct alignas(16) FlatWave {
+    float4 q[64];                        // the wave's queries (x, y, z, bits of the best d2 when the pass began)
+    unsigned long long best[64];         // running (d2 bits << 32 | index) per query
+    unsigned int ends[FLAT_PLANES][64];  // span-end bits, transposed (above)
+    uint2 span[4 * 64];                  // non-empty spans in flat order: (first reference - flat offset, query slot)
+};
+static_assert(sizeof(FlatWave) == 1024 + 512 + FLAT_PLANES * 256 + 2048, "LDS budget of k_grid_nn1_flat");
+
+__device__ __forceinline__ void flat_sync() {
+    // one wave, its own LDS block: DS operations of a wave execute in issue order, the compiler must keep that order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one pass over R rows: lane-local spans [s[r], s[r] + len[r]) of cell_refs, results folded into fw.best
+template <int R, int U, int B, bool LIVE>
+__device__ __forceinline__ void flat_pass(FlatWave& fw, const float4* __restrict__ cell_refs, const unsigned int (&s)[R],
+                                          const unsigned int (&len)[R], float qx, float qy, float qz, unsigned int lane) {
+    static_assert(B == 1 || B == 2 || B == 4 || B == 8, "a batch of windows never straddles a plane of 32");
+    unsigned int off[R];
+    unsigned int T = 0;  // wave-uniform
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int incl = wave_incl_scan_add(len[r]);
+        off[r] = T + incl - len[r];
+        T += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (T == 0) return;
+    if (T > (unsigned int)FLAT_CAP) {  // (piles of duplicates, very coarse grids: rare) the lane walk of k_grid_nn1
+        unsigned long long b = ~0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) b = scan_span<U>(cell_refs, s[r], s[r] + len[r], qx, qy, qz, b);
+        if (b < fw.best[lane]) fw.best[lane] = b;  // (only this lane touches its slot outside a flat drain)
+        flat_sync();
+        return;
+    }
+    const unsigned int nwin = (T + 63) >> 6;
+#pragma unroll
+    for (int p = 0; p < FLAT_PLANES; ++p)
+        if ((unsigned int)p * 2048u < T) fw.ends[p][lane] = 0u;
+    flat_sync();
+    unsigned int nspan = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long occ = __ballot(len[r] != 0);
+        if (len[r]) {
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(occ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)occ, nspan));
+            fw.span[rank] = make_uint2(s[r] - off[r], lane);
+            const unsigned int e = off[r] + len[r] - 1;  // last flat position of the span
+            if (e + 1 < T) atomicOr(&fw.ends[e >> 11][e & 63], 1u << ((e >> 6) & 31));
+        }
+        nspan += (unsigned int)__popcll(occ);
+    }
+    flat_sync();
+    // Windows are taken B at a time: B span records, B reference loads in flight before the first distance is formed
+    // (one window at a time left every wave waiting on a single load).  In the last batch, lanes past the end re-read
+    // the last candidate (a valid address) and are masked at the fold.
+    const unsigned int last_span = nspan - 1;
+    unsigned int before = 0;  // span ends in earlier windows (scalar)
+    unsigned int word = 0;
+    auto batch = [&](unsigned int w0, auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        uint2 rec[B];
+        bool ok[B];
+        unsigned int cc[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const unsigned int w = w0 + b;
+            const unsigned long long m = __ballot(((word >> (w & 31)) & 1u) != 0u);
+            unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
+            before += (unsigned int)__popcll(m);
+            cc[b] = (w << 6) + lane;
+            ok[b] = true;
+            if (TAIL) {
+                ok[b] = cc[b] < T;
+                cc[b] = ok[b] ? cc[b] : T - 1;
+                rank = ok[b] ? rank : last_span;
+            }
+            rec[b] = fw.span[rank];
+        }
+        float4 r4[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) r4[b] = cell_refs[rec[b].x + cc[b]];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const float4 qv = fw.q[rec[b].y];
+            const float d = dist2(qv.x, qv.y, qv.z, r4[b]);
+            const unsigned int db = __float_as_uint(d);
+            // most candidates do not beat what the query already has: look before the (serialising) atomic.  The own
+            // row has no bound yet: there the look goes to the live slot.
+            const unsigned int cur = LIVE ? reinterpret_cast<const unsigned int*>(&fw.best[rec[b].y])[1] : __float_as_uint(qv.w);
+            // (the test on the index is always true -- an index is never ~0 -- and keeps the candidate ONE 16-byte load:
+            // with w needed only behind the branch the compiler fetches it there, in a second dependent load)
+            const unsigned int ri = (unsigned int)__float_as_int(r4[b].w);
+            if (ok[b] && db <= cur && ri != 0xffffffffu) atomicMin(&fw.best[rec[b].y], ((unsigned long long)db << 32) | ri);
+        }
+    };
+    const unsigned int nfull = (T >> 6) / B * B;  // windows in batches that lie entirely below T
+    for (unsigned int p0 = 0; p0 < nwin; p0 += 32) {  // one plane of end bits = 32 windows
+        word = fw.ends[p0 >> 5][lane];
+        const unsigned int pend = min(p0 + 32u, nwin);
+        unsigned int w0 = p0;
+        for (; w0 + B <= min(pend, nfull); w0 += B) batch(w0, std::false_type{});
+        for (; w0 < pend; w0 += B) batch(w0, std::true_type{});
+    }
+    flat_sync();
+}
+
+template <int U, int B, int NW = 4, int WPE = 0, bool NOFIN = false>
+__global__ void __launch_bounds__(NW * 64)
+#if defined(__HIP_DEVICE_COMPILE__)
+__attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, WPE > 0 ? WPE : 8)))
+#endif
+k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+                const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+                const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
+                unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
+                unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk,
+                const float4* __restrict__ warm_refs) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    unsigned int bid = blockIdx.x;  // XCD-aware order of the workgroups, as in k_grid_nn1
+    if (xcd_run > 1) {
+        const unsigned int per = 8u * xcd_run, full = (gridDim.x / per) * per;
+        if (bid < full) {
+            const unsigned int base = bid / per * per, in = bid - base;
+            bid = base + (in & 7u) * xcd_run + (in >> 3);
+        }
+    }
+    // phase 1 works in the waves' FlatWave blocks; afterwards the same memory holds the packed open lanes
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NW * sizeof(FlatWave)];
+    __shared__ unsigned int open_count;
+    static_assert(sizeof(FlatWave) >= 64 * (sizeof(float4) + sizeof(unsigned long long)), "open-lane list fits");
+    FlatWave& fw = reinterpret_cast<FlatWave*>(lds_raw)[threadIdx.x >> 6];
+    float4* open_q = reinterpret_cast<float4*>(lds_raw);
+    unsigned long long* open_best = reinterpret_cast<unsigned long long*>(lds_raw + NW * 64 * sizeof(float4));
+    if (threadIdx.x == 0) open_count = 0;
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int t = bid * blockDim.x + threadIdx.x;
+    const unsigned int ns = n_sorted_ptr ? *n_sorted_ptr : n;
+    unsigned int qi = 0;
+    float4 qv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (t < ns) { qi = order ? order[t] : t; qv = q[qi]; }
+    const bool active = __float_as_int(qv.w) >= 0;
+    float qx = qv.x, qy = qv.y, qz = qv.z;
+    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    fw.q[lane] = make_float4(qx, qy, qz, __uint_as_float(0xffffffffu));
+    fw.best[lane] = ~0ull;
+    flat_sync();
+    unsigned long long best = ~0ull;
+    bool resolved = false;
+    {
+        const int x0 = max(cx - 1, 0);
+        const bool shifted = cx == 0;
+        const bool has_right = cx + 1 < g.dim[0];
+        // the clipped span of row i (0..8: z = cz + i / 3 - 1, y = cy + i % 3 - 1) against the best squared distance bd
+        // -- the same four-bound gather, the same gap tests and slack as k_grid_nn1's phase 1
+        const float fx = g.org[0] + cx * g.h, fy = g.org[1] + cy * g.h, fz = g.org[2] + cz * g.h;
+        const float gxl = fmaxf((qx - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - qx) - slack, 0.f);
+        const float gyl = fmaxf((qy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - qy) - slack, 0.f);
+        const float gzl = fmaxf((qz - fz) - slack, 0.f), gzr = fmaxf(((fz + g.h) - qz) - slack, 0.f);
+        const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
+        const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
+        const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
+        auto row_span = [&](int i, float bd, unsigned int& s0, unsigned int& ln) {
+            s0 = 0u; ln = 0u;
+            const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
+            const float rem = bd - (gy2[i % 3] + gz2[i / 3]);  // (NaN while nothing is found: keeps the row whole)
+            if (!active || rem < 0.f || z < 0 || z >= g.dim[2] || y < 0 || y >= g.dim[1]) return;
+            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+            const uint4 b4 = *reinterpret_cast<const uint4*>(cell_start + row + x0);
+            const unsigned int L = b4.x, A = shifted ? b4.x : b4.y, Bc = shifted ? b4.y : b4.z;
+            const unsigned int r3 = shifted ? b4.z : b4.w, Rr = has_right ? r3 : Bc;
+            s0 = gxl2 > rem ? A : L;
+            const unsigned int e0 = gxr2 > rem ? Bc : Rr;
+            ln = e0 - s0;
+        };
+        {   // own row, whole
+            unsigned int s1[1], l1[1];
+            row_span(4, __uint_as_float(0xffffffffu), s1[0], l1[0]);
+            flat_pass<1, U, B, true>(fw, cell_refs, s1, l1, qx, qy, qz, lane);
+        }
+        constexpr int pass_rows[2][4] = {{3, 5, 1, 7}, {0, 2, 6, 8}};  // face neighbours, then the diagonal rows
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float bd = __uint_as_float((unsigned int)(fw.best[lane] >> 32));
+            fw.q[lane].w = bd;  // the flat drain's pre-filter (read with the query, no extra LDS access)
+            unsigned int s4[4], l4[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) row_span(pass_rows[p][o], bd, s4[o], l4[o]);
+            flat_pass<4, U, B, false>(fw, cell_refs, s4, l4, qx, qy, qz, lane);
+        }
+        best = fw.best[lane];
+        if (active) {
+            const int x1 = min(cx + 1, g.dim[0] - 1);
+            const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
+            const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
+            const float bd = __uint_as_float((unsigned int)(best >> 32));
+            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+            if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
+        }
+    }
+    __syncthreads();  // every wave is done with its FlatWave block: the open-lane list may overwrite them
+    if (active && resolved) out[qi] = best;
+    if (active && !resolved) {
+        const unsigned int slot = atomicAdd(&open_count, 1u);
+        open_q[slot] = make_float4(qx, qy, qz, __uint_as_float(qi));
+        open_best[slot] = best;
+    }
+    __syncthreads();
+    const unsigned int n_open = open_count;
+    for (unsigned int j = threadIdx.x; j < n_open; j += blockDim.x) {
+        const float4 oq = open_q[j];
+        if (NOFIN) { out[__float_as_uint(oq.w)] = open_best[j]; continue; }
+        nn1_finish<2>(cell_refs, cell_start, g, slack, oq.x, oq.y, oq.z, __float_as_uint(oq.w), open_best[j], out, fb_list,
+                      fb_count, ball_walk, warm_refs);
+    }
+}
+
 // ---- far queries -------------------------------------------------------------------------------
 // A query whose neighbourhood is empty for KMAX cells, or whose nearest point lies further than
 // KMAX cells (a source cloud that is still misaligned in ICP, points outside the reference's
@@ -660,9 +900,24 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us)
     const bool ball_walk = !ix->keep_order;
     const bool warm = ix->warm_start && ix->keep_order;  // out[] holds the previous pass's keys of the SAME queries (pcc_icp_align)
-    hipLaunchKernelGGL(k_grid_nn1<4>, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
-                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
-                       fb_count, xcd_run, ball_walk, warm ? ix->refs.as<float4>() : nullptr);
+#define PCC_LAUNCH_FLAT(BB, NW, WPE) hipLaunchKernelGGL((k_grid_nn1_flat<4, BB, NW, WPE>), dim3((n + NW * 64 - 1) / (NW * 64)), dim3(NW * 64), 0, s, ix->cell_refs.as<float4>(), \
+                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, \
+                           fb_count, xcd_run * 4 / NW, ball_walk, warm ? ix->refs.as<float4>() : nullptr)
+    switch (ix->opt.nn1_kernel) {
+        case 1: PCC_LAUNCH_FLAT(4, 2, 0); break;
+        case 2: PCC_LAUNCH_FLAT(4, 4, 8); break;
+        case 3: PCC_LAUNCH_FLAT(2, 4, 8); break;
+        case 4: PCC_LAUNCH_FLAT(4, 4, 0); break;
+        case 5: PCC_LAUNCH_FLAT(4, 2, 8); break;
+        case 6: PCC_LAUNCH_FLAT(2, 2, 8); break;
+        case 7: hipLaunchKernelGGL((k_grid_nn1_flat<4, 4, 2, 0, true>), dim3((n + 127) / 128), dim3(128), 0, s, ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr); break;
+        default: break;
+    }
+#undef PCC_LAUNCH_FLAT
+    if (ix->opt.nn1_kernel == 0)
+        hipLaunchKernelGGL(k_grid_nn1<4>, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
+                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
+                           fb_count, xcd_run, ball_walk, warm ? ix->refs.as<float4>() : nullptr);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     // queries the cell walk could not resolve.  When an earlier search on this index had such
@@ -672,7 +927,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     ev_mark(ix, EV_FB0);
     const unsigned int seen = static_cast<volatile unsigned int*>(ix->pinned)[40];
     if (seen > ix->last_fallback_seen) ix->last_fallback_seen = seen;
-    static const int far_mode = getenv("PCC_GRID_FAR") ? atoi(getenv("PCC_GRID_FAR")) : -1;  // -1 auto, 0 off, 1 on
+    const int far_mode = ix->opt.far_mode;  // -1 auto, 0 off, 1 on
     // (ICP passes always take it: their loop may be enqueued as a whole before the first count comes back)
     const bool far = far_mode == 1 || (far_mode == -1 && (ix->last_fallback_seen >= 64 || ix->keep_order));
     if (far) {

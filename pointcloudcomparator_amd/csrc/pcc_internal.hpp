@@ -73,6 +73,23 @@ struct GridDev {
     unsigned int voxel;     // 1: cells are PCL VoxelGrid voxels -- id from floor(v*inv_h) - org (org = float(min_b))
 };
 
+// Tuning knobs of one handle (pcc_index_set_option).  The PCC_* environment variables only supply the defaults a new
+// handle starts with; nothing in the library reads the environment after that.
+struct Options {
+    double grid_ppc = 0.5;          // PCC_OPT_GRID_PPC: mean references per cell the grid aims for (measured optimum on the corridor scene)
+    int grid_trim = 3;              // PCC_OPT_GRID_TRIM: k of the trimmed bounding box (0: plain bounding box)
+    int far_mode = -1;              // PCC_OPT_FAR_MODE: -1 auto, 0 exhaustive fallback only, 1 always seed scan + ball walk
+    int icp_warm = 1;               // PCC_OPT_ICP_WARM: ICP passes start from the previous pass's neighbours
+    int icp_device_loop = 1;        // PCC_OPT_ICP_DEVICE_LOOP: 0 = the host-driven loop (same bits)
+    int ec_cells = 1;               // PCC_OPT_EC_CELLS: clustering on the clique-cell grid (0: per-point ball scan)
+    double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
+    double sort_mp_min_q = 5e6;     // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds
+    int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 dense rows drained flat, lanes over candidates
+    int grid_occupancy = 1;         // PCC_OPT_GRID_OCCUPANCY: cell size from the occupied-cell statistics (0: bounding-box volume)
+    int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
+    void from_env();
+};
+
 }  // namespace pcc
 
 #define PCC_EV_SLOTS 64
@@ -80,6 +97,7 @@ struct GridDev {
 // The opaque handle of the C-ABI.
 struct pcc_index {
     std::mutex mu;                     // every entry point holds it: calls on ONE handle from several threads are serialised
+    pcc::Options opt;                  // pcc_index_set_option
     int device = 0;
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // library-owned stream
@@ -200,7 +218,7 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks);  // async: d_grid + pinned mirror
 int grid_build(pcc_index* ix);                                             // async: cell sort of the references
 int sync_info(pcc_index* ix);                                              // wait for the pinned mirror, refresh host fields
-unsigned int grid_nc_cap(size_t n);
+unsigned int grid_nc_cap(size_t n, double ppc);
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out);
 // sort queries by reference-grid cell: order[0..*n_sorted) (device) lists the valid queries
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,

@@ -124,20 +124,25 @@ def test_device_memory_path(gpu):
     assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
 
 
-def test_far_queries_take_the_seed_and_ball_route(gpu, monkeypatch):
-    """queries far outside the reference cloud (misaligned ICP source): seed scan + ball walk,
-    bit-identical to the oracle, with and without the route forced on"""
+def test_far_queries_take_the_seed_and_ball_route(gpu):
+    """queries far outside the reference cloud (misaligned ICP source): seed scan + ball walk (PCC_OPT_FAR_MODE 1),
+    the exhaustive fallback alone (0) and the heuristic (-1) -- all bit-identical to the oracle, and the counters show
+    that the modes really took different routes"""
     a = synth.corridor_cloud(60000, synth.SEED_A)
     b = synth.corridor_cloud(6000, synth.SEED_B)
     b[:2000] += np.float32([1.5, -2.0, 0.7])
     b[2000:3000] += np.float32(30.0)
     oi, od = oracle.nn1_exhaustive(a, b)
-    for mode in ("1", "-1", "0"):
-        monkeypatch.setenv("PCC_GRID_FAR", mode)  # read once per process: first value wins, the rest re-check
+    left = {}
+    for mode in (1, -1, 0):
         with capi.Index(a, engine=capi.ENGINE_GRID) as ix:
+            ix.set_option(capi.OPT_FAR_MODE, mode)
+            assert ix.get_option(capi.OPT_FAR_MODE) == mode
             for _ in range(2):  # second call: the heuristic has seen the first call's fallbacks
                 idx, d2 = ix.nn1(b)
                 assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+            left[mode] = ix.stats()[1]  # queries the cell walk did not resolve
+    assert left[0] == left[1] == left[-1] > 0
 
 
 # ---- PCC_TIES_FLANN: among equally near references, the one pcl::KdTreeFLANN's tree walk reaches first ---------------

@@ -203,6 +203,33 @@ def test_icp_align_criteria_run_on_the_device(gpu):
         assert not conv and it == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))
 
 
+@pytest.mark.parametrize("fixed", [False, True])
+def test_icp_align_options_do_not_change_a_bit(gpu, fixed):
+    """PCC_OPT_ICP_WARM = 0 (every pass searches from scratch) and PCC_OPT_ICP_DEVICE_LOOP = 0 (the host drives the loop,
+    reduces the sums and solves the transform) are other routes to the same numbers: transform, fitness, iteration count
+    and verdict carry identical bits, with criteria active and with a fixed count.  A source that starts
+    well off the target exercises the far walk and the warm start's empty-cube branch."""
+    base = _scene(60000)
+    src = synth.rigid_offset(base[:20000], jitter=0.002)
+    src[:500] += np.float32([0.8, -0.5, 0.3])  # stragglers beyond the cell walk
+    runs = {}
+    with capi.Index(base, engine=capi.ENGINE_GRID) as ix:
+        for warm in (1, 0):
+            for loop in (1, 0):
+                ix.set_option(capi.OPT_ICP_WARM, warm)
+                ix.set_option(capi.OPT_ICP_DEVICE_LOOP, loop)
+                T, fit, it, conv = ix.icp_align(src, max_iter=12, fixed=fixed)
+                runs[(warm, loop)] = (T.view(np.uint32).copy(), np.float64(fit).view(np.uint64), it, conv)
+    first = runs[(1, 1)]
+    assert first[2] > 1
+    for key, r in runs.items():
+        assert (r[0] == first[0]).all() and r[1] == first[1] and r[2] == first[2] and r[3] == first[3], key
+    # and the loop as such: the oracle's host loop from the same start, compared as floats (Horn vs Jacobi SVD)
+    oT, ofit, oit, _, _ = oracle.icp(src, base, max_iter=12, fixed=fixed)
+    assert first[2] == oit
+    assert np.allclose(first[0].view(np.float32), oT, atol=5e-5)
+
+
 def test_icp_align_far_from_the_origin(gpu):
     """a small cloud at geo-referenced coordinates (8 cm across at (1e3, 1e5, 1e5)): the rotation comes from sum q p^T
     - n pm qm^T, 4e11 against 0.3 -- summed about the origin it lost five digits and an exact copy of the cloud came out
