@@ -134,7 +134,8 @@ enum pcc_option {
     PCC_OPT_EC_CELLS = 6,        /* clustering over the clique-cell grid (default 1; 0 = per-point ball scan) */
     PCC_OPT_SORT_MP_MIN = 7,     /* reference clouds from this size take the three-level cell sort */
     PCC_OPT_SORT_MP_MIN_Q = 8,   /* the same for query clouds */
-    PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query, 1 dense rows drained with lanes over candidates */
+    PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query; 1 rows drained with lanes over candidates (default);
+                                    2 / 3 the same with the open lanes always listed for a second kernel / always finished in place */
     PCC_OPT_GRID_OCCUPANCY = 10, /* cell edge from the occupied-cell statistics instead of the bounding-box volume (default 1) */
     PCC_OPT_FLANN_SPLIT = 11     /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
 };

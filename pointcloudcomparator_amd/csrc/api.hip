@@ -306,7 +306,7 @@ static int new_handle(int device, int engine, pcc_index** out) {
     if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(PCC_ERR_DEVICE); }
     ix->stream = ix->own_stream;
     if (hipHostMalloc(&ix->pinned, PACK_MAX_BLOCKS * 8 * sizeof(float) + 4096, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
-    if ((st = ix->small.reserve(4096)) != PCC_OK) return fail(st);
+    if ((st = ix->small.reserve(PCC_SMALL_BYTES)) != PCC_OK) return fail(st);
     if ((st = ix->blk_stats.reserve(PACK_MAX_BLOCKS * 8 * sizeof(float))) != PCC_OK) return fail(st);
     ix->engine_requested = engine;
     ix->engine = engine;
@@ -514,7 +514,7 @@ int pcc_index_set_option(pcc_index* ix, int option, double value) {
         case PCC_OPT_GRID_TRIM: ok = value >= 0 && value <= 8; break;
         case PCC_OPT_FAR_MODE: ok = value >= -1 && value <= 1; break;
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
-        case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 7; break;  // (2, 3: other batch sizes of the flat drain -- measurements)
+        case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 3; break;
         default: ok = value == 0 || value == 1; break;
     }
     if (!ok) { set_error("option %d: value %g out of range", option, value); return PCC_ERR_INVALID; }

@@ -527,30 +527,23 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
-// ---- k_grid_nn1_flat: the rows drained with lanes over CANDIDATES -------------------------------------------
+// ---- k_grid_nn1_flat2: the rows drained with lanes over CANDIDATES ---------------------------------------------
 // k_grid_nn1 gives every query a lane, and a wave's walk over a row of cells lasts as long as the LONGEST of its 64
 // spans: 20 of 64 lanes active per VALU instruction at 10M x 10M (profiles/r02_nn1_counters.json) -- a row of three
 // cells holds 1.5 references on average in sparse regions, and in dense ones the rows are clipped to the ball of the
 // best distance, so most lanes skip most rows while the wave still walks all nine at full length.
-// Here the rows of a pass (own row / the four face rows / the four diagonal rows -- the same rows, bounds, clipping and
-// slack as k_grid_nn1, so the candidate set and every result bit are the same) are DRAINED FLAT: the lanes' spans are
-// laid end to end in (row, lane) order and the wave takes the candidates 64 at a time across span boundaries.
-// Consecutive lanes read consecutive cell_refs entries (neighbouring lanes' spans overlap or adjoin: few lines per
-// load), fetch their query from LDS and fold (d2 bits, index) into the query's LDS slot with one ds_min_u64 -- order
+// Here the spans of a pass (the same rows, bounds, clipping and slack as k_grid_nn1: the candidate set covers every
+// reference that kernel looks at, and a reference more never changes a minimum) are DRAINED FLAT: laid end to end, and
+// the wave takes the candidates 64 at a time across span boundaries.  Consecutive lanes read consecutive cell_refs
+// entries, fetch their query from LDS and fold (d2 bits, index) into the query's LDS slot with one ds_min_u64 -- order
 // free, hence exact.  Which span a candidate belongs to: one bit per span END over the flat index space; the rank of a
 // candidate's span = ends before it = ends of earlier windows (a scalar count) + v_mbcnt of its window's bits.  The bits
 // are stored TRANSPOSED -- word (p mod 64) of plane (p / 2048) holds flat position p at bit (p / 64) mod 32 -- so the
-// ends of one row, which are a few positions apart, go to different words (the atomic ORs that set them do not collide),
-// lane l's word serves 32 consecutive windows, and a window's mask is a ballot of one bit test.
+// ends of neighbouring spans, a few positions apart, go to different words (the atomic ORs that set them do not
+// collide: with one word per 64 positions half of the LDS cycles were conflicts), lane l's word serves 32 consecutive
+// windows, and a window's mask is a ballot of one bit test.
 constexpr int FLAT_PLANES = 4;
 constexpr int FLAT_CAP = FLAT_PLANES * 2048;  // candidates one flat pass can hold; larger passes fall back to the lane walk
-struct alignas(16) FlatWave {
-    float4 q[64];                        // the wave's queries (x, y, z, bits of the best d2 when the pass began)
-    unsigned long long best[64];         // running (d2 bits << 32 | index) per query
-    unsigned int ends[FLAT_PLANES][64];  // span-end bits, transposed (above)
-    uint2 span[4 * 64];                  // non-empty spans in flat order: (first reference - flat offset, query slot)
-};
-static_assert(sizeof(FlatWave) == 1024 + 512 + FLAT_PLANES * 256 + 2048, "LDS budget of k_grid_nn1_flat");
 
 __device__ __forceinline__ void flat_sync() {
     // one wave, its own LDS block: DS operations of a wave execute in issue order, the compiler must keep that order
@@ -559,19 +552,35 @@ __device__ __forceinline__ void flat_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// one pass over R rows: lane-local spans [s[r], s[r] + len[r]) of cell_refs, results folded into fw.best
+// Two passes.  The spans of a pass are laid out lane by lane (a lane's rows next to each other), so ONE wave scan
+// gives every lane its flat offset and its first record slot
+// (candidate total and non-empty-span count travel in one 32-bit word); records are one word, (first reference - flat
+// offset) and the query slot packed.  Pass 0 gives every query a bound: the own row where the wave is sparse, the own CELL
+// where it is dense (>= 4 references per cell on average over the wave: there the nearest neighbour is almost always in
+// the own cell, and the other two cells of the row cost 17 candidates per query).  Pass 1 takes everything else -- the
+// rest of the own row and the eight neighbour rows, each skipped or clipped against the bound exactly as in k_grid_nn1.
+constexpr int F2_R = 10;
+struct alignas(16) FlatWave2 {
+    float4 q[64];                        // the wave's queries (x, y, z, bits of the best d2 when the pass began)
+    unsigned long long best[64];         // running (d2 bits << 32 | index) per query
+    unsigned int ends[FLAT_PLANES][64];  // span-end bits, transposed (k_grid_nn1_flat)
+    unsigned int span[F2_R * 64];        // non-empty spans in flat order: (first reference - flat offset + FLAT_CAP) << 6 | query slot
+};
+static_assert(sizeof(FlatWave2) == 1024 + 512 + FLAT_PLANES * 256 + F2_R * 256, "LDS budget of k_grid_nn1_flat2");
+constexpr size_t F2_MAX_REFS = (1u << 26) - 2 * FLAT_CAP;  // the packed record holds 26 bits of reference position
+
 template <int R, int U, int B, bool LIVE>
-__device__ __forceinline__ void flat_pass(FlatWave& fw, const float4* __restrict__ cell_refs, const unsigned int (&s)[R],
-                                          const unsigned int (&len)[R], float qx, float qy, float qz, unsigned int lane) {
+__device__ __forceinline__ void flat2_pass(FlatWave2& fw, const float4* __restrict__ cell_refs, const unsigned int (&s)[R],
+                                           const unsigned int (&len)[R], float qx, float qy, float qz, unsigned int lane) {
     static_assert(B == 1 || B == 2 || B == 4 || B == 8, "a batch of windows never straddles a plane of 32");
-    unsigned int off[R];
-    unsigned int T = 0;  // wave-uniform
+    unsigned int tot = 0, cnt = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned int incl = wave_incl_scan_add(len[r]);
-        off[r] = T + incl - len[r];
-        T += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
-    }
+    for (int r = 0; r < R; ++r) { tot += len[r]; cnt += len[r] != 0 ? 1u : 0u; }
+    // (a lane total past 16383 means the pass is past FLAT_CAP anyway; clamped so that the wave sum stays below 2^20)
+    const unsigned int v = min(tot, 16383u) | (cnt << 20);
+    const unsigned int incl = wave_incl_scan_add(v);
+    const unsigned int last = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+    const unsigned int T = last & 0xfffffu, nspan = last >> 20;  // wave-uniform
     if (T == 0) return;
     if (T > (unsigned int)FLAT_CAP) {  // (piles of duplicates, very coarse grids: rare) the lane walk of k_grid_nn1
         unsigned long long b = ~0ull;
@@ -581,69 +590,62 @@ __device__ __forceinline__ void flat_pass(FlatWave& fw, const float4* __restrict
         flat_sync();
         return;
     }
+    unsigned int off = (incl - v) & 0xfffffu, rank = (incl - v) >> 20;
     const unsigned int nwin = (T + 63) >> 6;
 #pragma unroll
     for (int p = 0; p < FLAT_PLANES; ++p)
         if ((unsigned int)p * 2048u < T) fw.ends[p][lane] = 0u;
     flat_sync();
-    unsigned int nspan = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const unsigned long long occ = __ballot(len[r] != 0);
         if (len[r]) {
-            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(occ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)occ, nspan));
-            fw.span[rank] = make_uint2(s[r] - off[r], lane);
-            const unsigned int e = off[r] + len[r] - 1;  // last flat position of the span
-            if (e + 1 < T) atomicOr(&fw.ends[e >> 11][e & 63], 1u << ((e >> 6) & 31));
+            fw.span[rank] = ((s[r] - off + (unsigned int)FLAT_CAP) << 6) | lane;
+            const unsigned int e = off + len[r] - 1;  // last flat position of the span
+            // (the end of the very last span is marked too: only lanes past the end could count it, and they are masked)
+            atomicOr(&fw.ends[e >> 11][e & 63], 1u << ((e >> 6) & 31));
+            off += len[r];
+            ++rank;
         }
-        nspan += (unsigned int)__popcll(occ);
     }
     flat_sync();
-    // Windows are taken B at a time: B span records, B reference loads in flight before the first distance is formed
-    // (one window at a time left every wave waiting on a single load).  In the last batch, lanes past the end re-read
-    // the last candidate (a valid address) and are masked at the fold.
     const unsigned int last_span = nspan - 1;
     unsigned int before = 0;  // span ends in earlier windows (scalar)
     unsigned int word = 0;
     auto batch = [&](unsigned int w0, auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
-        uint2 rec[B];
+        unsigned int rec[B], cc[B];
         bool ok[B];
-        unsigned int cc[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const unsigned int w = w0 + b;
             const unsigned long long m = __ballot(((word >> (w & 31)) & 1u) != 0u);
-            unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
+            unsigned int rk = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
             before += (unsigned int)__popcll(m);
             cc[b] = (w << 6) + lane;
             ok[b] = true;
             if (TAIL) {
                 ok[b] = cc[b] < T;
                 cc[b] = ok[b] ? cc[b] : T - 1;
-                rank = ok[b] ? rank : last_span;
+                rk = ok[b] ? rk : last_span;
             }
-            rec[b] = fw.span[rank];
+            rec[b] = fw.span[rk];
         }
         float4 r4[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) r4[b] = cell_refs[rec[b].x + cc[b]];
+        for (int b = 0; b < B; ++b) r4[b] = cell_refs[(rec[b] >> 6) + cc[b] - (unsigned int)FLAT_CAP];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-            const float4 qv = fw.q[rec[b].y];
+            const unsigned int slot = rec[b] & 63u;
+            const float4 qv = fw.q[slot];
             const float d = dist2(qv.x, qv.y, qv.z, r4[b]);
             const unsigned int db = __float_as_uint(d);
-            // most candidates do not beat what the query already has: look before the (serialising) atomic.  The own
-            // row has no bound yet: there the look goes to the live slot.
-            const unsigned int cur = LIVE ? reinterpret_cast<const unsigned int*>(&fw.best[rec[b].y])[1] : __float_as_uint(qv.w);
-            // (the test on the index is always true -- an index is never ~0 -- and keeps the candidate ONE 16-byte load:
-            // with w needed only behind the branch the compiler fetches it there, in a second dependent load)
-            const unsigned int ri = (unsigned int)__float_as_int(r4[b].w);
-            if (ok[b] && db <= cur && ri != 0xffffffffu) atomicMin(&fw.best[rec[b].y], ((unsigned long long)db << 32) | ri);
+            const unsigned int cur = LIVE ? reinterpret_cast<const unsigned int*>(&fw.best[slot])[1] : __float_as_uint(qv.w);
+            const unsigned int ri = (unsigned int)__float_as_int(r4[b].w);  // (never ~0: keeps the candidate ONE 16-byte load)
+            if (ok[b] && db <= cur && ri != 0xffffffffu) atomicMin(&fw.best[slot], ((unsigned long long)db << 32) | ri);
         }
     };
-    const unsigned int nfull = (T >> 6) / B * B;  // windows in batches that lie entirely below T
-    for (unsigned int p0 = 0; p0 < nwin; p0 += 32) {  // one plane of end bits = 32 windows
+    const unsigned int nfull = (T >> 6) / B * B;
+    for (unsigned int p0 = 0; p0 < nwin; p0 += 32) {
         word = fw.ends[p0 >> 5][lane];
         const unsigned int pend = min(p0 + 32u, nwin);
         unsigned int w0 = p0;
@@ -653,17 +655,16 @@ __device__ __forceinline__ void flat_pass(FlatWave& fw, const float4* __restrict
     flat_sync();
 }
 
-template <int U, int B, int NW = 4, int WPE = 0, bool NOFIN = false>
+template <int U, int B, int NW, bool OPENK>
 __global__ void __launch_bounds__(NW * 64)
-#if defined(__HIP_DEVICE_COMPILE__)
-__attribute__((amdgpu_waves_per_eu(WPE > 0 ? WPE : 1, WPE > 0 ? WPE : 8)))
-#endif
-k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
-                const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-                const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
-                unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
-                unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk,
-                const float4* __restrict__ warm_refs) {
+k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+                 const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+                 const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
+                 unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
+                 unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk,
+                 const float4* __restrict__ warm_refs, unsigned int dense_min,
+                 unsigned int* __restrict__ open_list, unsigned long long* __restrict__ open_keys,
+                 unsigned int* __restrict__ open_total) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
     unsigned int bid = blockIdx.x;  // XCD-aware order of the workgroups, as in k_grid_nn1
@@ -674,11 +675,10 @@ k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
             bid = base + (in & 7u) * xcd_run + (in >> 3);
         }
     }
-    // phase 1 works in the waves' FlatWave blocks; afterwards the same memory holds the packed open lanes
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NW * sizeof(FlatWave)];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NW * sizeof(FlatWave2)];
     __shared__ unsigned int open_count;
-    static_assert(sizeof(FlatWave) >= 64 * (sizeof(float4) + sizeof(unsigned long long)), "open-lane list fits");
-    FlatWave& fw = reinterpret_cast<FlatWave*>(lds_raw)[threadIdx.x >> 6];
+    static_assert(sizeof(FlatWave2) >= 64 * (sizeof(float4) + sizeof(unsigned long long)), "open-lane list fits");
+    FlatWave2& fw = reinterpret_cast<FlatWave2*>(lds_raw)[threadIdx.x >> 6];
     float4* open_q = reinterpret_cast<float4*>(lds_raw);
     unsigned long long* open_best = reinterpret_cast<unsigned long long*>(lds_raw + NW * 64 * sizeof(float4));
     if (threadIdx.x == 0) open_count = 0;
@@ -689,7 +689,7 @@ k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
     float4 qv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     if (t < ns) { qi = order ? order[t] : t; qv = q[qi]; }
     const bool active = __float_as_int(qv.w) >= 0;
-    float qx = qv.x, qy = qv.y, qz = qv.z;
+    const float qx = qv.x, qy = qv.y, qz = qv.z;
     const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
     const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
     const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
@@ -702,8 +702,6 @@ k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
         const int x0 = max(cx - 1, 0);
         const bool shifted = cx == 0;
         const bool has_right = cx + 1 < g.dim[0];
-        // the clipped span of row i (0..8: z = cz + i / 3 - 1, y = cy + i % 3 - 1) against the best squared distance bd
-        // -- the same four-bound gather, the same gap tests and slack as k_grid_nn1's phase 1
         const float fx = g.org[0] + cx * g.h, fy = g.org[1] + cy * g.h, fz = g.org[2] + cz * g.h;
         const float gxl = fmaxf((qx - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - qx) - slack, 0.f);
         const float gyl = fmaxf((qy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - qy) - slack, 0.f);
@@ -711,33 +709,61 @@ k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
         const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
         const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
         const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
-        auto row_span = [&](int i, float bd, unsigned int& s0, unsigned int& ln) {
-            s0 = 0u; ln = 0u;
-            const int z = cz + i / 3 - 1, y = cy + i % 3 - 1;
-            const float rem = bd - (gy2[i % 3] + gz2[i / 3]);  // (NaN while nothing is found: keeps the row whole)
-            if (!active || rem < 0.f || z < 0 || z >= g.dim[2] || y < 0 || y >= g.dim[1]) return;
-            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
-            const uint4 b4 = *reinterpret_cast<const uint4*>(cell_start + row + x0);
-            const unsigned int L = b4.x, A = shifted ? b4.x : b4.y, Bc = shifted ? b4.y : b4.z;
-            const unsigned int r3 = shifted ? b4.z : b4.w, Rr = has_right ? r3 : Bc;
-            s0 = gxl2 > rem ? A : L;
-            const unsigned int e0 = gxr2 > rem ? Bc : Rr;
-            ln = e0 - s0;
+        // the four bounds L <= A <= Bc <= Rr of row i (0..8: z = cz + i / 3 - 1, y = cy + i % 3 - 1): [L, A) left cell,
+        // [A, Bc) own column's cell, [Bc, Rr) right cell -- one unaligned 16-byte gather, as in k_grid_nn1
+        const unsigned int rowc = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + x0;
+        const bool ok_y[3] = {cy > 0, true, cy + 1 < g.dim[1]}, ok_z[3] = {cz > 0, true, cz + 1 < g.dim[2]};
+        // (two steps, so that the gathers of all rows of a pass are in flight together: the loads first, nothing else
+        // inside their predicate; the selects afterwards)
+        auto row_load = [&](int i, bool wanted) -> uint4 {
+            uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
+            if (wanted & active & ok_y[i % 3] & ok_z[i / 3]) {  // (one predicate, one branch)
+                const int delta = ((i / 3 - 1) * g.dim[1] + (i % 3 - 1)) * g.dim[0];
+                b4 = *reinterpret_cast<const uint4*>(cell_start + (rowc + (unsigned int)delta));
+            }
+            return b4;
         };
-        {   // own row, whole
-            unsigned int s1[1], l1[1];
-            row_span(4, __uint_as_float(0xffffffffu), s1[0], l1[0]);
-            flat_pass<1, U, B, true>(fw, cell_refs, s1, l1, qx, qy, qz, lane);
+        auto row_bounds = [&](const uint4& b4, unsigned int& L, unsigned int& A, unsigned int& Bc, unsigned int& Rr) {
+            L = b4.x;
+            A = shifted ? b4.x : b4.y;
+            Bc = shifted ? b4.y : b4.z;
+            const unsigned int r3 = shifted ? b4.z : b4.w;
+            Rr = has_right ? r3 : Bc;
+        };
+        unsigned int oL, oA, oB, oR;
+        row_bounds(row_load(4, true), oL, oA, oB, oR);
+        // dense wave: >= dense_min references per own cell on average
+        const unsigned int own_cells = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(oB - oA), 63);
+        const bool dense = own_cells >= 64u * dense_min;
+        {
+            unsigned int s1[1] = {dense ? oA : oL}, l1[1] = {dense ? oB - oA : oR - oL};
+            flat2_pass<1, U, B, true>(fw, cell_refs, s1, l1, qx, qy, qz, lane);
         }
-        constexpr int pass_rows[2][4] = {{3, 5, 1, 7}, {0, 2, 6, 8}};  // face neighbours, then the diagonal rows
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float bd = __uint_as_float((unsigned int)(fw.best[lane] >> 32));
+        {
+            const float bd = __uint_as_float((unsigned int)(fw.best[lane] >> 32));  // (NaN while nothing is found: every test below keeps its span)
             fw.q[lane].w = bd;  // the flat drain's pre-filter (read with the query, no extra LDS access)
-            unsigned int s4[4], l4[4];
+            unsigned int sp[F2_R], ln[F2_R];
+            // the rest of the own row (dense waves): a side cell is dropped when the gap to it exceeds the bound
+            sp[0] = oL; ln[0] = dense && !(gxl2 > bd) ? oA - oL : 0u;
+            sp[1] = oB; ln[1] = dense && !(gxr2 > bd) ? oR - oB : 0u;
+            constexpr int rows[8] = {3, 5, 1, 7, 0, 2, 6, 8};  // face neighbours, then the diagonal rows
+            uint4 b4[8];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) row_span(pass_rows[p][o], bd, s4[o], l4[o]);
-            flat_pass<4, U, B, false>(fw, cell_refs, s4, l4, qx, qy, qz, lane);
+            for (int o = 0; o < 8; ++o) {
+                const int i = rows[o];
+                b4[o] = row_load(i, !(bd - (gy2[i % 3] + gz2[i / 3]) < 0.f));
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const int i = rows[o];
+                const float rem = bd - (gy2[i % 3] + gz2[i / 3]);
+                unsigned int L, A, Bc, Rr;
+                row_bounds(b4[o], L, A, Bc, Rr);
+                const unsigned int s0 = gxl2 > rem ? A : L, e0 = gxr2 > rem ? Bc : Rr;
+                sp[2 + o] = s0;
+                ln[2 + o] = e0 - s0;
+            }
+            flat2_pass<F2_R, U, B, false>(fw, cell_refs, sp, ln, qx, qy, qz, lane);
         }
         best = fw.best[lane];
         if (active) {
@@ -749,7 +775,29 @@ k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
             if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
         }
     }
-    __syncthreads();  // every wave is done with its FlatWave block: the open-lane list may overwrite them
+    if (OPENK) {
+        // the lanes phase 1 leaves open go to a device-wide list, finished by k_nn1_open with every lane busy (in place,
+        // a workgroup's dozen open lanes ran the ball walk at a fifth of the lanes: 45 % of the kernel's instructions)
+        if (active && resolved) out[qi] = best;
+        const bool open = active && !resolved;
+        const unsigned long long om = __ballot(open);
+        if (om != 0ull) {
+            // (one returning atomic per wave; the counters are sharded by workgroup so that no single word has to take them
+            // all: every shard owns the slice of the list its workgroups could fill)
+            const unsigned int shard = blockIdx.x % PCC_OPEN_SHARDS;
+            const unsigned int cap = (gridDim.x + PCC_OPEN_SHARDS - 1) / PCC_OPEN_SHARDS * (NW * 64);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(open_total + shard * PCC_OPEN_CTR_STRIDE, (unsigned int)__popcll(om));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (open) {
+                const unsigned int k = shard * cap + base + __builtin_amdgcn_mbcnt_hi((unsigned int)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)om, 0u));
+                open_list[k] = qi;
+                open_keys[k] = best;
+            }
+        }
+        return;
+    }
+    __syncthreads();  // every wave is done with its block: the open-lane list may overwrite them
     if (active && resolved) out[qi] = best;
     if (active && !resolved) {
         const unsigned int slot = atomicAdd(&open_count, 1u);
@@ -760,9 +808,29 @@ k_grid_nn1_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
     const unsigned int n_open = open_count;
     for (unsigned int j = threadIdx.x; j < n_open; j += blockDim.x) {
         const float4 oq = open_q[j];
-        if (NOFIN) { out[__float_as_uint(oq.w)] = open_best[j]; continue; }
         nn1_finish<2>(cell_refs, cell_start, g, slack, oq.x, oq.y, oq.z, __float_as_uint(oq.w), open_best[j], out, fb_list,
                       fb_count, ball_walk, warm_refs);
+    }
+}
+
+// the open lanes of k_grid_nn1_flat2, compacted: one lane per listed query, every lane busy
+__global__ void __launch_bounds__(256)
+k_nn1_open(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, const GridDev* __restrict__ gd,
+           const float4* __restrict__ q, const unsigned int* __restrict__ open_list,
+           const unsigned long long* __restrict__ open_keys, const unsigned int* __restrict__ open_total,
+           unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count,
+           bool ball_walk, const float4* __restrict__ warm_refs, unsigned int shard_cap) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    // block b works on shard b % PCC_OPEN_SHARDS, as chunk b / PCC_OPEN_SHARDS of gridDim / PCC_OPEN_SHARDS
+    const unsigned int shard = blockIdx.x % PCC_OPEN_SHARDS, chunk = blockIdx.x / PCC_OPEN_SHARDS, nchunk = gridDim.x / PCC_OPEN_SHARDS;
+    const unsigned int cnt = open_total[shard * PCC_OPEN_CTR_STRIDE];
+    for (unsigned int j = chunk * blockDim.x + threadIdx.x; j < cnt; j += nchunk * blockDim.x) {
+        const unsigned int k = shard * shard_cap + j;
+        const unsigned int qi = open_list[k];
+        const float4 qv = q[qi];
+        nn1_finish<2>(cell_refs, cell_start, g, slack, qv.x, qv.y, qv.z, qi, open_keys[k], out, fb_list, fb_count, ball_walk,
+                      warm_refs);
     }
 }
 
@@ -878,7 +946,10 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     unsigned int* fb_count = ix->small.as<unsigned int>() + 32;
     // zeroed by the query pack kernel of this call; searches that re-use packed queries (the ICP
     // loop transforms them in place) have no pack and zero it here
-    if (!ix->fb_zeroed) PCC_HIP(hipMemsetAsync(fb_count, 0, 4, s));
+    if (!ix->fb_zeroed) {  // fallback and far counters, the sharded open-lane counters
+        PCC_HIP(hipMemsetAsync(fb_count, 0, 8, s));
+        PCC_HIP(hipMemsetAsync(ix->small.as<unsigned int>() + PCC_OPEN_CTR0, 0, PCC_OPEN_SHARDS * PCC_OPEN_CTR_STRIDE * 4, s));
+    }
     ix->fb_zeroed = false;
     unsigned int *order = nullptr, *n_sorted = nullptr;
     if (ix->keep_order && ix->order_valid && ix->order_nq == nq) {
@@ -900,21 +971,42 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us)
     const bool ball_walk = !ix->keep_order;
     const bool warm = ix->warm_start && ix->keep_order;  // out[] holds the previous pass's keys of the SAME queries (pcc_icp_align)
-#define PCC_LAUNCH_FLAT(BB, NW, WPE) hipLaunchKernelGGL((k_grid_nn1_flat<4, BB, NW, WPE>), dim3((n + NW * 64 - 1) / (NW * 64)), dim3(NW * 64), 0, s, ix->cell_refs.as<float4>(), \
-                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, \
-                           fb_count, xcd_run * 4 / NW, ball_walk, warm ? ix->refs.as<float4>() : nullptr)
-    switch (ix->opt.nn1_kernel) {
-        case 1: PCC_LAUNCH_FLAT(4, 2, 0); break;
-        case 2: PCC_LAUNCH_FLAT(4, 4, 8); break;
-        case 3: PCC_LAUNCH_FLAT(2, 4, 8); break;
-        case 4: PCC_LAUNCH_FLAT(4, 4, 0); break;
-        case 5: PCC_LAUNCH_FLAT(4, 2, 8); break;
-        case 6: PCC_LAUNCH_FLAT(2, 2, 8); break;
-        case 7: hipLaunchKernelGGL((k_grid_nn1_flat<4, 4, 2, 0, true>), dim3((n + 127) / 128), dim3(128), 0, s, ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr); break;
-        default: break;
+    // PCC_OPT_NN1_KERNEL: 0 one lane per query (k_grid_nn1); 1 rows drained flat (k_grid_nn1_flat2), the lanes it leaves open
+    // finished by k_nn1_open from 2M queries on and in place below (a compacted list of 100k queries is a few hundred
+    // waves whose dependent loads nothing hides: 116 vs 99 us at 1M x 1M; 688 vs 792 us at 10M x 10M); 2 / 3 force the
+    // list / the in-place finish (tests, measurements)
+    int form = ix->opt.nn1_kernel;
+    if (form != 0 && ix->n_orig > F2_MAX_REFS) form = 0;  // (the packed span record holds 26 bits of reference position)
+    if (form != 0) {
+        const bool listed = form == 2 || (form == 1 && nq >= 2000000);
+        const unsigned int dm = 4u;
+        const unsigned int f2_bs = 128u, f2_grid = (n + f2_bs - 1) / f2_bs;
+        const unsigned int shard_cap = (f2_grid + PCC_OPEN_SHARDS - 1) / PCC_OPEN_SHARDS * f2_bs;
+        const size_t list_cap = (size_t)shard_cap * PCC_OPEN_SHARDS;
+        unsigned int* open_list = nullptr;
+        unsigned long long* open_keys = nullptr;
+        unsigned int* open_total = ix->small.as<unsigned int>() + PCC_OPEN_CTR0;
+        if (listed) {
+            PCC_TRY(ix->scratch_f.reserve(list_cap * 12 + 64));
+            open_list = ix->scratch_f.as<unsigned int>();
+            open_keys = reinterpret_cast<unsigned long long*>(ix->scratch_f.as<char>() + ((list_cap * 4 + 15) & ~(size_t)15));
+        }
+#define PCC_F2_ARGS ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, \
+                               fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr, dm, open_list, open_keys, open_total
+        if (listed) {
+            hipLaunchKernelGGL((k_grid_nn1_flat2<4, 4, 2, true>), dim3(f2_grid), dim3(f2_bs), 0, s, PCC_F2_ARGS);
+            // (chunks per shard: enough blocks for every listed query to have a lane at once, at most 64)
+            unsigned int chunks = (shard_cap / 4 + 255) / 256;
+            chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+            hipLaunchKernelGGL(k_nn1_open, dim3(chunks * PCC_OPEN_SHARDS), dim3(256), 0, s, ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(),
+                               ix->d_grid.as<GridDev>(), q, open_list, open_keys, open_total, out, fb_list, fb_count, ball_walk,
+                               warm ? ix->refs.as<float4>() : nullptr, shard_cap);
+        } else {
+            hipLaunchKernelGGL((k_grid_nn1_flat2<4, 4, 2, false>), dim3(f2_grid), dim3(f2_bs), 0, s, PCC_F2_ARGS);
+        }
+#undef PCC_F2_ARGS
     }
-#undef PCC_LAUNCH_FLAT
-    if (ix->opt.nn1_kernel == 0)
+    if (form == 0)
         hipLaunchKernelGGL(k_grid_nn1<4>, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
                            fb_count, xcd_run, ball_walk, warm ? ix->refs.as<float4>() : nullptr);

@@ -33,7 +33,10 @@ __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
        float* __restrict__ blk, unsigned int* __restrict__ zero_word, float4* __restrict__ seeds,
        unsigned long long* __restrict__ invalid_keys) {
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // saves a 5 us memset node
+    if (zero_word && blockIdx.x == 0 && threadIdx.x < 64) {  // counters of the search that follows: saves a 5 us memset node
+        if (threadIdx.x < 2) zero_word[threadIdx.x] = 0u;                      // fallback list, far list
+        zero_word[PCC_OPEN_CTR0 - 32 + threadIdx.x * PCC_OPEN_CTR_STRIDE] = 0u;  // the sharded open-lane counters (grid.hip)
+    }
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};

@@ -11,6 +11,12 @@
 // every PCC_SEED_STRIDE-th reference is a "seed": the exhaustive scan of the seeds bounds a far query's ball
 #define PCC_SEED_SHIFT 6
 #define PCC_SEED_STRIDE (1 << PCC_SEED_SHIFT)
+// pcc_index::small (uint32 words): [32] fallback count, [33] far-list count, [PCC_OPEN_CTR0 + s * PCC_OPEN_CTR_STRIDE] open-lane
+// count of shard s -- one 128-byte line each, PCC_OPEN_SHARDS of them (a single word takes ~88 atomics per microsecond)
+#define PCC_OPEN_SHARDS 64
+#define PCC_OPEN_CTR0 1024
+#define PCC_OPEN_CTR_STRIDE 32
+#define PCC_SMALL_BYTES ((PCC_OPEN_CTR0 + PCC_OPEN_SHARDS * PCC_OPEN_CTR_STRIDE) * 4)
 
 namespace pcc {
 
@@ -84,7 +90,7 @@ struct Options {
     int ec_cells = 1;               // PCC_OPT_EC_CELLS: clustering on the clique-cell grid (0: per-point ball scan)
     double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
     double sort_mp_min_q = 5e6;     // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds
-    int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 dense rows drained flat, lanes over candidates
+    int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 rows drained flat, lanes over candidates (2 / 3: open lanes listed / in place)
     int grid_occupancy = 1;         // PCC_OPT_GRID_OCCUPANCY: cell size from the occupied-cell statistics (0: bounding-box volume)
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     void from_env();

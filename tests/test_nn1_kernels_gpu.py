@@ -1,7 +1,7 @@
 """The pruned k = 1 kernel has two forms (PCC_OPT_NN1_KERNEL): 0 = one lane per query (k_grid_nn1), 1 = rows drained
-flat with lanes over candidates where that is cheaper (k_grid_nn1_flat), 2 = every pass that fits drained flat (the mode
-that exercises the flat path on small clouds too).  All of them scan the same candidates with the same arithmetic:
-indices and d2 bits must equal the oracle's exhaustive scan -- reference src/comparator.cpp:571-577."""
+flat with lanes over candidates (k_grid_nn1_flat2); 2 and 3 force how the flat form finishes the lanes its cube leaves
+open (a second kernel over a compacted list / in place), which 1 chooses by the number of queries.  All of them are
+exact: indices and d2 bits must equal the oracle's exhaustive scan -- reference src/comparator.cpp:571-577."""
 import numpy as np
 import pytest
 
@@ -46,7 +46,7 @@ def _scenes():
     return out
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_nn1_kernel_forms_match_the_oracle(gpu, mode):
     for name, ref, qry in _scenes():
         oi, od = oracle.nn1_exhaustive(ref, qry)
@@ -66,7 +66,7 @@ def test_nn1_kernel_forms_agree_at_a_million(gpu):
     b = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_B)).cuda()
     res = []
     with capi.Index(a, engine=capi.ENGINE_GRID) as ix:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             ix.set_option(capi.OPT_NN1_KERNEL, mode)
             idx, d2 = ix.nn1(b)
             res.append((idx.cpu().numpy(), d2.cpu().numpy()))
