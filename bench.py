@@ -339,6 +339,61 @@ def main():
                 "clusters_expected": synth.N_BALLS, "points_clustered": int(np.asarray(sizes).sum()),
                 "all_points_clustered": bool(int(np.asarray(sizes).sum()) == n)}
 
+    # ---- a surface-sampled scene next to the volumetric corridor: two scans of a room ------------------------------
+    def run_room(n, reps=3, full=True):
+        """points on 2-D surfaces (synth.room_cloud; sizes from the reference's own result file): the k = 1 step, the -n
+        noise pass (SOR, 51-NN) and the -e clustering of the furniture.  Reported beside C3, never instead of it."""
+        a_host, b_host = synth.room_cloud(n, synth.SEED_A), synth.room_cloud(n, synth.SEED_B)
+        a, b = torch.from_numpy(a_host).to(dev), torch.from_numpy(b_host).to(dev)
+        idx = torch.empty(n, dtype=torch.int32, device=dev)
+        d2 = torch.empty(n, dtype=torch.float32, device=dev)
+        ix = capi.Index(a, auto_sync=False)
+
+        def step():
+            ix.set_input(a)
+            ix.nn1(b, idx, d2)
+
+        for _ in range(3):
+            step()
+        dt = timed(ix, step, 10) / 10
+        ix.enable_timing(2)
+        timed(ix, step, 5)
+        tm = ix.timing()
+        ix.enable_timing(0)
+        r = {"workload": f"room scan, {n} x {n} points on the surfaces of a 6 x 5 x 2.5 m room with furniture (synth.room_cloud)",
+             "points": n, "nn1_step_ms": dt * 1e3, "nn1_queries_per_sec": n / dt, "build_ms": tm[3], "query_sort_ms": tm[4],
+             "nn1_kernel_ms": tm[0], "cells": int(ix.stats()[3]), "fallback_queries": int(ix.stats()[1])}
+        if full:
+            best = 1e9
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                md, inl, thr, kept = ix.sor(50, 1.5)
+                best = min(best, time.perf_counter() - t0)
+            r["sor_k51_ms"] = best * 1e3
+            r["sor_kept"] = int(kept)
+            m = max(n // 4, 100_000)
+            f = torch.from_numpy(synth.room_cloud(m, synth.SEED_A, part="furniture")).to(dev)
+            labels = torch.empty(m, dtype=torch.int32, device=dev)
+            fx = capi.Index(f, auto_sync=False)
+            best = 1e9
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fx.set_input(f)
+                lab, ncl, sizes = fx.euclidean_clusters(0.05, 100, 2_000_000_000, device_out=labels)
+                fx.sync()
+                best = min(best, time.perf_counter() - t0)
+            r["clusters_ms"] = best * 1e3
+            r["clusters_points"] = m
+            r["clusters"] = int(ncl)
+            r["clusters_expected"] = len(synth._ROOM_BOXES)
+            fx.close()
+        ix.close()
+        del a, b, idx, d2
+        torch.cuda.empty_cache()
+        return r
+
     # ---- C4: -i ICP, 50 fixed iterations, 2M x 2M -------------------------------------------------------------
     def run_icp(reps=2, iters=50):
         M, N, floats, desc = CONFIGS["c4"]
@@ -398,6 +453,7 @@ def main():
             extra["c2"] = run_nn("c2", with_exhaustive=not args.no_exhaustive, with_cpu=False)
             extra["c3_clusters"] = run_clusters()
             extra["c4_icp"] = run_icp()
+            extra["room"] = {"scan": run_room(synth.ROOM_SIZES[1]), "10M": run_room(synth.ROOM_SIZES[2], full=False)}
         else:
             # BASELINE configs[4]: 32M queries vs 8M references, sharded over the ranks present
             c5 = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // n_gpus, steps=min(K, 10), warmup=2)

@@ -37,6 +37,7 @@ void Options::from_env() {
     nn1_kernel = (int)num("PCC_NN1_KERNEL", nn1_kernel);
     grid_occupancy = (int)num("PCC_GRID_OCCUPANCY", grid_occupancy);
     flann_split = (int)num("PCC_FLANN_SPLIT", flann_split);
+    nn1_dense_min = (int)num("PCC_NN1_DENSE_MIN", nn1_dense_min);
 }
 
 int DevBuf::reserve(size_t bytes) {
@@ -499,6 +500,7 @@ static double* option_slot(pcc_index* ix, int option, int** as_int) {
         case PCC_OPT_NN1_KERNEL: *as_int = &o.nn1_kernel; return nullptr;
         case PCC_OPT_GRID_OCCUPANCY: *as_int = &o.grid_occupancy; return nullptr;
         case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
+        case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
         default: return nullptr;
     }
 }
@@ -515,6 +517,7 @@ int pcc_index_set_option(pcc_index* ix, int option, double value) {
         case PCC_OPT_FAR_MODE: ok = value >= -1 && value <= 1; break;
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
         case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 3; break;
+        case PCC_OPT_NN1_DENSE_MIN: ok = value >= 1 && value <= 1000000; break;
         default: ok = value == 0 || value == 1; break;
     }
     if (!ok) { set_error("option %d: value %g out of range", option, value); return PCC_ERR_INVALID; }

@@ -979,7 +979,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     if (form != 0 && ix->n_orig > F2_MAX_REFS) form = 0;  // (the packed span record holds 26 bits of reference position)
     if (form != 0) {
         const bool listed = form == 2 || (form == 1 && nq >= 2000000);
-        const unsigned int dm = 4u;
+        const unsigned int dm = (unsigned int)ix->opt.nn1_dense_min;
         const unsigned int f2_bs = 128u, f2_grid = (n + f2_bs - 1) / f2_bs;
         const unsigned int shard_cap = (f2_grid + PCC_OPEN_SHARDS - 1) / PCC_OPEN_SHARDS * f2_bs;
         const size_t list_cap = (size_t)shard_cap * PCC_OPEN_SHARDS;

@@ -67,6 +67,54 @@ def corridor_cloud(n: int, seed: int, layer: str = "both", start: int = 0) -> np
     return np.ascontiguousarray(pts.astype(np.float32))
 
 
+# ---- a surface-sampled scene: what the reference's real inputs look like --------------------------------------------
+# The reference compares two scans of a room (build/results.txt:4-8: 346 911 and 346 921 points in 74 / 65 clusters):
+# points on 2-D surfaces, not in a volume.  A 6 x 5 x 2.5 m room (75 m^3; floor, ceiling, four walls = 115 m^2) with
+# a few pieces of box-shaped furniture (five visible faces each), sampled uniformly by area, N(0, 2 mm) of jitter along
+# the surface normal.  ROOM_SIZES: the two cloud sizes of build/results.txt:4-5 and north_star's 10M.
+ROOM = np.array([6.0, 5.0, 2.5])
+ROOM_JITTER = 0.002
+ROOM_SIZES = (346_911, 1_379_736, 10_000_000)
+_ROOM_BOXES = (  # (x0, y0, x1, y1, height): furniture standing on the floor
+    (0.3, 0.3, 2.3, 1.2, 0.75), (3.0, 0.2, 3.6, 0.8, 1.9), (4.4, 3.6, 5.8, 4.8, 0.45), (0.2, 3.4, 0.8, 4.8, 2.0),
+    (2.4, 2.0, 3.6, 2.9, 0.72), (5.2, 0.3, 5.8, 2.3, 0.9))
+
+
+def _room_faces():
+    """list of (origin, edge u, edge v, unit normal): rectangles origin + s u + t v, s, t in [0, 1)"""
+    X, Y, Z = ROOM
+    f = [((0, 0, 0), (X, 0, 0), (0, Y, 0), (0, 0, 1)), ((0, 0, Z), (X, 0, 0), (0, Y, 0), (0, 0, 1)),
+         ((0, 0, 0), (X, 0, 0), (0, 0, Z), (0, 1, 0)), ((0, Y, 0), (X, 0, 0), (0, 0, Z), (0, 1, 0)),
+         ((0, 0, 0), (0, Y, 0), (0, 0, Z), (1, 0, 0)), ((X, 0, 0), (0, Y, 0), (0, 0, Z), (1, 0, 0))]
+    for x0, y0, x1, y1, h in _ROOM_BOXES:
+        f += [((x0, y0, h), (x1 - x0, 0, 0), (0, y1 - y0, 0), (0, 0, 1)),
+              ((x0, y0, 0), (x1 - x0, 0, 0), (0, 0, h), (0, 1, 0)), ((x0, y1, 0), (x1 - x0, 0, 0), (0, 0, h), (0, 1, 0)),
+              ((x0, y0, 0), (0, y1 - y0, 0), (0, 0, h), (1, 0, 0)), ((x1, y0, 0), (0, y1 - y0, 0), (0, 0, h), (1, 0, 0))]
+    return [tuple(np.asarray(v, np.float64) for v in face) for face in f]
+
+
+def room_cloud(n: int, seed: int, start: int = 0, part: str = "all") -> np.ndarray:
+    """(n, 3) float32: point i lies on the face its first random number picks (by area), at (s, t) from the next two,
+    pushed along the normal by a Box-Muller normal from the last two.  Counter-based like corridor_cloud.
+    part = 'furniture': only the box faces (what is left of a room once the planes are removed, the input of the
+    reference's -e clustering, src/segmentation.cpp:79-131): len(_ROOM_BOXES) clusters at tolerance 0.05."""
+    faces = _room_faces()
+    if part == "furniture":
+        faces = faces[6:]
+    area = np.array([np.linalg.norm(np.cross(u, v)) for _, u, v, _ in faces])
+    cum = np.cumsum(area) / area.sum()
+    i = np.arange(start, start + n, dtype=np.uint64)
+    u = [uniform24(seed ^ 0x400F, i * np.uint64(8) + np.uint64(j)) for j in range(5)]
+    k = np.minimum(np.searchsorted(cum, u[0], side="right"), len(faces) - 1)
+    org = np.stack([f[0] for f in faces])[k]
+    eu = np.stack([f[1] for f in faces])[k]
+    ev = np.stack([f[2] for f in faces])[k]
+    nr = np.stack([f[3] for f in faces])[k]
+    g = np.sqrt(-2.0 * np.log(np.maximum(u[3], 2.0 ** -24))) * np.cos(2.0 * np.pi * u[4])
+    pts = org + u[1][:, None] * eu + u[2][:, None] * ev + (ROOM_JITTER * g)[:, None] * nr
+    return np.ascontiguousarray(pts.astype(np.float32))
+
+
 def rigid_offset(points: np.ndarray, seed: int = 0x1C9, rot_deg: float = 2.0,
                  t=(0.03, -0.02, 0.01), jitter: float = 0.005) -> np.ndarray:
     """cloud B of the ICP config: rotate about z, translate, add N(0, jitter) noise."""

@@ -240,3 +240,34 @@ def test_2m_ransac_plane_against_the_restatement(gpu):
     assert its == w_its and (coeff.view(np.uint32) == w_c.view(np.uint32)).all()
     assert len(inl) == len(w_inl) and (inl == w_inl).all()
     assert len(inl) > 0.49 * n
+
+
+def test_room_scan_surface_sampled_scene(gpu):
+    """the reference's real inputs are scans of a room -- points on 2-D surfaces (reference build/results.txt:4-5: 346 911
+    and 1 379 736 points) -- not the volumetric corridor scene: k = 1 with both kernel forms against each other and
+    against the CPU kd-tree on a sample, 51-NN rows (the -n noise pass) on a sample against the exhaustive oracle, and the
+    furniture's known partition under the -e clustering"""
+    n = synth.ROOM_SIZES[1]
+    a, b = synth.room_cloud(n, synth.SEED_A), synth.room_cloud(n, synth.SEED_B)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    res = []
+    with capi.Index(ta, engine=capi.ENGINE_GRID) as ix:
+        for form in (1, 0, 2, 3):
+            ix.set_option(capi.OPT_NN1_KERNEL, form)
+            idx, d2 = ix.nn1(tb)
+            ix.sync()
+            res.append((idx.cpu().numpy(), d2.cpu().numpy()))
+        assert ix.stats()[1] < 1000
+        ix.set_option(capi.OPT_NN1_KERNEL, 1)
+        sel = np.sort(np.random.default_rng(5).choice(n, 200, replace=False))
+        ki, kd = ix.knn(np.ascontiguousarray(b[sel]), 51)
+    for idx, d2 in res[1:]:
+        assert (idx == res[0][0]).all() and (_bits(d2) == _bits(res[0][1])).all()
+    _sample_check(a, b, res[0][0], res[0][1])
+    ei, ed = oracle.knn_exhaustive(a, np.ascontiguousarray(b[sel]), 51)
+    assert (_bits(kd) == _bits(ed)).all() and (ki == ei).all()
+    m = 400_000
+    f = synth.room_cloud(m, synth.SEED_A, part="furniture")
+    with capi.Index(f) as fx:
+        labels, ncl, sizes = fx.euclidean_clusters(0.05, 100, 2_000_000_000)
+    assert ncl == len(synth._ROOM_BOXES) and int(sizes.sum()) == m and (labels >= 0).all()
