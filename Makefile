@@ -19,7 +19,7 @@ ubench: build/ubench_valu build/ubench_gather
 hosttest: build/test_host_mirror build/test_lane_ops build/test_report
 cli: build/comparator build/ply_dump
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_order.hpp include/pcc_nn.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 

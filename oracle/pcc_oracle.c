@@ -211,6 +211,55 @@ static void middle_split(const orc_kdtree *t, int *ind, int count, int *index,
     else *index = count / 2;
 }
 
+/* KDTreeSingleIndex::middleSplit_ -- the rule FLANN 1.8.x's divideTree calls, restated from memory of
+ * flann/algorithms/kdtree_single_index.h (1.8.4); like everything FLANN here it cannot be checked against the real
+ * source in this image.  Differences from middleSplit: the cut dimension is chosen among the sides within
+ * (1 - 1e-5) of the widest side of the BOX by the largest spread of the POINTS, and the cut value is the middle of the
+ * BOX side, clamped into the points' range.  1.8.4 as recalled passes `cutfeat` (not the loop variable) to
+ * computeMinMax inside the selection loop -- rule 0 keeps that; rule 2 is the form with the loop variable (nanoflann's
+ * later correction). */
+static void middle_split_(const orc_kdtree *t, int *ind, int count, int *index,
+                          int *cutfeat, float *cutval, const interval_t *bbox, int fixed) {
+    const float EPS = 0.00001f;
+    float max_span = bbox[0].high - bbox[0].low;
+    for (int i = 1; i < 3; ++i) {
+        float span = bbox[i].high - bbox[i].low;
+        if (span > max_span) max_span = span;
+    }
+    float max_spread = -1;
+    *cutfeat = 0;
+    for (int i = 0; i < 3; ++i) {
+        float span = bbox[i].high - bbox[i].low;
+        if (span > (float)((1 - EPS) * max_span)) {
+            float mn, mx;
+            compute_minmax(t, ind, count, fixed ? i : *cutfeat, &mn, &mx);
+            float spread = mx - mn;
+            if (spread > max_spread) {
+                *cutfeat = i;
+                max_spread = spread;
+            }
+        }
+    }
+    float split_val = (bbox[*cutfeat].low + bbox[*cutfeat].high) / 2;
+    float mn, mx;
+    compute_minmax(t, ind, count, *cutfeat, &mn, &mx);
+    if (split_val < mn) *cutval = mn;
+    else if (split_val > mx) *cutval = mx;
+    else *cutval = split_val;
+    int lim1, lim2;
+    plane_split(t, ind, count, *cutfeat, *cutval, &lim1, &lim2);
+    if (lim1 > count / 2) *index = lim1;
+    else if (lim2 < count / 2) *index = lim2;
+    else *index = count / 2;
+}
+
+/* which rule divide_tree uses: 0 middleSplit_ (default: what FLANN 1.8.x's divideTree is believed to call), 1 middleSplit
+ * (SURVEY 9.2), 2 middleSplit_ with the loop variable in the selection loop.  The choice shapes the tree, hence which of
+ * several EQUALLY near points a search names -- never a distance. */
+static int g_split_rule = 0;
+void orc_set_split_rule(int rule) { g_split_rule = rule; }
+int orc_get_split_rule(void) { return g_split_rule; }
+
 /* KDTreeSingleIndex::divideTree */
 static int divide_tree(orc_kdtree *t, int left, int right, interval_t *bbox) {
     int ni = new_node(t);
@@ -228,7 +277,8 @@ static int divide_tree(orc_kdtree *t, int left, int right, interval_t *bbox) {
     } else {
         int idx, cutfeat;
         float cutval;
-        middle_split(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, bbox);
+        if (g_split_rule == 1) middle_split(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, bbox);
+        else middle_split_(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, bbox, g_split_rule == 2);
         interval_t lb[3], rb[3];
         memcpy(lb, bbox, sizeof(lb));
         memcpy(rb, bbox, sizeof(rb));

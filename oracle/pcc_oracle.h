@@ -48,6 +48,10 @@ void orc_radius_count_exhaustive(const void *ref, size_t m, size_t rstride,
 typedef struct orc_kdtree orc_kdtree;
 /* Builds on the finite points of the cloud (leaf_max_size 15, middle split,
  * reorder).  Returns NULL when no valid point exists (PCL prints an error). */
+/* split rule of the trees built from now on: 0 middleSplit_ (default), 1 middleSplit, 2 middleSplit_ with the loop
+ * variable in its selection loop (pcc_oracle.c) */
+void orc_set_split_rule(int rule);
+int orc_get_split_rule(void);
 orc_kdtree *orc_kdtree_build(const void *pts, size_t m, size_t stride);
 void orc_kdtree_free(orc_kdtree *t);
 size_t orc_kdtree_size(const orc_kdtree *t);

@@ -142,6 +142,16 @@ def radius_count_exhaustive(ref, qry, radius):
     return cnt
 
 
+def set_split_rule(rule: int) -> None:
+    """which FLANN split rule the trees built from now on use (0 middleSplit_, 1 middleSplit, 2 middleSplit_ with the
+    loop variable): shapes the tree, hence tie order, never a distance"""
+    lib().orc_set_split_rule(int(rule))
+
+
+def get_split_rule() -> int:
+    return int(lib().orc_get_split_rule())
+
+
 class KdTree:
     """FLANN KDTreeSingleIndex restatement behind pcl::KdTreeFLANN semantics."""
 

@@ -201,61 +201,6 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     return st;
 }
 
-__global__ void __launch_bounds__(256)
-k_patch_keys(unsigned long long* __restrict__ keys, const uint2* __restrict__ patch, unsigned int n) {
-    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) keys[patch[t].x] = (keys[patch[t].x] & 0xffffffff00000000ull) | patch[t].y;
-}
-
-// PCC_TIES_FLANN: rewrite the index part of the keys of tied queries (ix->out_packed, queries in ix->q_packed)
-static int resolve_ties_flann(pcc_index* ix, size_t nq) {
-    ix->ties_flagged = ix->ties_changed = 0;
-    if (nq == 0) return PCC_OK;
-    PCC_TRY(ix->tie_buf.reserve(nq + nq * sizeof(uint2) + 256));
-    uint8_t* dflags = ix->tie_buf.as<uint8_t>();
-    PCC_TRY(launch_tie_flags(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq, dflags));
-    PCC_TRY(ix->host_b.reserve(nq));
-    uint8_t* hflags = ix->host_b.as<uint8_t>();
-    PCC_HIP(hipMemcpyAsync(hflags, dflags, nq, hipMemcpyDeviceToHost, ix->stream));
-    PCC_HIP(hipStreamSynchronize(ix->stream));
-    std::vector<uint32_t> tied;
-    for (size_t i = 0; i < nq; ++i)
-        if (hflags[i]) tied.push_back((uint32_t)i);
-    ix->ties_flagged = tied.size();
-    if (tied.empty()) return PCC_OK;
-    if (!ix->flann_valid) {  // FLANN's tree over the indexed cloud, from the packed copy on the device
-        std::vector<float> packed(ix->n_orig * 4);
-        PCC_HIP(hipMemcpyAsync(packed.data(), ix->refs.p, packed.size() * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-        PCC_HIP(hipStreamSynchronize(ix->stream));
-        ix->flann.build(packed.data(), ix->n_orig);
-        ix->flann_valid = true;
-    }
-    std::vector<float4> hq(nq);
-    std::vector<unsigned long long> hk(nq);
-    PCC_HIP(hipMemcpyAsync(hq.data(), ix->q_packed.p, nq * sizeof(float4), hipMemcpyDeviceToHost, ix->stream));
-    PCC_HIP(hipMemcpyAsync(hk.data(), ix->out_packed.p, nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, ix->stream));
-    PCC_HIP(hipStreamSynchronize(ix->stream));
-    std::vector<uint2> patch;
-    for (uint32_t i : tied) {
-        const float qv[3] = {hq[i].x, hq[i].y, hq[i].z};
-        float d2 = 0.f;
-        const int32_t fi = ix->flann.nearest(qv, &d2);
-        uint32_t bits;
-        memcpy(&bits, &d2, 4);
-        // same arithmetic => same minimum; should the bits ever differ the GPU result stands
-        if (fi >= 0 && bits == (uint32_t)(hk[i] >> 32) && (uint32_t)fi != (uint32_t)hk[i]) patch.push_back(make_uint2(i, (uint32_t)fi));
-    }
-    ix->ties_changed = patch.size();
-    if (patch.empty()) return PCC_OK;
-    uint2* dpatch = reinterpret_cast<uint2*>(ix->tie_buf.as<uint8_t>() + ((nq + 15) & ~(size_t)15));
-    PCC_HIP(hipMemcpyAsync(dpatch, patch.data(), patch.size() * sizeof(uint2), hipMemcpyHostToDevice, ix->stream));
-    hipLaunchKernelGGL(k_patch_keys, dim3((unsigned int)((patch.size() + 255) / 256)), dim3(256), 0, ix->stream,
-                       ix->out_packed.as<unsigned long long>(), dpatch, (unsigned int)patch.size());
-    PCC_HIP(hipGetLastError());
-    PCC_HIP(hipStreamSynchronize(ix->stream));  // `patch` is pageable host memory
-    return PCC_OK;
-}
-
 }  // namespace pcc
 
 using namespace pcc;
@@ -280,7 +225,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -518,6 +463,7 @@ int pcc_index_set_option(pcc_index* ix, int option, double value) {
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
         case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 3; break;
         case PCC_OPT_NN1_DENSE_MIN: ok = value >= 1 && value <= 1000000; break;
+        case PCC_OPT_FLANN_SPLIT: ok = value >= 0 && value <= 2; break;
         default: ok = value == 0 || value == 1; break;
     }
     if (!ok) { set_error("option %d: value %g out of range", option, value); return PCC_ERR_INVALID; }
@@ -545,6 +491,17 @@ int pcc_index_stats(const pcc_index* cix, uint64_t stats[8]) {
         ix->stats[1] = static_cast<unsigned int*>(ix->pinned)[40];
         ix->stats[0] = ix->last_nq - ix->stats[1];
     }
+    if (ix->ties_pending) {  // the sharded counters of the last search in FLANN mode
+        unsigned int h[PCC_TIE_SHARDS * PCC_OPEN_CTR_STRIDE];
+        PCC_HIP(hipMemcpyAsync(h, ix->small.as<unsigned int>() + PCC_TIE_CTR0, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        ix->ties_flagged = ix->ties_changed = 0;
+        for (int sh = 0; sh < PCC_TIE_SHARDS; ++sh) {
+            ix->ties_flagged += h[sh * PCC_OPEN_CTR_STRIDE];
+            ix->ties_changed += h[sh * PCC_OPEN_CTR_STRIDE + 1];
+        }
+        ix->ties_pending = false;
+    }
     ix->stats[5] = ix->ties_flagged;
     ix->stats[6] = ix->ties_changed;
     memcpy(stats, ix->stats, sizeof(ix->stats));
@@ -560,7 +517,7 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, q, nq, stride, mem));
     PCC_TRY(nn1_packed(ix, nq));
-    if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, nq));
+    if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq));
     int32_t* didx = idx;
     float* dd2 = d2;
     if (mem == PCC_MEM_HOST) {
@@ -1149,7 +1106,7 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
     PCC_TRY(nn1_packed(ix, n2));
-    if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, n2));
+    if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), n2));
     PCC_TRY(ix->out_idx.reserve(n2 * sizeof(int32_t)));
     PCC_TRY(ix->out_d2.reserve(n2 * sizeof(float)));
     PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n2, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));

@@ -1,203 +1,41 @@
-// flann_order.hip -- host-side restatement of FLANN 1.8 KDTreeSingleIndex (build + exact k = 1 search) used to
-// resolve exact-distance ties the way pcl::KdTreeFLANN does (see flann_order.hpp), and the kernels that flag the
-// tied queries.  Host code here is compiled by hipcc with -ffp-contract=off: the distances must round like
-// FLANN's L2_Simple<float>.
-#include "flann_order.hpp"
+// flann_order.hip -- PCC_TIES_FLANN on the device: the kernels that flag the queries whose minimum distance is shared by
+// a second reference, and the kernel that walks those through a kd-tree of FLANN's shape (flann_tree.hpp: built on the
+// host once per indexed cloud, uploaded as two flat arrays).  Nothing is copied back per call and the host never waits:
+// a search in FLANN mode costs the two kernels.  Compiled with -ffp-contract=off: the distances must round like FLANN's
+// L2_Simple<float>.  Reference call sites: src/comparator.cpp:576-580 (the indices matchRIFTFeaturesKnn hands on).
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
 #include <cfloat>
 #include <cstring>
+#include <thread>
 
 namespace pcc {
 
-static constexpr int32_t FLANN_LEAF_MAX = 15;  // KDTreeSingleIndexParams(15), pcl::KdTreeFLANN::setInputCloud
-
-static inline float l2_simple(const float* a, const float* b) {
-    float r = 0.f;
-    for (int i = 0; i < 3; ++i) { const float d = a[i] - b[i]; r += d * d; }
-    return r;
-}
-static inline bool is_valid_w(float w) {
-    uint32_t u;
-    memcpy(&u, &w, 4);
-    return (u >> 31) == 0;
-}
-
-void FlannOrder::minmax(const int32_t* ind, int32_t count, int dim, float& mn, float& mx) const {
-    mn = mx = pts_[(size_t)ind[0] * 3 + dim];
-    for (int32_t i = 1; i < count; ++i) {
-        const float v = pts_[(size_t)ind[i] * 3 + dim];
-        if (v < mn) mn = v;
-        if (v > mx) mx = v;
-    }
-}
-
-// indices rearranged into  < cutval | == cutval | > cutval ; lim1 / lim2 are the two boundaries
-void FlannOrder::planeSplit(int32_t* ind, int32_t count, int cutfeat, float cutval, int32_t& lim1, int32_t& lim2) const {
-    auto at = [&](int32_t k) { return pts_[(size_t)ind[k] * 3 + cutfeat]; };
-    int32_t lo = 0, hi = count - 1;
-    for (;;) {
-        while (lo <= hi && at(lo) < cutval) ++lo;
-        while (lo <= hi && at(hi) >= cutval) --hi;
-        if (lo > hi) break;
-        const int32_t t = ind[lo]; ind[lo] = ind[hi]; ind[hi] = t;
-        ++lo; --hi;
-    }
-    lim1 = lo;
-    hi = count - 1;
-    for (;;) {
-        while (lo <= hi && at(lo) <= cutval) ++lo;
-        while (lo <= hi && at(hi) > cutval) --hi;
-        if (lo > hi) break;
-        const int32_t t = ind[lo]; ind[lo] = ind[hi]; ind[hi] = t;
-        ++lo; --hi;
-    }
-    lim2 = lo;
-}
-
-// split dimension: the widest side of the (approximate) box, corrected by the exact spread of the points; the cut
-// is the middle of the exact range; the split position is the middle of the run of points equal to the cut when
-// that run straddles count / 2, else its nearer end
-void FlannOrder::middleSplit(int32_t* ind, int32_t count, int32_t& index, int& cutfeat, float& cutval, const Interval bbox[3]) const {
-    float max_span = bbox[0].high - bbox[0].low;
-    cutfeat = 0;
-    for (int i = 1; i < 3; ++i) {
-        const float span = bbox[i].high - bbox[i].low;
-        if (span > max_span) { max_span = span; cutfeat = i; }
-    }
-    float mn, mx;
-    minmax(ind, count, cutfeat, mn, mx);
-    cutval = (mn + mx) / 2;
-    max_span = mx - mn;
-    const int first = cutfeat;
-    for (int i = 0; i < 3; ++i) {
-        if (i == first) continue;
-        if (bbox[i].high - bbox[i].low > max_span) {
-            minmax(ind, count, i, mn, mx);
-            if (mx - mn > max_span) { max_span = mx - mn; cutfeat = i; cutval = (mn + mx) / 2; }
-        }
-    }
-    int32_t lim1, lim2;
-    planeSplit(ind, count, cutfeat, cutval, lim1, lim2);
-    if (lim1 > count / 2) index = lim1;
-    else if (lim2 < count / 2) index = lim2;
-    else index = count / 2;
-}
-
-int32_t FlannOrder::divide(int32_t left, int32_t right, Interval bbox[3]) {
-    const int32_t me = (int32_t)nodes_.size();
-    nodes_.push_back(Node());
-    if (right - left <= FLANN_LEAF_MAX) {
-        nodes_[me].left = left;
-        nodes_[me].right = right;
-        for (int d = 0; d < 3; ++d) bbox[d].low = bbox[d].high = pts_[(size_t)vind_[left] * 3 + d];
-        for (int32_t k = left + 1; k < right; ++k)
-            for (int d = 0; d < 3; ++d) {
-                const float v = pts_[(size_t)vind_[k] * 3 + d];
-                if (v < bbox[d].low) bbox[d].low = v;
-                if (v > bbox[d].high) bbox[d].high = v;
-            }
-        return me;
-    }
-    int32_t idx;
-    int cutfeat;
-    float cutval;
-    middleSplit(vind_.data() + left, right - left, idx, cutfeat, cutval, bbox);
-    Interval lb[3], rb[3];
-    memcpy(lb, bbox, sizeof(lb));
-    memcpy(rb, bbox, sizeof(rb));
-    lb[cutfeat].high = cutval;
-    const int32_t c1 = divide(left, left + idx, lb);
-    rb[cutfeat].low = cutval;
-    const int32_t c2 = divide(left + idx, right, rb);
-    Node& nd = nodes_[me];  // (after the recursion: the vector may have moved)
-    nd.child1 = c1;
-    nd.child2 = c2;
-    nd.divfeat = cutfeat;
-    nd.divlow = lb[cutfeat].high;   // the children have tightened their boxes
-    nd.divhigh = rb[cutfeat].low;
-    for (int d = 0; d < 3; ++d) {
-        bbox[d].low = lb[d].low < rb[d].low ? lb[d].low : rb[d].low;
-        bbox[d].high = lb[d].high > rb[d].high ? lb[d].high : rb[d].high;
-    }
-    return me;
-}
-
-void FlannOrder::build(const float* packed, size_t n) {
-    n_ = 0;
-    pts_.clear(); map_.clear(); vind_.clear(); data_.clear(); nodes_.clear();
-    root_ = -1;
-    for (size_t i = 0; i < n; ++i) {
-        const float* p = packed + i * 4;
-        if (!is_valid_w(p[3])) continue;  // convertCloudToArray: invalid points are skipped, order kept
-        pts_.push_back(p[0]); pts_.push_back(p[1]); pts_.push_back(p[2]);
-        map_.push_back((int32_t)i);
-    }
-    n_ = map_.size();
-    if (n_ == 0) return;
-    vind_.resize(n_);
-    for (size_t i = 0; i < n_; ++i) vind_[i] = (int32_t)i;
-    for (int d = 0; d < 3; ++d) minmax(vind_.data(), (int32_t)n_, d, root_bbox_[d].low, root_bbox_[d].high);
-    Interval bb[3];
-    memcpy(bb, root_bbox_, sizeof(bb));
-    nodes_.reserve(n_ / 4 + 16);
-    root_ = divide(0, (int32_t)n_, bb);
-    data_.resize(n_ * 3);
-    for (size_t i = 0; i < n_; ++i) memcpy(&data_[i * 3], &pts_[(size_t)vind_[i] * 3], 3 * sizeof(float));
-}
-
-void FlannOrder::searchLevel(const float q[3], int32_t ni, float mindistsq, float dists[3], float& worst, int32_t& best) const {
-    const Node& nd = nodes_[ni];
-    if (nd.child1 < 0) {
-        for (int32_t i = nd.left; i < nd.right; ++i) {
-            const float d = l2_simple(q, &data_[(size_t)i * 3]);
-            if (d < worst) { worst = d; best = vind_[i]; }  // k = 1: an equal distance never displaces the earlier point
-        }
-        return;
-    }
-    const int f = nd.divfeat;
-    const float val = q[f];
-    const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
-    int32_t near_child, far_child;
-    float cut;
-    if (diff1 + diff2 < 0) { near_child = nd.child1; far_child = nd.child2; cut = (val - nd.divhigh) * (val - nd.divhigh); }
-    else { near_child = nd.child2; far_child = nd.child1; cut = (val - nd.divlow) * (val - nd.divlow); }
-    searchLevel(q, near_child, mindistsq, dists, worst, best);
-    const float saved = dists[f];
-    mindistsq = mindistsq + cut - saved;
-    dists[f] = cut;
-    if (mindistsq <= worst) searchLevel(q, far_child, mindistsq, dists, worst, best);  // epsError = 1 (exact search)
-    dists[f] = saved;
-}
-
-int32_t FlannOrder::nearest(const float q[3], float* d2) const {
-    if (n_ == 0) { if (d2) *d2 = FLT_MAX; return -1; }
-    float dists[3] = {0.f, 0.f, 0.f};
-    float distsq = 0.f;
-    for (int i = 0; i < 3; ++i) {  // computeInitialDistances: the part of the query outside the root box
-        if (q[i] < root_bbox_[i].low) { dists[i] = (q[i] - root_bbox_[i].low) * (q[i] - root_bbox_[i].low); distsq += dists[i]; }
-        if (q[i] > root_bbox_[i].high) { dists[i] = (q[i] - root_bbox_[i].high) * (q[i] - root_bbox_[i].high); distsq += dists[i]; }
-    }
-    float worst = FLT_MAX;
-    int32_t best = -1;
-    searchLevel(q, root_, distsq, dists, worst, best);
-    if (d2) *d2 = worst;
-    return best < 0 ? -1 : map_[(size_t)best];
-}
-
 // ---- which queries have a tie ------------------------------------------------------------------------------
-// keys[i] = (d2 bits << 32 | index) of the nearest reference.  flags[i] = 1 when some OTHER reference has exactly
-// the same d2 (or when that cannot be decided cheaply: ball wider than the cell walk allows).
+// keys[i] = (d2 bits << 32 | index) of the nearest reference.  A query is TIED when some OTHER reference has exactly
+// the same d2 (or when that cannot be decided cheaply: ball wider than the cell walk allows).  The tied queries are
+// appended to a compact list (one returning atomic per wave, PCC_TIE_SHARDS counters each owning a slice of the list):
+// the tree walk then runs with every lane busy instead of one lane in ten.
+__device__ __forceinline__ void tie_append(bool tie, unsigned int i, unsigned int* __restrict__ list, unsigned int* __restrict__ counters,
+                                           unsigned int shard_cap) {
+    const unsigned long long m = __ballot(tie);
+    if (m == 0ull) return;
+    const unsigned int shard = blockIdx.x % PCC_TIE_SHARDS;
+    unsigned int base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counters + shard * PCC_OPEN_CTR_STRIDE, (unsigned int)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (tie) list[shard * shard_cap + base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = i;
+}
+
 __global__ void __launch_bounds__(256)
 k_tie_flags_grid(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                  const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned long long* __restrict__ keys,
-                 unsigned int n, uint8_t* __restrict__ flags) {
+                 unsigned int n, unsigned int* __restrict__ list, unsigned int* __restrict__ counters, unsigned int shard_cap) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const GridParams g = gd->g;
-    const float4 qv = q[i];
-    const unsigned long long key = keys[i];
-    if (__float_as_int(qv.w) < 0 || key_none(key)) { flags[i] = 0; return; }
+    const float4 qv = i < n ? q[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    const unsigned long long key = i < n ? keys[i] : ~0ull;
+    if (__float_as_int(qv.w) < 0 || key_none(key)) { tie_append(false, i, list, counters, shard_cap); return; }
     const float bd = __uint_as_float((unsigned int)(key >> 32));
     const unsigned int bi = (unsigned int)key;
     const float rb = sqrtf(bd) * 1.00001f + gd->slack;
@@ -205,8 +43,7 @@ k_tie_flags_grid(const float4* __restrict__ cell_refs, const unsigned int* __res
     cell_range(qv.x, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
     cell_range(qv.y, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
     cell_range(qv.z, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
-    if (!(rb < __builtin_inff()) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 4096) { flags[i] = 1; return; }
-    bool tie = false;
+    bool tie = !(rb < __builtin_inff()) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 4096;
     for (int z = z0; z <= z1 && !tie; ++z)
         for (int y = y0; y <= y1 && !tie; ++y) {
             const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
@@ -216,18 +53,18 @@ k_tie_flags_grid(const float4* __restrict__ cell_refs, const unsigned int* __res
                 if (dist2(qv.x, qv.y, qv.z, r) == bd && (unsigned int)__float_as_int(r.w) != bi) { tie = true; break; }
             }
         }
-    flags[i] = tie ? 1 : 0;
+    tie_append(tie, i, list, counters, shard_cap);
 }
 
 // exhaustive form (BRUTE engine: small clouds): one lane per query over all references
 __global__ void __launch_bounds__(256)
 k_tie_flags_brute(const float4* __restrict__ refs, unsigned int m, const float4* __restrict__ q,
-                  const unsigned long long* __restrict__ keys, unsigned int n, uint8_t* __restrict__ flags) {
+                  const unsigned long long* __restrict__ keys, unsigned int n, unsigned int* __restrict__ list,
+                  unsigned int* __restrict__ counters, unsigned int shard_cap) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 qv = q[i];
-    const unsigned long long key = keys[i];
-    if (__float_as_int(qv.w) < 0 || key_none(key)) { flags[i] = 0; return; }
+    const float4 qv = i < n ? q[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    const unsigned long long key = i < n ? keys[i] : ~0ull;
+    if (__float_as_int(qv.w) < 0 || key_none(key)) { tie_append(false, i, list, counters, shard_cap); return; }
     const float bd = __uint_as_float((unsigned int)(key >> 32));
     const unsigned int bi = (unsigned int)key;
     bool tie = false;
@@ -235,19 +72,135 @@ k_tie_flags_brute(const float4* __restrict__ refs, unsigned int m, const float4*
         const float4 r = refs[p];
         if (__float_as_int(r.w) >= 0 && p != bi && dist2(qv.x, qv.y, qv.z, r) == bd) tie = true;
     }
-    flags[i] = tie ? 1 : 0;
+    tie_append(tie, i, list, counters, shard_cap);
 }
 
-int launch_tie_flags(pcc_index* ix, const float4* q, const unsigned long long* keys, size_t nq, uint8_t* flags) {
-    if (nq == 0) return PCC_OK;
+// list: PCC_TIE_SHARDS slices of shard_cap entries; counters[shard * PCC_OPEN_CTR_STRIDE] = entries of the slice (pre-zeroed)
+static int launch_tie_list(pcc_index* ix, const float4* q, const unsigned long long* keys, size_t nq, unsigned int* list,
+                           unsigned int* counters, unsigned int shard_cap) {
     const unsigned int n = (unsigned int)nq, blocks = (n + 255) / 256;
     if (ix->engine == PCC_ENGINE_GRID && ix->has_grid)
         hipLaunchKernelGGL(k_tie_flags_grid, dim3(blocks), dim3(256), 0, ix->stream, ix->cell_refs.as<float4>(),
-                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, keys, n, flags);
+                           ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, keys, n, list, counters, shard_cap);
     else
         hipLaunchKernelGGL(k_tie_flags_brute, dim3(blocks), dim3(256), 0, ix->stream, ix->refs.as<float4>(),
-                           (unsigned int)ix->n_orig, q, keys, n, flags);
+                           (unsigned int)ix->n_orig, q, keys, n, list, counters, shard_cap);
     PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+
+// flagged queries through the tree: the index part of a key is replaced when FLANN's walk names another reference at
+// the SAME distance bits (same arithmetic => same minimum; should the bits ever differ the GPU result stands).
+// counters: PCC_TIE_SHARDS x {flagged, changed, too deep}, one 128-byte line per shard
+template <int STACK>
+__global__ void __launch_bounds__(256)
+k_tie_walk(const FlannNode* __restrict__ nodes, const float* __restrict__ leaf_pts, FlannBox root, unsigned int n_valid,
+           const float4* __restrict__ q, unsigned long long* __restrict__ keys, const unsigned int* __restrict__ list,
+           unsigned int shard_cap, unsigned int* __restrict__ counters) {
+    // block b works on slice b % PCC_TIE_SHARDS of the list, as chunk b / PCC_TIE_SHARDS of gridDim / PCC_TIE_SHARDS
+    const unsigned int shard = blockIdx.x % PCC_TIE_SHARDS, chunk = blockIdx.x / PCC_TIE_SHARDS, nchunk = gridDim.x / PCC_TIE_SHARDS;
+    unsigned int* c = counters + shard * PCC_OPEN_CTR_STRIDE;
+    const unsigned int cnt = c[0];
+    for (unsigned int j0 = chunk * blockDim.x; j0 < cnt; j0 += nchunk * blockDim.x) {  // (block-uniform trip count)
+        const unsigned int j = j0 + threadIdx.x;
+        bool changed = false;
+        if (j < cnt) {
+            const unsigned int i = list[shard * shard_cap + j];
+            const float4 qv = q[i];
+            const unsigned long long key = keys[i];
+            float d2 = 0.f;
+            const int32_t fi = flann_walk<STACK>(nodes, leaf_pts, root, n_valid, qv.x, qv.y, qv.z, &d2);
+            if (fi >= 0 && __float_as_uint(d2) == (unsigned int)(key >> 32) && (unsigned int)fi != (unsigned int)key) {
+                keys[i] = (key & 0xffffffff00000000ull) | (unsigned int)fi;
+                changed = true;
+            }
+        }
+        const unsigned long long mc = __ballot(changed);
+        if ((threadIdx.x & 63) == 0 && mc) atomicAdd(c + 1, (unsigned int)__popcll(mc));
+    }
+}
+
+// FLANN's tree over the indexed cloud, from the packed copy on the device; uploaded as flat arrays
+static int ensure_tree(pcc_index* ix) {
+    if (ix->flann_valid) return PCC_OK;
+    PCC_TRY(ix->host_a.reserve(ix->n_orig * sizeof(float4)));
+    PCC_HIP(hipMemcpyAsync(ix->host_a.p, ix->refs.p, ix->n_orig * sizeof(float4), hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    unsigned int threads = std::thread::hardware_concurrency();
+    threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    ix->flann.build(ix->host_a.as<float>(), ix->n_orig, ix->opt.flann_split, ix->n_orig >= 50000 ? threads : 1);
+    PCC_TRY(ix->flann_nodes.reserve(ix->flann.nodes.size() * sizeof(FlannNode) + 16));
+    PCC_TRY(ix->flann_leaf.reserve(ix->flann.leaf_pts.size() * sizeof(float) + 16));
+    PCC_HIP(hipMemcpyAsync(ix->flann_nodes.p, ix->flann.nodes.data(), ix->flann.nodes.size() * sizeof(FlannNode), hipMemcpyHostToDevice, ix->stream));
+    PCC_HIP(hipMemcpyAsync(ix->flann_leaf.p, ix->flann.leaf_pts.data(), ix->flann.leaf_pts.size() * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    PCC_HIP(hipStreamSynchronize(ix->stream));  // (the vectors are pageable host memory)
+    if (ix->flann.depth <= FLANN_DEV_STACK_MAX) {  // the host copy is only needed for trees the device stack cannot hold
+        std::vector<FlannNode>().swap(ix->flann.nodes);
+        std::vector<float>().swap(ix->flann.leaf_pts);
+    }
+    ix->flann_valid = true;
+    return PCC_OK;
+}
+
+// PCC_TIES_FLANN: rewrite the index part of the keys of tied queries (keys of the queries in q, nq of them)
+int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq) {
+    if (nq == 0) return PCC_OK;
+    PCC_TRY(ensure_tree(ix));
+    const unsigned int n = (unsigned int)nq, blocks = (n + 255) / 256;
+    const unsigned int shard_cap = (blocks + PCC_TIE_SHARDS - 1) / PCC_TIE_SHARDS * 256;  // what a slice's blocks could append
+    PCC_TRY(ix->tie_buf.reserve((size_t)shard_cap * PCC_TIE_SHARDS * sizeof(unsigned int) + 256));
+    unsigned int* list = ix->tie_buf.as<unsigned int>();
+    unsigned int* counters = ix->small.as<unsigned int>() + PCC_TIE_CTR0;
+    PCC_HIP(hipMemsetAsync(counters, 0, PCC_TIE_SHARDS * PCC_OPEN_CTR_STRIDE * 4, ix->stream));
+    PCC_TRY(launch_tie_list(ix, q, keys, nq, list, counters, shard_cap));
+    const FlannNode* nodes = ix->flann_nodes.as<FlannNode>();
+    const float* leaf = ix->flann_leaf.as<float>();
+    const unsigned int nv = (unsigned int)ix->flann.n_valid;
+    // blocks per slice: enough for every query to be listed without a second trip, at most 32
+    unsigned int chunks = (shard_cap / 8 + 255) / 256;
+    chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
+    const dim3 wg(chunks * PCC_TIE_SHARDS);
+    // the walk defers one far child per level: a stack of the tree's depth always suffices
+    if (ix->flann.depth <= 48)
+        hipLaunchKernelGGL(k_tie_walk<48>, wg, dim3(256), 0, ix->stream, nodes, leaf, ix->flann.root, nv, q, keys, list, shard_cap, counters);
+    else if (ix->flann.depth <= 128)
+        hipLaunchKernelGGL(k_tie_walk<128>, wg, dim3(256), 0, ix->stream, nodes, leaf, ix->flann.root, nv, q, keys, list, shard_cap, counters);
+    else if (ix->flann.depth <= FLANN_DEV_STACK_MAX)
+        hipLaunchKernelGGL(k_tie_walk<FLANN_DEV_STACK_MAX>, wg, dim3(256), 0, ix->stream, nodes, leaf, ix->flann.root, nv, q, keys, list, shard_cap, counters);
+    else {
+        // a tree deeper than any device stack (coordinates spread over hundreds of binades): the host walks the listed
+        // queries -- synchronous, and only here
+        std::vector<unsigned int> hl((size_t)shard_cap * PCC_TIE_SHARDS), hc(PCC_TIE_SHARDS * PCC_OPEN_CTR_STRIDE);
+        std::vector<float4> hq(nq);
+        std::vector<unsigned long long> hk(nq);
+        PCC_HIP(hipMemcpyAsync(hl.data(), list, hl.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipMemcpyAsync(hc.data(), counters, hc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipMemcpyAsync(hq.data(), q, nq * sizeof(float4), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipMemcpyAsync(hk.data(), keys, nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        unsigned int n_changed = 0;
+        for (int sh = 0; sh < PCC_TIE_SHARDS; ++sh)
+            for (unsigned int j = 0; j < hc[sh * PCC_OPEN_CTR_STRIDE]; ++j) {
+                const unsigned int i = hl[(size_t)sh * shard_cap + j];
+                const float qv[3] = {hq[i].x, hq[i].y, hq[i].z};
+                float d2 = 0.f;
+                const int32_t fi = ix->flann.nearest(qv, &d2);
+                uint32_t bits;
+                memcpy(&bits, &d2, 4);
+                if (fi >= 0 && bits == (uint32_t)(hk[i] >> 32) && (uint32_t)fi != (uint32_t)hk[i]) {
+                    hk[i] = (hk[i] & 0xffffffff00000000ull) | (uint32_t)fi;
+                    ++n_changed;
+                }
+            }
+        if (n_changed) {
+            PCC_HIP(hipMemcpyAsync(keys, hk.data(), nq * sizeof(unsigned long long), hipMemcpyHostToDevice, ix->stream));
+            PCC_HIP(hipMemcpyAsync(counters + 1, &n_changed, 4, hipMemcpyHostToDevice, ix->stream));
+        }
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    PCC_HIP(hipGetLastError());
+    ix->ties_pending = true;  // pcc_index_stats adds the shards up
     return PCC_OK;
 }
 

@@ -6,7 +6,7 @@
 #include <mutex>
 #include <string>
 #include "pcc_nn.h"
-#include "flann_order.hpp"
+#include "flann_tree.hpp"
 
 // every PCC_SEED_STRIDE-th reference is a "seed": the exhaustive scan of the seeds bounds a far query's ball
 #define PCC_SEED_SHIFT 6
@@ -16,7 +16,11 @@
 #define PCC_OPEN_SHARDS 64
 #define PCC_OPEN_CTR0 1024
 #define PCC_OPEN_CTR_STRIDE 32
-#define PCC_SMALL_BYTES ((PCC_OPEN_CTR0 + PCC_OPEN_SHARDS * PCC_OPEN_CTR_STRIDE) * 4)
+// [PCC_TIE_CTR0 + s * PCC_OPEN_CTR_STRIDE + {0, 1}] queries listed as tied / indices changed, per slice of the tie list (PCC_TIES_FLANN)
+#define PCC_TIE_SHARDS 16
+#define PCC_TIE_CTR0 (PCC_OPEN_CTR0 + PCC_OPEN_SHARDS * PCC_OPEN_CTR_STRIDE)
+#define PCC_SMALL_BYTES ((PCC_TIE_CTR0 + PCC_TIE_SHARDS * PCC_OPEN_CTR_STRIDE) * 4)
+#define FLANN_DEV_STACK_MAX 256  // deepest tree k_tie_walk takes (20 bytes of scratch per level and lane)
 
 namespace pcc {
 
@@ -142,11 +146,13 @@ struct pcc_index {
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
         scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, icp_state, vox_a, vox_b, vox_c,
         mp_a, mp_b, mp_c;  // cellsort_mp.hip: two intermediate point buffers, bucket counters
-    // PCC_TIES_FLANN (flann_order.hpp): host-side kd-tree in FLANN's shape, built on first use after every set_input
+    // PCC_TIES_FLANN (flann_tree.hpp): kd-tree of FLANN's shape, built on the host at the first search after every
+    // set_input, walked on the device (flann_order.hip)
     int tie_mode = PCC_TIES_LOWEST_INDEX;
-    pcc::FlannOrder flann;
+    pcc::FlannTree flann;
     bool flann_valid = false;
-    pcc::DevBuf tie_buf;
+    pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
+    bool ties_pending = false;                    // the tie counters of the last search are still on the device
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     pcc::HostBuf host_a, host_b;  // large pinned read-back buffers
@@ -261,8 +267,9 @@ int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, 
 // ---- cluster.hip ------------------------------------------------------------------------
 int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t max_size,
                   int32_t* labels_dev /* n_orig, device */, int32_t* n_clusters, int32_t* sizes, int max_sizes);
-// ---- flann_order.hip: flags[i] = 1 when another reference shares query i's minimum distance --------
-int launch_tie_flags(pcc_index* ix, const float4* q, const unsigned long long* keys, size_t nq, uint8_t* flags);
+// ---- flann_order.hip: flags[i] = 1 when another reference shares query i's minimum distance; the tied queries walked
+// through FLANN's tree on the device
+int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq);
 // ---- icp.hip -----------------------------------------------------------------------------
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,

@@ -4,6 +4,9 @@ import subprocess
 import sys
 from pathlib import Path
 
+import numpy as np
+import pytest
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -50,3 +53,58 @@ def test_bench_configs_match_baseline_json():
     assert bench.CONFIGS["c4"][:2] == (2_000_000, 2_000_000)
     assert bench.CONFIGS["c5"][0] == 8_000_000 and bench.C5_TOTAL_QUERIES == 32_000_000
     assert bench.C5_TOTAL_QUERIES // 8 == bench.CONFIGS["c5"][1]       # 8 shards of 4M
+
+
+def _flann_tree_answers(tmp_path, pts, qs, rule, threads):
+    """indices and d2 bits from the PRODUCT's tree (csrc/flann_tree.hpp: iterative build, flat nodes, explicit-stack
+    walk) through its g++-built self-test program"""
+    import subprocess
+    exe = ROOT / "build" / "test_flann_tree"
+    src = ROOT / "tests" / "cpp" / "test_flann_tree.cpp"
+    hdr = ROOT / "pointcloudcomparator_amd" / "csrc" / "flann_tree.hpp"
+    if not exe.exists() or exe.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        exe.parent.mkdir(exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-pthread",
+                               f"-I{hdr.parent}", str(src), "-o", str(exe)])
+    pf, qf = tmp_path / "p.bin", tmp_path / "q.bin"
+    np.ascontiguousarray(pts, np.float32).tofile(pf)
+    np.ascontiguousarray(qs, np.float32).tofile(qf)
+    out = subprocess.check_output([str(exe), str(pf), str(qf), str(rule), str(threads)], text=True)
+    rows = [l.split() for l in out.splitlines() if not l.startswith("#")]
+    return np.array([int(r[0]) for r in rows], np.int64), np.array([int(r[1]) for r in rows], np.uint32)
+
+
+@pytest.mark.parametrize("rule", [0, 1, 2])
+def test_flann_tree_of_the_product_matches_the_oracle_tree(tmp_path, rule):
+    """PCC_TIES_FLANN: the product's kd-tree (iterative build over an explicit stack, flat depth-first node array, top
+    levels forked over threads, explicit-stack walk shared with the device kernel) names the same reference as the
+    oracle's recursive kd-tree for every query, under each of the three split rules -- on clouds made of exact ties
+    (duplicates, lattices, a plane), with non-finite points, and with 1 and 8 build threads.  Two restatements of the
+    same recollection of FLANN agreeing is consistency, not verification against FLANN."""
+    import oracle
+    rng = np.random.default_rng(40 + rule)
+    base = rng.random((6000, 3), dtype=np.float32)
+    dup = np.concatenate([base, base[::-1], base[:1500]])
+    lattice = (rng.integers(0, 14, (20000, 3)) * np.float32(0.25)).astype(np.float32)
+    plane = rng.random((15000, 3), dtype=np.float32)
+    plane[:, 2] = 0.5
+    plane[::3] = np.round(plane[::3] * 8) / 8
+    holes = rng.random((9000, 3), dtype=np.float32)
+    holes[::7, 1] = np.nan
+    holes[5::11, 0] = np.inf
+    skew = (rng.random((12000, 3)) ** 6 * 100).astype(np.float32)  # deep, lopsided trees
+    tiny = rng.random((9, 3), dtype=np.float32)
+    oracle.set_split_rule(rule)
+    try:
+        for name, pts in (("dup", dup), ("lattice", lattice), ("plane", plane), ("holes", holes), ("skew", skew), ("tiny", tiny)):
+            qs = np.concatenate([pts[rng.integers(0, len(pts), 1500)], (rng.random((1500, 3)) * 1.2 - 0.1).astype(np.float32),
+                                 (rng.integers(0, 28, (1000, 3)) * np.float32(0.125)).astype(np.float32)])
+            qs = qs[np.isfinite(qs).all(1)]
+            tree = oracle.KdTree(pts)
+            oi, od = tree.nn1_batch(qs)
+            for threads in (1, 8):
+                pi, pd = _flann_tree_answers(tmp_path, pts, qs, rule, threads)
+                assert (pd == od.view(np.uint32)).all(), (name, rule, threads)
+                assert (pi == oi).all(), (name, rule, threads, np.nonzero(pi != oi)[0][:5])
+    finally:
+        oracle.set_split_rule(0)

@@ -186,6 +186,37 @@ def test_ties_flann_order_equals_the_kdtree_walk(gpu, engine):
             assert (ix.nn1(q)[0] == oracle.nn1_exhaustive(a[::-1].copy(), q)[0]).all()
 
 
+@pytest.mark.parametrize("rule", [0, 1, 2])
+def test_ties_flann_split_rules_and_scale(gpu, rule):
+    """PCC_OPT_FLANN_SPLIT: the tree the tied queries are walked through (on the device, k_tie_walk) is built with
+    middleSplit_ as recalled from FLANN 1.8.4 (0, default), middleSplit (1) or middleSplit_ with the loop variable (2) --
+    each against the oracle's recursive tree under the same rule, on a 300k-point mm-quantised scan with 10 % duplicated
+    points (tens of thousands of tied queries, the forked build) and after switching the rule on a live handle"""
+    import torch
+    n = 300_000
+    a = np.round(synth.room_cloud(n, synth.SEED_A) * 1000) / 1000
+    a[::10] = a[1::10][: len(a[::10])]                      # 10 % exact duplicates
+    a = a.astype(np.float32)
+    q = (np.round(synth.room_cloud(60_000, synth.SEED_B) * 1000) / 1000).astype(np.float32)
+    oracle.set_split_rule(rule)
+    try:
+        fi, fd = oracle.KdTree(a).nn1_batch(q)
+    finally:
+        oracle.set_split_rule(0)
+    li, ld = oracle.nn1_exhaustive(a[:1], q[:1])  # (touch the exhaustive oracle's loader)
+    with capi.Index(torch.from_numpy(a).cuda()) as ix:
+        ix.set_tie_order(capi.TIES_FLANN)
+        if rule != 0:
+            ix.nn1(torch.from_numpy(q[:100]).cuda())          # builds the default tree first: the option must replace it
+        ix.set_option(capi.OPT_FLANN_SPLIT, rule)
+        idx, d2 = ix.nn1(torch.from_numpy(q).cuda())
+        st = ix.stats()
+        idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    assert (_bits(d2) == _bits(fd)).all()
+    assert (idx == fi).all(), (rule, np.nonzero(idx != fi)[0][:5])
+    assert st[5] > 5000 and st[6] > 100, st
+
+
 def test_ties_flann_device_buffers_and_match_knn(gpu):
     import torch
     name, a, q = _tie_clouds()[1]
