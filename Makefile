@@ -45,7 +45,7 @@ build/test_lane_ops: tests/cpp/test_lane_ops.hip $(CSRC)/lane_ops.hpp
 
 build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc/multi_device.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
-	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+	$(CXX) -std=c++17 -O2 -Wall -pthread -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include $< -o $@ -L$(LIBDIR) -lpcc_nn -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 build/comparator: pointcloudcomparator_amd/host/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp pointcloudcomparator_amd/host/report.hpp include/pcc/multi_device.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build

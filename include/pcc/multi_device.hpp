@@ -3,8 +3,8 @@
 // by one against one tree); on a node with several MI355X the same loop is spread like this:
 //
 //   pcc::ShardedKdTree<PointT> tree({0, 1, 2, 3});      // or pcc::allDevices()
-//   tree.setInputCloud(cloud);                          // ONE host upload; the other devices get the packed
-//                                                       // cloud device-to-device (pcc_index_clone_to_device)
+//   tree.setInputCloud(cloud);                          // ONE host upload; the other devices get the packed cloud
+//                                                       // device-to-device, all copies at once (pcc_index_clone_to_devices)
 //   tree.nearestKSearchBatch(queries, idx, d2);         // contiguous query shards, one worker thread per device
 //
 // and independent clouds (the CLI has two: src/comparator.cpp:1191-1197, 1520-1549) run as REPLICAS, one device
@@ -70,11 +70,19 @@ public:
         if (st == PCC_ERR_EMPTY) return;  // PCL: "Cannot create a KDTree with an empty input cloud"
         check(st);
         handles_.push_back(first);
-        for (size_t k = 1; k < devices_.size(); ++k) {
-            pcc_index* h = nullptr;
-            check(pcc_index_clone_to_device(first, devices_[k], &h));
-            handles_.push_back(h);
+        if (devices_.size() > 1) {  // the other devices: every peer copy in flight at once, builds overlapped, one join
+            std::vector<pcc_index*> more(devices_.size() - 1, nullptr);
+            check(pcc_index_clone_to_devices(first, devices_.data() + 1, (int)more.size(), more.data()));
+            handles_.insert(handles_.end(), more.begin(), more.end());
         }
+    }
+    // Shard k's part of a batch whose queries already live in the HBM of device k (produced there, or uploaded once):
+    // nothing crosses PCIe.  Asynchronous on the shard's stream; syncShards() waits for all of them.
+    void nearestKSearchShardDevice(size_t shard, const void* queries_dev, size_t nq, size_t stride_bytes, int* idx_dev, float* d2_dev) const {
+        check(pcc_nn1(handles_.at(shard), queries_dev, nq, stride_bytes, PCC_MEM_DEVICE, idx_dev, d2_dev));
+    }
+    void syncShards() const {
+        for (pcc_index* h : handles_) check(pcc_index_sync(h));
     }
     size_t shards() const { return handles_.size(); }
     pcc_index* handle(size_t k) const { return handles_.at(k); }

@@ -96,6 +96,12 @@ int pcc_index_set_input(pcc_index *index, const void *pts, size_t n, size_t stri
  * handle with its own stream).  The reference is single-GPU code; this is what its one tree per search site
  * (src/comparator.cpp:564-565) becomes when the query loop is spread over several GPUs of a node. */
 int pcc_index_clone_to_device(pcc_index *src, int device, pcc_index **out);
+/* The same for `count` devices at once (an entry of devices[] may repeat, or name src's own device): every peer copy
+ * is issued before any of them is waited for -- each goes over its own xGMI link --, the builds follow on the clones'
+ * own streams, one join at the end.  out[count] receives the handles; on failure none is left behind.  Options, tie
+ * order and the requested engine of `src` carry over.  (The reference cloud is "broadcast once" this way in the C++
+ * host path; the Python bench uses torch.distributed.broadcast = RCCL for the same step.) */
+int pcc_index_clone_to_devices(pcc_index *src, const int *devices, int count, pcc_index **out);
 /* number of valid (finite) reference points == PCL total_nr_points_ */
 int pcc_index_size(const pcc_index *index, size_t *n_valid);
 /* run this index's work on a caller-owned hipStream_t (NULL = library stream) */
@@ -213,16 +219,19 @@ int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
  * pcc_transform: dst = T * src with PCL's transformPointCloud rounding
  *   ((m0*x + m1*y) + m2*z) + m3; T row-major 4x4 (host); dst may alias src.
  * pcc_icp_align: the whole loop on the device (source stays resident):
- *   max_iter iterations (early exit on |mse-prev| < 1e-12 unless fixed != 0; with fixed != 0 the transform of
- *   every pass is also solved on the device and the passes are enqueued without a host round trip),
+ *   max_iter iterations (early exit on |mse-prev| < 1e-12 unless fixed != 0).  In both modes the loop lives on the
+ *   device: every pass is search -> sums -> one-workgroup solve (transform, running product, convergence criteria) ->
+ *   transform, enqueued in chunks without a host round trip (5 passes per host look with the criteria active, up to 32
+ *   with a fixed count); the sums are taken about the first valid source point.  PCC_OPT_ICP_DEVICE_LOOP = 0 selects the
+ *   host-driven loop (same bits).
  *   final transform T (host, row-major), *fitness = mean squared NN distance of
  *   the finally transformed source, *converged as PCL's hasConverged(). */
 int pcc_rigid_from_sums(const double sums[17], float T[16]);
 int pcc_icp_step(pcc_index *target, const void *src, size_t n, size_t stride_bytes,
                  int mem, int32_t *idx, float *d2, double sums[17]);
 /* The same two with the sums taken about `center` (sum (p - c), sum (q - c), sum (q - c)(p - c)^T; NULL = origin):
- * what a multi-GPU ICP loop over a geo-referenced cloud should use -- every rank passes the SAME center (any point of
- * the cloud, e.g. its first), adds up the sums of all ranks and solves with that center. */
+ * what a multi-GPU ICP loop over a geo-referenced cloud should use -- every rank MUST pass the identical center bits
+ * (any point of the cloud, e.g. its first, broadcast once), adds up the sums of all ranks and solves with that center. */
 int pcc_rigid_from_sums_about(const double sums[17], const double center[3], float T[16]);
 int pcc_icp_step_about(pcc_index *target, const void *src, size_t n, size_t stride_bytes, int mem,
                        const double center[3], int32_t *idx, float *d2, double sums[17]);

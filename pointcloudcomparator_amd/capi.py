@@ -35,7 +35,7 @@ SYMBOLS = [
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
     "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
-    "pcc_index_set_option", "pcc_index_get_option",
+    "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices",
 ]
 
 
@@ -78,6 +78,7 @@ def _load() -> C.CDLL:
     lib.pcc_index_sync.argtypes = [vp]
     lib.pcc_index_set_tie_order.argtypes = [vp, i32]
     lib.pcc_index_clone_to_device.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.pcc_index_clone_to_devices.argtypes = [vp, C.POINTER(i32), i32, C.POINTER(vp)]
     lib.pcc_index_set_option.argtypes = [vp, i32, C.c_double]
     lib.pcc_index_get_option.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.pcc_index_wait_stream.argtypes = [vp, vp]
@@ -221,6 +222,19 @@ class Index:
         other = Index.__new__(Index)
         other._h, other.n_original, other.auto_sync = h, self.n_original, self.auto_sync
         return other
+
+    def clone_to_devices(self, devices):
+        """one more handle over the same cloud per entry of `devices`: all peer copies in flight together, then the builds"""
+        n = len(devices)
+        arr = (C.c_int * n)(*devices)
+        hs = (C.c_void_p * n)()
+        _check(LIB.pcc_index_clone_to_devices(self._h, arr, n, hs))
+        res = []
+        for k in range(n):
+            other = Index.__new__(Index)
+            other._h, other.n_original, other.auto_sync = C.c_void_p(hs[k]), self.n_original, self.auto_sync
+            res.append(other)
+        return res
 
     def set_input(self, points):
         """pcl::KdTreeFLANN::setInputCloud on an existing object: rebuild over a new cloud,

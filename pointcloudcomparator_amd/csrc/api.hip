@@ -10,6 +10,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
+#include <thread>
 
 namespace pcc {
 
@@ -288,43 +289,72 @@ int pcc_index_create(const void* pts, size_t n, size_t stride, int dim, int mem,
 }
 
 int pcc_index_clone_to_device(pcc_index* src, int device, pcc_index** out) {
-    if (!out) { set_error("null out"); return PCC_ERR_INVALID; }
-    *out = nullptr;
+    return pcc_index_clone_to_devices(src, &device, 1, out);
+}
+
+int pcc_index_clone_to_devices(pcc_index* src, const int* devices, int count, pcc_index** out) {
+    if (!out || !devices || count < 0) { set_error("null argument"); return PCC_ERR_INVALID; }
+    for (int k = 0; k < count; ++k) out[k] = nullptr;
     if (!src) { set_error("null index"); return PCC_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (libpcc_nn has no CPU path)"); return PCC_ERR_DEVICE; }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d present)", device, ndev); return PCC_ERR_INVALID; }
-    size_t n = 0;
-    int engine = PCC_ENGINE_AUTO, src_device = 0;
-    const float4* src_refs = nullptr;
+    for (int k = 0; k < count; ++k)
+        if (devices[k] < 0 || devices[k] >= ndev) { set_error("device %d out of range (%d present)", devices[k], ndev); return PCC_ERR_INVALID; }
+    if (count == 0) return PCC_OK;
+    // `src` stays locked until every peer copy has landed: a concurrent pcc_index_set_input on it may free or rewrite
+    // the packed cloud the copies read
+    std::lock_guard<std::mutex> lock(src->mu);
     {
-        std::lock_guard<std::mutex> lock(src->mu);
         DeviceGuard g(src->device);
         if (!g.ok) { set_error("hipSetDevice(%d) failed", src->device); return PCC_ERR_DEVICE; }
         if (src->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
         PCC_HIP(hipStreamSynchronize(src->stream));  // the packed cloud is complete
-        n = src->n_orig;
-        engine = src->engine_requested;
-        src_device = src->device;
-        src_refs = src->refs.as<float4>();
     }
-    pcc_index* ix = nullptr;
-    PCC_TRY(new_handle(device, engine, &ix));
-    DeviceGuard g(device);
-    auto fail = [&](int s) { pcc_index_destroy(ix); return s; };
-    int st = PCC_OK;
-    // the packed cloud (float4, w = validity) travels device to device; non-finite points get their NaN back so
-    // that the build sees what the original upload saw
-    if ((st = ix->icp_src.reserve(n * sizeof(float4))) != PCC_OK) return fail(st);
-    if (hipMemcpyPeerAsync(ix->icp_src.p, device, src_refs, src_device, n * sizeof(float4), ix->stream) != hipSuccess) {
-        set_error("hipMemcpyPeerAsync %d -> %d failed: %s", src_device, device, hipGetErrorString(hipGetLastError()));
-        return fail(PCC_ERR_DEVICE);
+    const size_t n = src->n_orig;
+    // One host thread per clone: handle creation (stream, pinned blocks, device allocations: ~3 ms of driver calls
+    // each -- more than the copy itself), the peer copy on the clone's own stream over its own xGMI link, the build
+    // behind it, the join.  Nothing of one clone waits for another: the copies to the other GPUs of a node and their
+    // builds all overlap (one after the other: 7 x (3 ms + 160 MB + build) at 10M points).
+    std::vector<int> status((size_t)count, PCC_OK);
+    std::vector<std::string> errors((size_t)count);
+    auto one = [&](int k) {
+        auto run = [&]() -> int {
+            pcc_index* ix = nullptr;
+            PCC_TRY(new_handle(devices[k], src->engine_requested, &ix));
+            out[k] = ix;
+            ix->opt = src->opt;
+            ix->tie_mode = src->tie_mode;
+            DeviceGuard g(devices[k]);
+            PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
+            if (hipMemcpyPeerAsync(ix->icp_src.p, devices[k], src->refs.p, src->device, n * sizeof(float4), ix->stream) != hipSuccess) {
+                set_error("hipMemcpyPeerAsync %d -> %d failed: %s", src->device, devices[k], hipGetErrorString(hipGetLastError()));
+                return PCC_ERR_DEVICE;
+            }
+            // (non-finite points get their NaN back so that the build sees what the original upload saw)
+            PCC_TRY(launch_nanify(ix->stream, ix->icp_src.as<float4>(), n));
+            PCC_TRY(set_input(ix, ix->icp_src.p, n, sizeof(float4), PCC_MEM_DEVICE));
+            PCC_TRY(sync_info(ix));
+            if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return PCC_ERR_DEVICE; }
+            return PCC_OK;
+        };
+        status[(size_t)k] = run();
+        if (status[(size_t)k] != PCC_OK) errors[(size_t)k] = g_err;  // (the message is thread-local)
+    };
+    if (count == 1) {
+        one(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < count; ++k) th.emplace_back(one, k);
+        for (std::thread& t : th) t.join();
     }
-    if ((st = launch_nanify(ix->stream, ix->icp_src.as<float4>(), n)) != PCC_OK) return fail(st);
-    if ((st = set_input(ix, ix->icp_src.p, n, sizeof(float4), PCC_MEM_DEVICE)) != PCC_OK) return fail(st);
-    if ((st = sync_info(ix)) != PCC_OK) return fail(st);
-    if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
-    *out = ix;
+    for (int k = 0; k < count; ++k)
+        if (status[(size_t)k] != PCC_OK) {
+            const int bad = status[(size_t)k];
+            const std::string msg = errors[(size_t)k];
+            for (int j = 0; j < count; ++j) { if (out[j]) pcc_index_destroy(out[j]); out[j] = nullptr; }
+            set_error("%s", msg.c_str());
+            return bad;
+        }
     return PCC_OK;
 }
 
@@ -1025,7 +1055,10 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         PCC_HIP(hipStreamSynchronize(ix->stream));  // (h0 lives on this stack frame)
         IcpState* st = ix->icp_state.as<IcpState>();
         IcpState h1 = h0;
-        const int chunk = fixed ? max_iter : 5;
+        // passes per host look: 5 with criteria active; with a fixed count the loop would need none, but a source that
+        // leaves fewer than 3 correspondences stops it on the device and every pass enqueued beyond that is a wasted
+        // search -- so at most 32 at a time (one look costs ~20 us)
+        const int chunk = fixed ? (max_iter < 32 ? max_iter : 32) : 5;
         for (int pass = 0; pass < max_iter && !h1.stopped;) {
             for (int c = 0; c < chunk && pass < max_iter; ++c, ++pass) {
                 ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)

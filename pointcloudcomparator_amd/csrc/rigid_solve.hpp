@@ -80,8 +80,9 @@ PCC_HD void sym4_max_eigvec(double A[4][4], double v[4]) {
 // with Horn's unit-quaternion method in double.  Returns 0, or -1 with < 3 correspondences.
 // `center` (nullable): the sums were accumulated over p - center and q - center.  S = sum q p^T - n pm qm^T cancels
 // catastrophically for a small cloud far from the origin (43 points 8 cm across at (1e3, 1e5, 1e5): sums of 4e11 for
-// a covariance of 0.3 -- the rotation came out 3e-5 rad off, 7 mm on that cloud); the ICP loop therefore sums about the
-// centre of the target's bounding box.  The translation is formed with the true means.
+// a covariance of 0.3 -- the rotation came out 3e-5 rad off, 7 mm on that cloud); pcc_icp_align therefore sums about a
+// point of the SOURCE cloud (k_icp_center: its first valid point; the centre of the target's bounding box was no better
+// once stray points stretched the box).  The translation is formed with the true means.
 PCC_HD int rigid_from_sums(const double sums[17], float T[16], const double* center = nullptr) {
     const double n = sums[16];
     if (n < 3) return -1;  // min_number_correspondences_

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <chrono>
+#include <hip/hip_runtime_api.h>
 #include "pcc/comparator_nn.hpp"
 #include "pcc/multi_device.hpp"
 
@@ -130,6 +132,61 @@ int main() {
         size_t s0, c0;
         shardRange(10, 3, 4, s0, c0);
         REQUIRE(s0 == 8 && c0 == 2);
+    }
+
+    // concurrent multi-device set-up: four handles from one upload, every peer copy issued before any wait
+    // (pcc_index_clone_to_devices) against four clones made one after the other; options and tie order carry over;
+    // a shard searched through device pointers (nothing crosses PCIe)
+    {
+        const size_t big = 2000000;
+        PointCloud<PointXYZRGB>::Ptr bc(new PointCloud<PointXYZRGB>);
+        bc->points.resize(big);
+        uint64_t st = 0x1234567ull;
+        auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) * (1.0 / (1 << 24))); };
+        for (size_t i = 0; i < big; ++i) { bc->points[i].x = rnd() * 10.f; bc->points[i].y = rnd() * 8.f; bc->points[i].z = rnd() * 3.f; }
+        pcc_index* src = nullptr;
+        REQUIRE(pcc_index_create(bc->points.data(), big, sizeof(PointXYZRGB), 3, PCC_MEM_HOST, 0, PCC_ENGINE_GRID, &src) == PCC_OK);
+        REQUIRE(pcc_index_set_tie_order(src, PCC_TIES_FLANN) == PCC_OK);
+        REQUIRE(pcc_index_set_option(src, PCC_OPT_FAR_MODE, 1) == PCC_OK);
+        const int devs[4] = {0, 0, 0, 0};
+        pcc_index* seq[4] = {nullptr, nullptr, nullptr, nullptr};
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 4; ++k) REQUIRE(pcc_index_clone_to_device(src, devs[k], &seq[k]) == PCC_OK);
+        auto t1 = std::chrono::steady_clock::now();
+        pcc_index* par[4] = {nullptr, nullptr, nullptr, nullptr};
+        REQUIRE(pcc_index_clone_to_devices(src, devs, 4, par) == PCC_OK);
+        auto t2 = std::chrono::steady_clock::now();
+        printf("multi-device set-up, 4 handles over %zu points on device 0: one after the other %.2f ms, pcc_index_clone_to_devices %.2f ms\n",
+               big, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+        double v = -5;
+        REQUIRE(pcc_index_get_option(par[3], PCC_OPT_FAR_MODE, &v) == PCC_OK && v == 1);
+        size_t nv = 0;
+        for (int k = 0; k < 4; ++k) REQUIRE(pcc_index_size(par[k], &nv) == PCC_OK && nv == big);
+        const size_t nq = 50000;
+        std::vector<int32_t> ia(nq), ib(nq); std::vector<float> da(nq), db(nq);
+        REQUIRE(pcc_nn1(src, bc->points.data() + 1000, nq, sizeof(PointXYZRGB), PCC_MEM_HOST, ia.data(), da.data()) == PCC_OK);
+        // the same queries through device pointers on a clone
+        void *dq = nullptr, *di = nullptr, *dd = nullptr;
+        REQUIRE(hipMalloc(&dq, nq * sizeof(PointXYZRGB)) == hipSuccess && hipMalloc(&di, nq * 4) == hipSuccess && hipMalloc(&dd, nq * 4) == hipSuccess);
+        REQUIRE(hipMemcpy(dq, bc->points.data() + 1000, nq * sizeof(PointXYZRGB), hipMemcpyHostToDevice) == hipSuccess);
+        REQUIRE(pcc_nn1(par[2], dq, nq, sizeof(PointXYZRGB), PCC_MEM_DEVICE, (int32_t*)di, (float*)dd) == PCC_OK);
+        REQUIRE(pcc_index_sync(par[2]) == PCC_OK);
+        REQUIRE(hipMemcpy(ib.data(), di, nq * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(db.data(), dd, nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        REQUIRE(ia == ib && da == db);
+        for (int k = 0; k < 4; ++k) REQUIRE(ia[k] == 1000 + k);
+        const int bad[2] = {0, 99};
+        pcc_index* none[2] = {src, src};
+        REQUIRE(pcc_index_clone_to_devices(src, bad, 2, none) == PCC_ERR_INVALID && none[0] == nullptr && none[1] == nullptr);
+        // the C++ mirror on top of it: ShardedKdTree with its shards searched through device pointers
+        ShardedKdTree<PointXYZRGB> sh(std::vector<int>{0, 0});
+        sh.setInputCloud(bc);
+        sh.nearestKSearchShardDevice(1, dq, nq, sizeof(PointXYZRGB), (int*)di, (float*)dd);
+        sh.syncShards();
+        REQUIRE(hipMemcpy(ib.data(), di, nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        REQUIRE(ia == ib);
+        (void)hipFree(dq); (void)hipFree(di); (void)hipFree(dd);
+        for (int k = 0; k < 4; ++k) { pcc_index_destroy(seq[k]); pcc_index_destroy(par[k]); }
+        pcc_index_destroy(src);
     }
 
     // EuclideanClusterExtraction (src/segmentation.cpp:125-131)
