@@ -59,7 +59,26 @@ build/ply_dump: tests/cpp/ply_dump.cpp pointcloudcomparator_amd/host/ply_io.hpp 
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Ipointcloudcomparator_amd/host $< -o $@
 
+# ---- sanitizers on the host-side code (CPU build only; sanitizers never run on the GPU box) --------------------
+# oracle/pcc_oracle.c, csrc/flann_tree.hpp (the PCC_TIES_FLANN tree: build + walk), csrc/rigid_solve.hpp,
+# csrc/plane_fit.hpp and host/ply_io.hpp under ASan + UBSan with a CPU-only driver, and the report writer's self-test.
+SANFLAGS := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1 -ffp-contract=off
+asan: build/asan/asan_driver build/asan/test_flann_tree
+	ASAN_OPTIONS=detect_leaks=1 build/asan/asan_driver build/asan
+	@echo "asan: clean"
+
+build/asan/pcc_oracle.o: oracle/pcc_oracle.c oracle/pcc_oracle.h
+	@mkdir -p build/asan
+	$(CC) $(SANFLAGS) -fno-fast-math -pthread -c $< -o $@
+
+build/asan/asan_driver: tests/cpp/asan_driver.cpp build/asan/pcc_oracle.o $(CSRC)/flann_tree.hpp $(CSRC)/rigid_solve.hpp $(CSRC)/plane_fit.hpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc/point_types.hpp
+	$(CXX) -std=c++17 $(SANFLAGS) -Wall -pthread -Iinclude -I$(CSRC) -Ipointcloudcomparator_amd/host -Ioracle $< build/asan/pcc_oracle.o -o $@ -lm
+
+build/asan/test_flann_tree: tests/cpp/test_flann_tree.cpp $(CSRC)/flann_tree.hpp
+	@mkdir -p build/asan
+	$(CXX) -std=c++17 $(SANFLAGS) -Wall -pthread -I$(CSRC) $< -o $@
+
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/_build
 
-.PHONY: all lib oracle ubench hosttest cli clean
+.PHONY: all lib oracle ubench hosttest cli clean asan

@@ -456,7 +456,7 @@ int orc_kdtree_radius(const orc_kdtree *t, const float q[3], float r2, int sorte
     rs.radius = r2;
     find_neighbors(t, &rs, q);
     for (size_t i = 0; i < rs.rcnt; ++i) rs.items[i].i = t->map[rs.items[i].i];
-    if (sorted) qsort(rs.items, rs.rcnt, sizeof(di_t), di_cmp); /* (dist, index) */
+    if (sorted && rs.rcnt) qsort(rs.items, rs.rcnt, sizeof(di_t), di_cmp); /* (dist, index); (an empty result has no array) */
     for (size_t i = 0; i < rs.rcnt && (int)i < cap; ++i) {
         idx[i] = rs.items[i].i;
         d2[i] = rs.items[i].d;
@@ -1019,7 +1019,7 @@ int orc_euclidean_clusters(const void *pts, size_t m, size_t stride, float toler
         }
     }
     /* std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters) */
-    qsort(cl, ncl, sizeof(clus_t), clus_cmp);
+    if (ncl) qsort(cl, ncl, sizeof(clus_t), clus_cmp);
     int32_t *remap = (int32_t *)malloc(sizeof(int32_t) * (ncl ? ncl : 1));
     for (size_t r = 0; r < ncl; ++r) {
         remap[cl[r].id] = (int32_t)r;

@@ -5,7 +5,16 @@
 // The three transcendental calls: on the host the float libm versions PCL itself calls; on the device they
 // are evaluated in double and rounded once (= a correctly rounded float libm), see DESIGN.md 4.6.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else  // plain C++ (the sanitizer build of the host-side code, `make asan`)
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#endif
 #include <cfloat>
 #include <cmath>
 

@@ -3,13 +3,27 @@
 // Plain IEEE double arithmetic and correctly rounded sqrt on both sides, compiled with -ffp-contract=off: the device
 // copy returns the host copy's bits.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else  // plain C++ (the sanitizer build of the host-side code, `make asan`)
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#endif
 #include <cmath>
 #include <cstring>
 
 namespace pcc {
 
 #define PCC_HD __host__ __device__ inline
+#if defined(__HIPCC__)
+#define PCC_UNROLL _Pragma("unroll")
+#else
+#define PCC_UNROLL
+#endif
 
 // largest eigenvector of a symmetric 4x4 (cyclic Jacobi), for Horn's closed-form absolute orientation
 PCC_HD void sym4_max_eigvec(double A[4][4], double v[4]) {
@@ -21,40 +35,40 @@ PCC_HD void sym4_max_eigvec(double A[4][4], double v[4]) {
     // a rotation leaves a residue of ~1e-16 |A|, not zero -- so every solve ran all 64 sweeps: ~25 us on the host per
     // ICP pass, 160 us as one lane of k_icp_solve.
     double fro = 0;
-#pragma unroll
+PCC_UNROLL
     for (int p = 0; p < 4; ++p)
-#pragma unroll
+PCC_UNROLL
         for (int q = 0; q < 4; ++q) fro += A[p][q] * A[p][q];
     double prev_off = 1.79769313486231570e308;
     for (int sweep = 0; sweep < 64; ++sweep) {
         double off = 0;
-#pragma unroll
+PCC_UNROLL
         for (int p = 0; p < 4; ++p)
-#pragma unroll
+PCC_UNROLL
             for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
         if (off <= 1e-30 * fro || !(off < prev_off)) break;
         prev_off = off;
-#pragma unroll
+PCC_UNROLL
         for (int p = 0; p < 4; ++p)
-#pragma unroll
+PCC_UNROLL
             for (int q = p + 1; q < 4; ++q) {
                 if (fabs(A[p][q]) < 1e-300) continue;
                 double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                 double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-#pragma unroll
+PCC_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     double akp = A[k][p], akq = A[k][q];
                     A[k][p] = c * akp - sn * akq;
                     A[k][q] = sn * akp + c * akq;
                 }
-#pragma unroll
+PCC_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     double apk = A[p][k], aqk = A[q][k];
                     A[p][k] = c * apk - sn * aqk;
                     A[q][k] = sn * apk + c * aqk;
                 }
-#pragma unroll
+PCC_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = c * vkp - sn * vkq;
@@ -64,13 +78,13 @@ PCC_HD void sym4_max_eigvec(double A[4][4], double v[4]) {
     }
     // (selects instead of a dynamic column index, for the same reason)
     double bestd = A[0][0];
-#pragma unroll
+PCC_UNROLL
     for (int k = 0; k < 4; ++k) v[k] = V[k][0];
-#pragma unroll
+PCC_UNROLL
     for (int i = 1; i < 4; ++i)
         if (A[i][i] > bestd) {
             bestd = A[i][i];
-#pragma unroll
+PCC_UNROLL
             for (int k = 0; k < 4; ++k) v[k] = V[k][i];
         }
 }
