@@ -656,8 +656,6 @@ int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int 
     if (total == 0) return PCC_OK;
     PCC_TRY(ix->out_packed.reserve((size_t)total * sizeof(unsigned long long)));
     auto* keys = ix->out_packed.as<unsigned long long>();
-    PCC_HIP(hipMemsetAsync(keys, 0xff, (size_t)total * sizeof(unsigned long long), ix->stream));
-    PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), nullptr, doff, keys, sorted, (size_t)total));
     int32_t* didx = idx;
     float* dd2 = d2;
     if (mem == PCC_MEM_HOST) {
@@ -666,7 +664,14 @@ int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int 
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, (size_t)total, didx, dd2));
+    // rows of 24 neighbours and more on average: the fill delivers index and distance itself (sorted in registers, no
+    // key array in between); otherwise keys -> sort -> unpack.  (Slots a fill does not reach read "nothing found".)
+    const bool wave_fill = (size_t)total >= 24 * nq && (didx || dd2);
+    if (!wave_fill) PCC_HIP(hipMemsetAsync(keys, 0xff, (size_t)total * sizeof(unsigned long long), ix->stream));
+    bool delivered = false;
+    PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), nullptr, doff, keys, sorted, (size_t)total,
+                        didx, dd2, &delivered));
+    if (!delivered) PCC_TRY(launch_unpack(ix->stream, keys, nullptr, (size_t)total, didx, dd2));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, (size_t)total, mem));

@@ -14,6 +14,7 @@
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
 #include "lane_ops.hpp"
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 
@@ -490,96 +491,6 @@ int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, 
     return PCC_OK;
 }
 
-// ---- wave-cooperative fill ------------------------------------------------------------------------
-// One WAVE per query for the fill pass: the rows of cells the r-ball touches go into an LDS table (lanes over
-// rows), their points are taken 64 at a time across row boundaries (as in k_grid_knn_wave), tested, and the hits
-// are written with a ballot-compacted, coalesced store.  One lane per query walked hundreds of candidates
-// alone and scattered 8-byte stores over 64 different rows per instruction: 10 of the 13.7 ms of an unsorted
-// 5M x 83 search.
-constexpr int RAD_ROWCAP = 11 * 11;
-__global__ void __launch_bounds__(256)
-k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
-                        const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-                        const unsigned int* __restrict__ n_sorted_ptr, float r, float r2, const int64_t* __restrict__ offsets,
-                        unsigned long long* __restrict__ keys) {
-    __shared__ unsigned int tab_s_all[4][RAD_ROWCAP], tab_o_all[4][RAD_ROWCAP], win_all[4][64];
-    unsigned int* tab_s = tab_s_all[threadIdx.x >> 6];
-    unsigned int* tab_o = tab_o_all[threadIdx.x >> 6];
-    unsigned int* win = win_all[threadIdx.x >> 6];
-    const GridParams g = gd->g;
-    const float slack = gd->slack;
-    const unsigned int ns = *n_sorted_ptr;
-    const unsigned int lane = threadIdx.x & 63;
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
-        const unsigned int qi = order[t];
-        const float4 qv = q[qi];
-        const float qx = qv.x, qy = qv.y, qz = qv.z;
-        int x0, x1, y0, y1, z0, z1;
-        const float rr = r + slack;
-        cell_range(qx, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
-        cell_range(qy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
-        cell_range(qz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
-        unsigned long long* row_out = keys + offsets[qi];
-        unsigned int written = 0;  // wave-uniform
-        const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-        // the rows in chunks of at most RAD_ROWCAP (one chunk unless the radius spans more than 11 cells)
-        for (int rbase = 0; rbase < nrow; rbase += RAD_ROWCAP) {
-            const int rchunk = min(RAD_ROWCAP, nrow - rbase);
-            unsigned int nspans = 0, total = 0;
-            __builtin_amdgcn_wave_barrier();
-            for (int base = 0; base < rchunk; base += 64) {
-                const int rr_i = base + (int)lane;
-                unsigned int s0 = 0, cnt = 0;
-                if (rr_i < rchunk) {
-                    const int rrow = rbase + rr_i;
-                    const unsigned int row = ((unsigned int)(z0 + rrow / ny) * g.dim[1] + (y0 + rrow % ny)) * g.dim[0];
-                    s0 = cell_start[row + x0];
-                    cnt = cell_start[row + x1 + 1] - s0;
-                }
-                const unsigned int incl = wave_incl_scan_add(cnt);
-                const unsigned long long occ = __ballot(cnt != 0);
-                if (cnt) {
-                    const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
-                    tab_s[slot] = s0;
-                    tab_o[slot] = total + incl - cnt;
-                }
-                nspans += (unsigned int)__popcll(occ);
-                total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-            __builtin_amdgcn_wave_barrier();
-            unsigned int next_span = 0, carry_span = 0;
-            for (unsigned int B = 0; B < total; B += 64) {
-                win[lane] = 0u;
-                __builtin_amdgcn_wave_barrier();
-                const unsigned int sp = next_span + lane;
-                const bool starts = sp < nspans && tab_o[sp] < B + 64;
-                if (starts) win[tab_o[sp] - B] = sp + 1;
-                next_span += (unsigned int)__popcll(__ballot(starts));
-                __builtin_amdgcn_wave_barrier();
-                unsigned int v = wave_incl_scan_max(win[lane]);
-                v = max(v, carry_span);
-                carry_span = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
-                const unsigned int c = B + lane;
-                bool hit = false;
-                unsigned long long key = 0;
-                if (c < total) {
-                    const unsigned int my = v - 1;
-                    const float4 r4 = cell_refs[tab_s[my] + (c - tab_o[my])];
-                    const float d = dist2(qx, qy, qz, r4);
-                    hit = d < r2;
-                    key = make_key(d, r4);
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (hit) row_out[written + (unsigned int)__popcll(mask & lt_mask)] = key;
-                written += (unsigned int)__popcll(mask);
-            }
-        }
-    }
-}
-
 // ---- sorting the rows of a filled radius search ---------------------------------------------------
 // pcl::KdTreeFLANN::radiusSearch returns its neighbours ascending by distance.  One WAVE per row: the row's
 // keys live in R registers per lane (element e = r * 64 + lane), a bitonic network sorts them -- exchanges at
@@ -683,37 +594,248 @@ __device__ __noinline__ void sort_long_row(unsigned long long* row, unsigned int
     }
 }
 
+// ---- wave-cooperative fill ------------------------------------------------------------------------
+// One WAVE per query for the fill pass: the rows of cells the r-ball touches go into an LDS table (lanes over
+// rows), their points are taken 64 at a time across row boundaries (as in k_grid_knn_wave), tested, and the hits
+// are written with a ballot-compacted, coalesced store.  One lane per query walked hundreds of candidates
+// alone and scattered 8-byte stores over 64 different rows per instruction: 10 of the 13.7 ms of an unsorted
+// 5M x 83 search.
+constexpr int RAD_ROWCAP = 11 * 11;
+constexpr unsigned int RAD_FLAT_CAP = 4 * 2048;  // flat candidates the span-end bits cover (4 planes of 64 words)
 __global__ void __launch_bounds__(256)
-k_sort_rows(const int64_t* __restrict__ offsets, unsigned int nq, unsigned long long* __restrict__ keys) {
+k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+                        const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+                        const unsigned int* __restrict__ n_sorted_ptr, float r, float r2, const int64_t* __restrict__ offsets,
+                        unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
+                        int sorted) {
+    // FUSED (idx_out / d2_out given): a row of up to ROW_SORT_MAX neighbours never leaves the chip between the search and
+    // the caller's arrays -- its hits gather in LDS, are sorted in registers (PCL's sorted results) and go out as index
+    // and squared distance in two coalesced stores.  Before: keys to memory (8 B), sorted in place by a second kernel
+    // (16 B), unpacked by a third (16 B).  Longer rows keep that route (k_finish_long_rows).
+    __shared__ unsigned long long stage_all[4][ROW_SORT_MAX];
+    __shared__ unsigned int tab_s_all[4][RAD_ROWCAP], tab_o_all[4][RAD_ROWCAP], win_all[4][64], endb_all[4][4][64];
+    unsigned int (*endb)[64] = endb_all[threadIdx.x >> 6];
+    unsigned long long* stage = stage_all[threadIdx.x >> 6];
+    const bool fused = idx_out != nullptr || d2_out != nullptr;
+    unsigned int* tab_s = tab_s_all[threadIdx.x >> 6];
+    unsigned int* tab_o = tab_o_all[threadIdx.x >> 6];
+    unsigned int* win = win_all[threadIdx.x >> 6];
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    const unsigned int ns = *n_sorted_ptr;
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
+        const unsigned int qi = order[t];
+        const float4 qv = q[qi];
+        const float qx = qv.x, qy = qv.y, qz = qv.z;
+        int x0, x1, y0, y1, z0, z1;
+        const float rr = r + slack;
+        cell_range(qx, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
+        cell_range(qy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
+        cell_range(qz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
+        const int64_t row_beg = offsets[qi];
+        const unsigned int row_len = (unsigned int)(offsets[qi + 1] - row_beg);
+        const bool in_lds = fused && row_len <= ROW_SORT_MAX;
+        unsigned long long* row_out = in_lds ? stage : keys + row_beg;
+        unsigned int written = 0;  // wave-uniform
+        const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+        // the rows in chunks of at most RAD_ROWCAP (one chunk unless the radius spans more than 11 cells)
+        for (int rbase = 0; rbase < nrow; rbase += RAD_ROWCAP) {
+            const int rchunk = min(RAD_ROWCAP, nrow - rbase);
+            unsigned int nspans = 0, total = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 64) { endb[0][lane] = 0u; endb[1][lane] = 0u; endb[2][lane] = 0u; endb[3][lane] = 0u; }
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < rchunk; base += 64) {
+                const int rr_i = base + (int)lane;
+                unsigned int s0 = 0, cnt = 0;
+                if (rr_i < rchunk) {
+                    // the row's cells the BALL reaches: a row whose y/z gap leaves nothing of r^2 is skipped, the others are
+                    // clipped to the chord (same slack as the cell range above; boundary rows of the grid are open-ended)
+                    const int rrow = rbase + rr_i;
+                    const int z = z0 + rrow / ny, y = y0 + rrow % ny;
+                    const float gy = fmaxf(fmaxf((y == 0 ? -__builtin_inff() : g.org[1] + y * g.h) - qy,
+                                                 qy - (y == g.dim[1] - 1 ? __builtin_inff() : g.org[1] + (y + 1) * g.h)) - slack, 0.f);
+                    const float gz = fmaxf(fmaxf((z == 0 ? -__builtin_inff() : g.org[2] + z * g.h) - qz,
+                                                 qz - (z == g.dim[2] - 1 ? __builtin_inff() : g.org[2] + (z + 1) * g.h)) - slack, 0.f);
+                    const float rem = rr * rr - (gy * gy + gz * gz) * 0.9999f;
+                    if (rem >= 0.f) {
+                        int xa, xb;
+                        cell_range(qx, sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
+                        xa = max(xa, x0);
+                        xb = min(xb, x1);
+                        if (xa <= xb) {
+                            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                            s0 = cell_start[row + xa];
+                            cnt = cell_start[row + xb + 1] - s0;
+                        }
+                    }
+                }
+                const unsigned int incl = wave_incl_scan_add(cnt);
+                const unsigned long long occ = __ballot(cnt != 0);
+                if (cnt) {
+                    const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
+                    const unsigned int off = total + incl - cnt;
+                    tab_s[slot] = s0;
+                    tab_o[slot] = off;
+                    // one bit per span END over the flat candidate positions, transposed (grid.hip, k_grid_nn1_flat2): word
+                    // (p mod 64) of plane (p / 2048), bit (p / 64) mod 32 -- a candidate's span = ends before it
+                    const unsigned int e = off + cnt - 1;
+                    if (e < RAD_FLAT_CAP) atomicOr(&endb[e >> 11][e & 63], 1u << ((e >> 6) & 31));
+                }
+                nspans += (unsigned int)__popcll(occ);
+                total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (total <= RAD_FLAT_CAP) {
+                // (four windows with their loads in flight together measured 5.6 against 5.3 ms at 5M x 83: the registers
+                // cost more occupancy than the overlap buys -- 28 resident waves per CU hide a single load already)
+                unsigned int before = 0, word = 0;
+                for (unsigned int B = 0; B < total; B += 64) {
+                    const unsigned int w = B >> 6;
+                    if ((w & 31u) == 0u) word = endb[w >> 5][lane];
+                    const unsigned long long m = __ballot(((word >> (w & 31u)) & 1u) != 0u);
+                    const unsigned int my = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
+                    before += (unsigned int)__popcll(m);
+                    const unsigned int c = B + lane;
+                    bool hit = false;
+                    unsigned long long key = 0;
+                    if (c < total) {
+                        const float4 r4 = cell_refs[tab_s[my] + (c - tab_o[my])];
+                        const float d = dist2(qx, qy, qz, r4);
+                        hit = d < r2;
+                        key = make_key(d, r4);
+                    }
+                    const unsigned long long mask = __ballot(hit);
+                    const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
+                    if (hit && (!in_lds || slot < ROW_SORT_MAX)) row_out[slot] = key;
+                    written += (unsigned int)__popcll(mask);
+                }
+                continue;
+            }
+            unsigned int next_span = 0, carry_span = 0;
+            for (unsigned int B = 0; B < total; B += 64) {
+                win[lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                const unsigned int sp = next_span + lane;
+                const bool starts = sp < nspans && tab_o[sp] < B + 64;
+                if (starts) win[tab_o[sp] - B] = sp + 1;
+                next_span += (unsigned int)__popcll(__ballot(starts));
+                __builtin_amdgcn_wave_barrier();
+                unsigned int v = wave_incl_scan_max(win[lane]);
+                v = max(v, carry_span);
+                carry_span = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+                const unsigned int c = B + lane;
+                bool hit = false;
+                unsigned long long key = 0;
+                if (c < total) {
+                    const unsigned int my = v - 1;
+                    const float4 r4 = cell_refs[tab_s[my] + (c - tab_o[my])];
+                    const float d = dist2(qx, qy, qz, r4);
+                    hit = d < r2;
+                    key = make_key(d, r4);
+                }
+                const unsigned long long mask = __ballot(hit);
+                // (a fill can only find what the count found -- same arithmetic --; the bound is belt and braces)
+                const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
+                if (hit && (!in_lds || slot < ROW_SORT_MAX)) row_out[slot] = key;
+                written += (unsigned int)__popcll(mask);
+            }
+        }
+        if (in_lds) {
+            __builtin_amdgcn_wave_barrier();
+            const unsigned int have = written < row_len ? written : row_len;
+            auto emit = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                unsigned long long v[R];
+#pragma unroll
+                for (int rr_ = 0; rr_ < R; ++rr_) v[rr_] = (unsigned int)(rr_ * 64) + lane < have ? stage[rr_ * 64 + lane] : ~0ull;
+                if (sorted) bitonic_sort_regs<R>(v, lane);
+#pragma unroll
+                for (int rr_ = 0; rr_ < R; ++rr_) {
+                    const unsigned int e = (unsigned int)(rr_ * 64) + lane;
+                    if (e < row_len) {
+                        const bool none = key_none(v[rr_]);
+                        if (idx_out) idx_out[row_beg + e] = none ? -1 : (int32_t)(unsigned int)v[rr_];
+                        if (d2_out) d2_out[row_beg + e] = none ? __builtin_inff() : __uint_as_float((unsigned int)(v[rr_] >> 32));
+                    }
+                }
+            };
+            if (row_len <= 64) emit(std::integral_constant<int, 1>{});
+            else if (row_len <= 128) emit(std::integral_constant<int, 2>{});
+            else if (row_len <= 256) emit(std::integral_constant<int, 4>{});
+            else emit(std::integral_constant<int, 8>{});
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// min_len: rows shorter than that are someone else's (the fused fill has delivered them).  idx_out / d2_out: the
+// rows handled here are also unpacked into the caller's arrays (the long rows of a fused fill).
+__global__ void __launch_bounds__(256)
+k_sort_rows(const int64_t* __restrict__ offsets, unsigned int nq, unsigned long long* __restrict__ keys, unsigned int min_len,
+            int sorted, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (unsigned int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nq; i += nwaves) {  // wave-uniform
         const int64_t beg = offsets[i];
         const unsigned int len = (unsigned int)(offsets[i + 1] - beg);
         unsigned long long* row = keys + beg;
-        if (len <= 1) continue;
-        if (len > ROW_SORT_MAX) { sort_long_row(row, len, lane); continue; }
-        if (len <= 64) sort_row<1>(row, len, lane);
-        else if (len <= 128) sort_row<2>(row, len, lane);
-        else if (len <= 256) sort_row<4>(row, len, lane);
-        else sort_row<8>(row, len, lane);
+        if (len < min_len) continue;
+        if (sorted && len > 1) {
+            if (len > ROW_SORT_MAX) sort_long_row(row, len, lane);
+            else if (len <= 64) sort_row<1>(row, len, lane);
+            else if (len <= 128) sort_row<2>(row, len, lane);
+            else if (len <= 256) sort_row<4>(row, len, lane);
+            else sort_row<8>(row, len, lane);
+        }
+        if (idx_out || d2_out) {
+            if (sorted && len > ROW_SORT_MAX) __threadfence();
+            for (unsigned int e = lane; e < len; e += 64) {
+                const unsigned long long k = len > ROW_SORT_MAX ? row_ld(row + e) : row[e];
+                const bool none = key_none(k);
+                if (idx_out) idx_out[beg + e] = none ? -1 : (int32_t)(unsigned int)k;
+                if (d2_out) d2_out[beg + e] = none ? __builtin_inff() : __uint_as_float((unsigned int)(k >> 32));
+            }
+        }
     }
 }
 
+// idx_out / d2_out (fill only, nullable): the caller's result arrays (device).  When the fill takes the wave-per-query
+// route it delivers them itself and *delivered is set: the caller skips its unpack pass.
 int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
-                const int64_t* offsets, unsigned long long* keys, int sorted, size_t total) {
+                const int64_t* offsets, unsigned long long* keys, int sorted, size_t total, int32_t* idx_out,
+                float* d2_out, bool* delivered) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)nq;
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     const GridDev* gd = ix->d_grid.as<GridDev>();
+    if (delivered) *delivered = false;
     ev_mark(ix, EV_MAIN0);
+    unsigned int gw = (n + 3) / 4;  // 4 waves per workgroup, waves loop
+    if (gw > 8192) gw = 8192;
     if (keys && total >= 24 * nq) {  // long rows: a wave per query (short rows leave most of its lanes idle)
-        unsigned int gw = (n + 3) / 4;  // 4 waves per workgroup, waves loop
-        if (gw > 8192) gw = 8192;
+        const bool fused = delivered != nullptr && (idx_out || d2_out);
         hipLaunchKernelGGL(k_grid_radius_fill_wave, dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                           ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, r, r2, offsets, keys);
-    } else if (keys)
+                           ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, r, r2, offsets, keys,
+                           fused ? idx_out : nullptr, fused ? d2_out : nullptr, sorted);
+        PCC_HIP(hipGetLastError());
+        if (fused) {  // what is left: rows beyond the register sort, still as keys in memory
+            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, ROW_SORT_MAX + 1, sorted, idx_out, d2_out);
+            PCC_HIP(hipGetLastError());
+            *delivered = true;
+        } else if (sorted) {
+            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr);
+            PCC_HIP(hipGetLastError());
+        }
+        ev_mark(ix, EV_MAIN1);
+        return PCC_OK;
+    }
+    if (keys)
         hipLaunchKernelGGL((k_grid_radius<true>), dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, n, r, r2, counts,
                            offsets, keys, sorted);
@@ -723,9 +845,7 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
                            offsets, keys, sorted);
     PCC_HIP(hipGetLastError());
     if (keys && sorted) {
-        unsigned int gw = (n + 3) / 4;
-        if (gw > 8192) gw = 8192;
-        hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys);
+        hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr);
         PCC_HIP(hipGetLastError());
     }
     ev_mark(ix, EV_MAIN1);

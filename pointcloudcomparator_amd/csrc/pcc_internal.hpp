@@ -252,8 +252,11 @@ int voxel_grid(pcc_index* ctx, const void* pts, size_t n, size_t stride, int mem
 // keys[nq][K] (pre-set to ~0) receive the K smallest (d2, position) keys ascending
 int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys);
 // counts[i] = #refs with d2 < r2; with fill != 0 also writes keys at offsets[i]..
+// idx_out / d2_out / delivered (fill only): when given, a fill that takes the wave-per-query route writes the caller's
+// arrays itself (sorted in registers) and sets *delivered
 int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
-                const int64_t* offsets, unsigned long long* keys, int sorted, size_t total = 0);
+                const int64_t* offsets, unsigned long long* keys, int sorted, size_t total = 0, int32_t* idx_out = nullptr,
+                float* d2_out = nullptr, bool* delivered = nullptr);
 int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n, const char* host_base, size_t host_stride,
               int max_iterations, double threshold, double probability, int optimize, int32_t* inliers_dev,
               size_t* n_inliers, float coeff[4], int* iterations_out);

@@ -1,0 +1,110 @@
+"""Per-operation rooflines beyond k = 1: every other operation of the hot path at benchmark scale, with the
+algorithmic bytes 8d prescribes, timed call by call (device memory in, device memory out, stream synchronised around the
+call).  Two steps:
+    rocprofv3 --kernel-trace --stats -d gpurun_out/ops -- python3 tools/ops_roofline.py run gpurun_out/ops_run.json
+    python3 tools/ops_roofline.py merge gpurun_out/ops_run.json <kernel_stats.csv> profiles/r03_ops_roofline.json
+`merge` adds, per operation, the rocprofv3 average of each kernel it launches and prices the dominant one against the
+HBM roof (8 TB/s) on the operation's algorithmic bytes."""
+import csv, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+HBM = 8000.0  # GB/s
+
+
+def run(out_path):
+    import numpy as np, torch
+    from pointcloudcomparator_amd import capi, synth
+    res = []
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best, r
+
+    def add(op, config, seconds, alg_bytes, kernels, note=""):
+        res.append({"op": op, "config": config, "call_ms": seconds * 1e3, "algorithmic_bytes": alg_bytes,
+                    "achieved_GBps": alg_bytes / seconds / 1e9, "frac_of_hbm": alg_bytes / seconds / 1e9 / HBM,
+                    "kernels": kernels, "note": note})
+        print(res[-1], flush=True)
+
+    n = 1_000_000
+    a = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_A)).cuda()
+    ix = capi.Index(a, auto_sync=False)
+    for K in (51, 100):
+        t, _ = timed(lambda: (ix.knn(a, K), ix.sync()))
+        add(f"k-NN K={K} (self query)", f"{n} x {n} corridor", t, 16.0 * n + 16.0 * n + 8.0 * K * n + 8.0 * K * n,
+            ["k_grid_knn_wave", "k_unpack"], "refs + queries once (16 B packed), K keys per query written and unpacked; the kernel is "
+            "selection-network (VALU / cross-lane) bound, the byte figure is what 8d asks for")
+    t, _ = timed(lambda: ix.sor(50, 1.5))
+    add("SOR mean_k=50 (-n noise pass)", f"{n} points", t, 32.0 * n + 8.0 * 51 * n + 4.0 * n, ["k_grid_knn_wave", "k_sor_mean_staged"],
+        "includes PCL's in-order host reduction (D2H of the means)")
+    t, _ = timed(lambda: (ix.radius_count(a, 0.05), ix.sync()))
+    add("radius count r=0.05", f"{n} x {n} corridor", t, 32.0 * n + 4.0 * n, ["k_grid_radius"])
+    nrm = None
+    t, nrm = timed(lambda: ix.normals(50, device="cuda:0"))
+    add("normals K=50", f"{n} points", t, 32.0 * n + 8.0 * 50 * n + 16.0 * n, ["k_grid_knn_wave", "k_normals"])
+    t, _ = timed(lambda: ix.region_growing(nrm, k=100), reps=2)
+    add("region growing K=100", f"{n} points", t, 32.0 * n + 8.0 * 100 * n + 16.0 * n + 4.0 * n, ["k_grid_knn_wave", "k_rg_"])
+    ix.close()
+    # radius search with materialised lists: the object layer, r = 0.05 (rows of ~80 neighbours)
+    m = 5_000_000
+    obj = torch.from_numpy(synth.corridor_cloud(m, synth.SEED_A, layer="objects")).cuda()
+    ix = capi.Index(obj, auto_sync=False)
+    cnt = ix.radius_count(obj, 0.05); ix.sync()
+    total = int(cnt.to(torch.int64).sum().item())
+    offs = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
+    offs[1:] = torch.cumsum(cnt.to(torch.int64), 0)
+    idx = torch.empty(total, dtype=torch.int32, device="cuda"); d2 = torch.empty(total, dtype=torch.float32, device="cuda")
+    import ctypes as C
+    ptr, nn_, stride, mem = capi._points(obj)
+    for srt in (1, 0):
+        def fill():
+            capi._check(capi.LIB.pcc_radius_fill(ix._h, ptr, nn_, stride, mem, 0.05, srt, offs.data_ptr(), idx.data_ptr(), d2.data_ptr()))
+            ix.sync()
+        t, _ = timed(fill)
+        add(f"radius fill r=0.05 {'sorted' if srt else 'unsorted'}", f"{m} queries x {total / m:.1f} neighbours (object layer)", t,
+            32.0 * m + 8.0 * m + 8.0 * total, ["k_grid_radius_fill_wave", "k_sort_rows", "k_unpack"],
+            "8d: 12 B per point read (16 B packed here) + 8 B per emitted (idx, d2)")
+    t, r = timed(lambda: ix.euclidean_clusters(0.05, 100, 250000, device_out=obj), reps=2)
+    add("Euclidean clustering r=0.05 (-e)", f"{m} object-layer points, {r[1]} clusters", t, 2 * (16.0 * m + 4.0 * m) + 16.0 * m,
+        ["k_uf_link_cells", "k_uf_"], "8d: 12 M' read + 4 M' label write per propagation round (two passes over the points here) + the cell sort")
+    ix.close()
+    del obj, idx, d2, offs, cnt
+    torch.cuda.empty_cache()
+    mm = 2_000_000
+    tgt = torch.from_numpy(synth.corridor_cloud(mm, synth.SEED_A)).cuda()
+    src = torch.from_numpy(synth.rigid_offset(synth.corridor_cloud(mm, synth.SEED_B))).cuda()
+    ix = capi.Index(tgt, auto_sync=False)
+    t, _ = timed(lambda: ix.icp_align(src, max_iter=50, fixed=True), reps=2)
+    passes = 51
+    add("ICP 50 fixed iterations + fitness (-i)", f"{mm} x {mm}", t, passes * (16.0 * mm + 28.0 * mm + 40.0 * mm + 32.0 * mm),
+        ["k_grid_nn1", "k_nn1_open", "k_icp_sums", "k_transform", "k_icp_solve", "k_grid_far"],
+        "per pass: NN as the k = 1 kernel (16 M + 28 N), sums (16 B source + 8 B key + 16 B matched reference per point), transform 16 + 16 B per point")
+    ix.close()
+    json.dump(res, open(out_path, "w"), indent=1)
+
+
+def merge(run_json, stats_csv, out_path):
+    ops = json.load(open(run_json))
+    rows = list(csv.DictReader(open(stats_csv)))
+    for op in ops:
+        ks = {}
+        for r in rows:
+            name = r["Name"]
+            if any(k in name for k in op["kernels"]):
+                short = name.split("(")[0].replace("void ", "").replace("pcc::", "")
+                ks[short] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+        op["rocprof_kernels"] = ks
+    json.dump({"hbm_peak_GBps": HBM, "operations": ops}, open(out_path, "w"), indent=1)
+    for op in ops:
+        print(f"{op['op']:45s} {op['call_ms']:9.3f} ms  {op['achieved_GBps']:8.1f} GB/s  {op['frac_of_hbm'] * 100:5.1f} % of HBM")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2])
+    else:
+        merge(sys.argv[2], sys.argv[3], sys.argv[4])
