@@ -245,17 +245,20 @@ def main():
             r["per_rank_ms_per_step"] = per_rank_ms
         # ---- roofline of the dominant kernel of the measured path -----------------------------------------
         if engine_name == "grid":
-            # k_grid_nn1: every reference point (16 B packed) has to be read at least once, every query read
-            # once (16 B packed + 4 B order) and its result written (8 B)
+            # the pruned search (k_grid_nn1_flat2, plus k_nn1_open for the lanes its cube leaves open from 2M queries on;
+            # both inside the event bracket): every reference point (16 B packed) has to be read at least once, every
+            # query read once (16 B packed + 4 B order) and its result written (8 B)
             alg = 16.0 * M + 28.0 * N
             ach = alg / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else 0.0
-            traffic, stale = load_pmc_traffic("k_grid_nn1", cfg)
-            r["roofline"] = {"kernel": "k_grid_nn1", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale, "kernel_ms": tm[0],
-                             "algorithmic_bytes": alg,
-                             "note": "pruned exact search: VALU-issue bound at 20 of 64 lanes active (VALU 68 % busy at C3, "
-                                     "profiles/r02_nn1_counters.json, DESIGN.md 4.2); compulsory HBM bytes are a few % of the "
-                                     "roof by construction"}
+            t_main, stale = load_pmc_traffic("k_grid_nn1_flat2", cfg)
+            t_open, _ = load_pmc_traffic("k_nn1_open", cfg)
+            traffic = None if t_main is None else t_main + (t_open or 0.0)
+            r["roofline"] = {"kernel": "k_grid_nn1_flat2 (+ k_nn1_open)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale,
+                             "kernel_ms": tm[0], "algorithmic_bytes": alg,
+                             "note": "pruned exact search, rows drained with lanes over candidates: latency / VALU-issue bound "
+                                     "(profiles/r03_nn1_counters.json, DESIGN.md 4.2); compulsory HBM bytes are a few % of the roof "
+                                     "by construction, the traffic above them is neighbouring rows re-read through the caches"}
         else:
             ach = float(M) * N * OPS_PER_PAIR / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else 0.0
             traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
@@ -454,6 +457,18 @@ def main():
             extra["c3_clusters"] = run_clusters()
             extra["c4_icp"] = run_icp()
             extra["room"] = {"scan": run_room(synth.ROOM_SIZES[1]), "10M": run_room(synth.ROOM_SIZES[2], full=False)}
+            # the other operations of the hot path against the HBM roof on their algorithmic bytes: measured by
+            # tools/ops_roofline.py under rocprofv3, committed as profiles/*_ops_roofline.json (not re-measured here)
+            ops_files = sorted((ROOT / "profiles").glob("*_ops_roofline.json"))
+            if ops_files:
+                try:
+                    ops = json.loads(ops_files[-1].read_text())["operations"]
+                    extra["ops_roofline"] = {"source": "profiles/" + ops_files[-1].name,
+                                             "operations": [{"op": o["op"], "config": o["config"], "call_ms": round(o["call_ms"], 3),
+                                                             "achieved_GBps": round(o["achieved_GBps"], 1),
+                                                             "frac_of_hbm": round(o["frac_of_hbm"], 4)} for o in ops]}
+                except Exception:
+                    pass
         else:
             # BASELINE configs[4]: 32M queries vs 8M references, sharded over the ranks present
             c5 = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // n_gpus, steps=min(K, 10), warmup=2)

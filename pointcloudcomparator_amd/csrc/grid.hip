@@ -968,7 +968,8 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
     // phase 2 as the ball outside the finished cube, except in ICP passes: while the source is still misaligned the
     // balls are several cells wide and the per-row chord arithmetic costs more than the rows it drops
-    // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us)
+    // (2M x 2M, 50 passes: 26.5 ms with the plain box, 29.1 ms with the ball; 10M x 10M sorted: 1047 vs 1030 us; again with the
+    // open lanes in their own kernel, round 3: 19.5 vs 21.1 ms)
     const bool ball_walk = !ix->keep_order;
     const bool warm = ix->warm_start && ix->keep_order;  // out[] holds the previous pass's keys of the SAME queries (pcc_icp_align)
     // PCC_OPT_NN1_KERNEL: 0 one lane per query (k_grid_nn1); 1 rows drained flat (k_grid_nn1_flat2), the lanes it leaves open

@@ -23,7 +23,7 @@ for i in range(1, 12):
     if not fs: continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if 'k_grid_nn1' in r['Kernel_Name']:
+        if '${PMC_KERNEL:-k_grid_nn1}' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in acc.items():
         v = v[len(v) // 2:]
