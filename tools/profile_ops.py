@@ -28,6 +28,11 @@ timed("voxel_grid 0.025 1M (host)", lambda: ix.voxel_grid(a, 0.025))
 timed("sac_plane 1M (device)", lambda: ix.sac_plane(ta))
 timed("first_within 100k queries", lambda: (ix.first_within(ta[:100000] + 0.01, 0.05), ix.sync()))
 ix.close()
+room = torch.from_numpy(synth.room_cloud(synth.ROOM_SIZES[1], synth.SEED_A)).cuda()
+ix = capi.Index(room)
+timed(f"room scan {synth.ROOM_SIZES[1]} points: sor k=50", lambda: ix.sor(50, 1.5))
+timed(f"room scan {synth.ROOM_SIZES[1]} points: knn k=51 (device)", lambda: (ix.knn(room, 51), ix.sync()))
+ix.close()
 obj = synth.corridor_cloud(5_000_000, synth.SEED_A, layer="objects")
 ix = capi.Index(torch.from_numpy(obj).cuda())
 r = timed("euclidean_clusters 5M object points", lambda: ix.euclidean_clusters(0.05, 100, 250000))

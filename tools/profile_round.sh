@@ -27,4 +27,15 @@ python3 bench.py > $S/${TAG}_bench_default.json 2> $O/bench_default.err
 echo "default bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ops -- python3 tools/profile_ops.py > $S/${TAG}_ops_wallclock.txt 2> $O/ops.err
 cp $(find $O/ops -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_kernel_stats.csv
+python3 tools/exp_ties.py 1e6 2>/dev/null | tail -1 >> $S/${TAG}_ops_wallclock.txt
 cat $S/${TAG}_ops_wallclock.txt
+# per-operation rooflines (algorithmic bytes of SURVEY 8d against the HBM roof, rocprofv3 averages per kernel)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/opsr -- python3 tools/ops_roofline.py run $O/ops_run.json > $O/opsr.log 2> $O/opsr.err
+python3 tools/ops_roofline.py merge $O/ops_run.json $(find $O/opsr -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_roofline.json
+# counters of the k = 1 kernels (one --pmc pass per group), 10M x 10M and 1M x 1M corridor scene
+rm -rf gpurun_out/pmcf_1_both
+bash tools/pmc_flat.sh 1 1e7 both 1 2 3 4 > $O/pmcf_c3.log 2>&1
+mv gpurun_out/pmcf_1_both $O/pmcf_c3
+bash tools/pmc_flat.sh 1 1e6 both 1 2 3 4 > $O/pmcf_c2.log 2>&1
+mv gpurun_out/pmcf_1_both $O/pmcf_c2
+python3 tools/nn1_counters.py $S/${TAG}_nn1_counters.json c3_flat2=$O/pmcf_c3:k_grid_nn1_flat2 c3_open=$O/pmcf_c3:k_nn1_open c2_flat2=$O/pmcf_c2:k_grid_nn1_flat2 > $O/nn1_counters.log
