@@ -128,7 +128,7 @@ int pcc_index_set_tie_order(pcc_index *index, int ties);
 /* Tuning knobs of one handle.  None of them changes a result bit (every mode is exact); they select between
  * implementations that the tests compare with each other and that measurements are taken with.  The PCC_*
  * environment variables of the same names give the DEFAULTS a new handle starts with; the library does not read
- * the environment anywhere else.  Options that shape the index (GRID_PPC, GRID_TRIM, GRID_OCCUPANCY, SORT_MP_MIN)
+ * the environment anywhere else.  Options that shape the index (GRID_PPC, GRID_TRIM, SORT_MP_MIN)
  * take effect at the next pcc_index_set_input.  (The reference has no such surface -- PCL's KdTreeFLANN exposes
  * only setEpsilon / setSortedResults, src/comparator.cpp:564 uses neither.) */
 enum pcc_option {
@@ -142,9 +142,8 @@ enum pcc_option {
     PCC_OPT_SORT_MP_MIN_Q = 8,   /* the same for query clouds */
     PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query; 1 rows drained with lanes over candidates (default);
                                     2 / 3 the same with the open lanes always listed for a second kernel / always finished in place */
-    PCC_OPT_GRID_OCCUPANCY = 10, /* cell edge from the occupied-cell statistics instead of the bounding-box volume (default 1) */
-    PCC_OPT_FLANN_SPLIT = 11,    /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
-    PCC_OPT_NN1_DENSE_MIN = 12   /* flat k = 1 kernel: a wave whose queries' own cells hold at least this many references on average
+    PCC_OPT_FLANN_SPLIT = 10,    /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
+    PCC_OPT_NN1_DENSE_MIN = 11   /* flat k = 1 kernel: a wave whose queries' own cells hold at least this many references on average
                                     takes its first bound from the own cell instead of the own row (default 4) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);

@@ -36,7 +36,6 @@ void Options::from_env() {
     sort_mp_min = num("PCC_SORT_MP_MIN", sort_mp_min);
     sort_mp_min_q = num("PCC_SORT_MP_MIN_Q", sort_mp_min_q);
     nn1_kernel = (int)num("PCC_NN1_KERNEL", nn1_kernel);
-    grid_occupancy = (int)num("PCC_GRID_OCCUPANCY", grid_occupancy);
     flann_split = (int)num("PCC_FLANN_SPLIT", flann_split);
     nn1_dense_min = (int)num("PCC_NN1_DENSE_MIN", nn1_dense_min);
 }
@@ -473,7 +472,6 @@ static double* option_slot(pcc_index* ix, int option, int** as_int) {
         case PCC_OPT_ICP_DEVICE_LOOP: *as_int = &o.icp_device_loop; return nullptr;
         case PCC_OPT_EC_CELLS: *as_int = &o.ec_cells; return nullptr;
         case PCC_OPT_NN1_KERNEL: *as_int = &o.nn1_kernel; return nullptr;
-        case PCC_OPT_GRID_OCCUPANCY: *as_int = &o.grid_occupancy; return nullptr;
         case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
         case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
         default: return nullptr;

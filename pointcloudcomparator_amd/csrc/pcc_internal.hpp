@@ -95,7 +95,6 @@ struct Options {
     double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
     double sort_mp_min_q = 5e6;     // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds
     int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 rows drained flat, lanes over candidates (2 / 3: open lanes listed / in place)
-    int grid_occupancy = 1;         // PCC_OPT_GRID_OCCUPANCY: cell size from the occupied-cell statistics (0: bounding-box volume)
     int nn1_dense_min = 4;          // PCC_OPT_NN1_DENSE_MIN: references per own cell from which a wave starts with the own cell alone
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     void from_env();
