@@ -49,7 +49,7 @@ CONFIGS = {
     "c2": (1_000_000, 1_000_000, 3, "C2: 1M x 1M XYZ, k=1 NN"),
     "c3": (10_000_000, 10_000_000, 8, "C3: 10M x 10M XYZRGB (32-B stride), k=1 NN"),
     "c4": (2_000_000, 2_000_000, 3, "C4: 2M x 2M XYZ, -i ICP, 50 fixed iterations"),
-    "c5": (8_000_000, 4_000_000, 3, "C5: 32M queries in total (4M per GPU at 8 GPUs; one 4M shard on a single GPU) vs 8M references"),
+    "c5": (8_000_000, 4_000_000, 3, "C5: 32M queries in total, sharded over the ranks present (one 4M shard when run on a single GPU), vs 8M references"),
 }
 C5_TOTAL_QUERIES = 32_000_000
 # sources whose kernels the committed PMC passes describe; a profile taken from other sources is flagged stale
