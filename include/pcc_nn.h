@@ -132,7 +132,7 @@ int pcc_index_set_tie_order(pcc_index *index, int ties);
  * take effect at the next pcc_index_set_input.  (The reference has no such surface -- PCL's KdTreeFLANN exposes
  * only setEpsilon / setSortedResults, src/comparator.cpp:564 uses neither.) */
 enum pcc_option {
-    PCC_OPT_GRID_PPC = 1,        /* mean references per cell the grid aims for (default 1.0) */
+    PCC_OPT_GRID_PPC = 1,        /* mean references per cell the grid aims for (default 0.75) */
     PCC_OPT_GRID_TRIM = 2,       /* k of the trimmed bounding box the grid is laid over (default 3; 0 = plain box) */
     PCC_OPT_FAR_MODE = 3,        /* queries the cell walk leaves: -1 auto, 0 exhaustive kernel, 1 seed scan + ball walk */
     PCC_OPT_ICP_WARM = 4,        /* pcc_icp_align: passes start from the previous pass's neighbours (default 1) */

@@ -27,7 +27,7 @@ void set_error(const char* fmt, ...) {
 void Options::from_env() {
     auto num = [](const char* name, double dflt) { const char* v = getenv(name); return v && *v ? atof(v) : dflt; };
     grid_ppc = num("PCC_GRID_PPC", grid_ppc);
-    if (!(grid_ppc > 0)) grid_ppc = 1.0;
+    if (!(grid_ppc > 0)) grid_ppc = 0.75;
     grid_trim = (int)num("PCC_GRID_TRIM", grid_trim);
     far_mode = (int)num("PCC_GRID_FAR", far_mode);
     icp_warm = (int)num("PCC_ICP_WARM", icp_warm);

@@ -24,7 +24,7 @@
 
 namespace pcc {
 
-constexpr float GRID_TARGET_PPC = 1.0f; // mean points per cell (over the bounding box) the cell size aims for (Options::grid_ppc);
+constexpr float GRID_TARGET_PPC = 0.75f; // mean points per cell (over the bounding box) the cell size aims for (Options::grid_ppc);
                                          // measured optimum on the corridor scene at 1M and 10M points
 constexpr unsigned int GRID_MAX_CELLS = 1u << 26;
 

@@ -86,8 +86,9 @@ struct GridDev {
 // Tuning knobs of one handle (pcc_index_set_option).  The PCC_* environment variables only supply the defaults a new
 // handle starts with; nothing in the library reads the environment after that.
 struct Options {
-    double grid_ppc = 1.0;          // PCC_OPT_GRID_PPC: mean references per cell the grid aims for (0.5 was the optimum of the lane-per-query
-                                    // kernel; with the flat kernels 0.7-1.0 is as fast at 10M and 4-7 % faster at 1M / 2M / 8M)
+    double grid_ppc = 0.75;         // PCC_OPT_GRID_PPC: mean references per cell the grid aims for (0.5 was the optimum of the lane-per-query
+                                    // kernel; with the flat kernels 0.7-1.0 is a plateau for volumetric scenes, surface scans of 10M points
+                                    // prefer 0.25-0.5, those of the reference's sizes 1.0: DESIGN.md 5)
     int grid_trim = 3;              // PCC_OPT_GRID_TRIM: k of the trimmed bounding box (0: plain bounding box)
     int far_mode = -1;              // PCC_OPT_FAR_MODE: -1 auto, 0 exhaustive fallback only, 1 always seed scan + ball walk
     int icp_warm = 1;               // PCC_OPT_ICP_WARM: ICP passes start from the previous pass's neighbours
