@@ -109,8 +109,13 @@ k_tie_walk(const FlannNode* __restrict__ nodes, const float* __restrict__ leaf_p
             const unsigned int i = list[shard * shard_cap + j];
             const float4 qv = q[i];
             const unsigned long long key = keys[i];
-            float d2 = 0.f;
-            const int32_t fi = flann_walk<STACK>(nodes, leaf_pts, root, n_valid, qv.x, qv.y, qv.z, &d2);
+            // the short walk first (the minimum distance is known: straight to the first reference at it); the full walk
+            // only where the short one cannot vouch for its answer (flann_tree.hpp)
+            const float bd = __uint_as_float((unsigned int)(key >> 32));
+            bool unc = true;
+            int32_t fi = flann_walk_tied<24>(nodes, leaf_pts, root, n_valid, qv.x, qv.y, qv.z, bd, &unc);
+            float d2 = bd;
+            if (unc) fi = flann_walk<STACK>(nodes, leaf_pts, root, n_valid, qv.x, qv.y, qv.z, &d2);
             if (fi >= 0 && __float_as_uint(d2) == (unsigned int)(key >> 32) && (unsigned int)fi != (unsigned int)key) {
                 keys[i] = (key & 0xffffffff00000000ull) | (unsigned int)fi;
                 changed = true;

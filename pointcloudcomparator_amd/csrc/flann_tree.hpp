@@ -136,6 +136,81 @@ PCC_FLANN_HD inline int32_t flann_walk(const FlannNode* nodes, const float* leaf
     return best;
 }
 
+// The same answer for a query whose minimum distance `bd` is KNOWN (the GPU search has it, exactly) and shared by two
+// or more references: the first of those the walk above would meet.  With the worst distance known from the start the
+// walk needs nothing beyond it: FLANN takes up a deferred far child when its bound does not exceed the worst distance of
+// that moment, which is never below bd -- so every branch with bound <= bd is visited by FLANN whatever it found before,
+// in the fixed near-first order, and a branch whose bound exceeds bd cannot hold a point at bd.  "Cannot" holds up to
+// the rounding of the bound (a sum and a difference of at most three squares, all of magnitude <= bd): branches whose
+// bound lies in a thin band above bd (2e-6 relative + 1.2e-37) are entered too, and if the first tied point found lies
+// under such a branch -- FLANN may or may not have gone there, depending on what it had found by then -- the caller is
+// told (`uncertain`) and runs the full walk.  Otherwise: ~depth node visits, a handful of deferred children, stop at the
+// first hit.  Returns the position, or -1 if no point at bd was met (then also `uncertain`).
+template <int STACK>
+PCC_FLANN_HD inline int32_t flann_walk_tied(const FlannNode* nodes, const float* leaf_pts, const FlannBox& root, size_t n_valid,
+                                            float qx, float qy, float qz, float bd, bool* uncertain) {
+    *uncertain = true;
+    if (n_valid == 0) return -1;
+    const float thr = bd * 1.000002f + 1.2e-37f;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, mind = 0.f;
+    if (qx < root.lo[0]) { d0 = (qx - root.lo[0]) * (qx - root.lo[0]); mind += d0; }
+    if (qx > root.hi[0]) { d0 = (qx - root.hi[0]) * (qx - root.hi[0]); mind += d0; }
+    if (qy < root.lo[1]) { d1 = (qy - root.lo[1]) * (qy - root.lo[1]); mind += d1; }
+    if (qy > root.hi[1]) { d1 = (qy - root.hi[1]) * (qy - root.hi[1]); mind += d1; }
+    if (qz < root.lo[2]) { d2 = (qz - root.lo[2]) * (qz - root.lo[2]); mind += d2; }
+    if (qz > root.hi[2]) { d2 = (qz - root.hi[2]) * (qz - root.hi[2]); mind += d2; }
+    if (!(mind <= thr)) return -1;  // (cannot be: the root bound is below every distance; the full walk sorts it out)
+    struct Deferred { int32_t node; float mind, d0, d1, d2; int band; };
+    Deferred stack[STACK];
+    int sp = 0;
+    int band = mind > bd ? 1 : 0;  // the current branch was admitted only thanks to the band
+    int32_t ni = 0;
+    for (;;) {
+        const FlannNode nd = nodes[ni];
+        if (nd.b < 0) {
+            const int32_t first = nd.a, cnt = ~nd.b;
+            for (int32_t i = first; i < first + cnt; ++i) {
+                const float* p = leaf_pts + (size_t)i * 4;
+                const float dx = qx - p[0], dy = qy - p[1], dz = qz - p[2];
+                float d = dx * dx;
+                d = d + dy * dy;
+                d = d + dz * dz;
+                if (d == bd) {
+                    int32_t w;
+                    memcpy(&w, p + 3, 4);
+                    *uncertain = band != 0;
+                    return w;
+                }
+            }
+            if (sp == 0) return -1;
+            const Deferred e = stack[--sp];
+            ni = e.node; mind = e.mind; d0 = e.d0; d1 = e.d1; d2 = e.d2; band = e.band;
+            continue;
+        }
+        const int f = nd.b;
+        const float val = f == 0 ? qx : (f == 1 ? qy : qz);
+        const float cur = f == 0 ? d0 : (f == 1 ? d1 : d2);
+        const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int32_t near_child, far_child;
+        float cut;
+        if (diff1 + diff2 < 0) { near_child = ni + 1; far_child = nd.a; cut = (val - nd.divhigh) * (val - nd.divhigh); }
+        else { near_child = nd.a; far_child = ni + 1; cut = (val - nd.divlow) * (val - nd.divlow); }
+        const float fm = mind + cut - cur;
+        if (fm <= thr) {
+            if (sp == STACK) return -1;  // (deeper than the stack: the caller's full walk decides)
+            Deferred e;
+            e.node = far_child;
+            e.mind = fm;
+            e.d0 = f == 0 ? cut : d0;
+            e.d1 = f == 1 ? cut : d1;
+            e.d2 = f == 2 ? cut : d2;
+            e.band = (band != 0 || fm > bd) ? 1 : 0;
+            stack[sp++] = e;
+        }
+        ni = near_child;
+    }
+}
+
 class FlannTree {
 public:
     std::vector<FlannNode> nodes;  // depth-first order, root at 0
@@ -177,6 +252,16 @@ public:
         std::vector<int32_t>().swap(vind_);
     }
 
+    // first reference at distance bd in FLANN's visit order (bd must be the query's exact minimum distance); falls back
+    // to the full walk when the short one cannot vouch for its answer
+    int32_t nearest_tied(const float q[3], float bd, bool* used_full = nullptr) const {
+        bool unc = true;
+        int32_t r = flann_walk_tied<32>(nodes.data(), leaf_pts.data(), root, n_valid, q[0], q[1], q[2], bd, &unc);
+        if (used_full) *used_full = unc;
+        if (!unc) return r;
+        float d2 = 0.f;
+        return nearest(q, &d2);
+    }
     // host walk (any depth: the stack grows to the tree's own depth in steps)
     int32_t nearest(const float q[3], float* d2) const {
         int32_t r = flann_walk<64>(nodes.data(), leaf_pts.data(), root, n_valid, q[0], q[1], q[2], d2);

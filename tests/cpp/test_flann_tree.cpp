@@ -39,12 +39,18 @@ int main(int argc, char** argv) {
     pcc::FlannTree t;
     t.build(packed.data(), n, rule, threads);
     printf("# n_valid %zu nodes %zu depth %d\n", t.n_valid, t.nodes.size(), t.depth);
+    size_t full_walks = 0;
     for (size_t j = 0; j < nq; ++j) {
         float d2 = 0.f;
         const int32_t idx = t.nearest(&qs[j * 3], &d2);
         uint32_t bits;
         memcpy(&bits, &d2, 4);
-        printf("%d %u\n", idx, bits);
+        // the short walk for a known minimum distance must name the same reference (or hand over to the full walk)
+        bool full = false;
+        const int32_t tied = t.nearest_tied(&qs[j * 3], d2, &full);
+        full_walks += full ? 1 : 0;
+        printf("%d %u %d\n", idx, bits, tied);
     }
+    printf("# short walks that handed over to the full walk: %zu of %zu\n", full_walks, nq);
     return 0;
 }

@@ -71,7 +71,14 @@ def _flann_tree_answers(tmp_path, pts, qs, rule, threads):
     np.ascontiguousarray(qs, np.float32).tofile(qf)
     out = subprocess.check_output([str(exe), str(pf), str(qf), str(rule), str(threads)], text=True)
     rows = [l.split() for l in out.splitlines() if not l.startswith("#")]
-    return np.array([int(r[0]) for r in rows], np.int64), np.array([int(r[1]) for r in rows], np.uint32)
+    handed = [l for l in out.splitlines() if l.startswith("# short walks")][0].split()
+    full, total = int(handed[-3]), int(handed[-1])
+    idx = np.array([int(r[0]) for r in rows], np.int64)
+    tied = np.array([int(r[2]) for r in rows], np.int64)
+    # the short walk (minimum distance known: what the device runs for tied queries) names the same reference as the full one
+    assert (tied == idx).all(), np.nonzero(tied != idx)[0][:5]
+    assert full <= total // 50, (full, total)  # and it is the short walk that answers, not its fallback
+    return idx, np.array([int(r[1]) for r in rows], np.uint32)
 
 
 @pytest.mark.parametrize("rule", [0, 1, 2])
