@@ -545,12 +545,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
 constexpr int FLAT_PLANES = 4;
 constexpr int FLAT_CAP = FLAT_PLANES * 2048;  // candidates one flat pass can hold; larger passes fall back to the lane walk
 
-__device__ __forceinline__ void flat_sync() {
-    // one wave, its own LDS block: DS operations of a wave execute in issue order, the compiler must keep that order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+__device__ __forceinline__ void flat_sync() { wave_lds_sync(); }  // (lane_ops.hpp)
 
 // Two passes.  The spans of a pass are laid out lane by lane (a lane's rows next to each other), so ONE wave scan
 // gives every lane its flat offset and its first record slot

@@ -217,27 +217,27 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
             if (mask == 0) return;
             if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
             scnt += (unsigned int)__popcll(mask);
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             if (scnt >= 64) {
                 const unsigned long long batch = stage[lane];
                 const unsigned int rest = scnt - 64;
                 const unsigned long long carry = lane < rest ? stage[64 + lane] : ~0ull;
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 if (lane < rest) stage[lane] = carry;
                 scnt = rest;
                 topk_merge<KR>(top, batch, lane);
                 tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
             }
         };
         auto flush = [&]() {
             if (scnt) {
                 const unsigned long long batch = lane < scnt ? stage[lane] : ~0ull;
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 topk_merge<KR>(top, batch, lane);
                 tau = shfl_u64(top[(want - 1) >> 6], (want - 1) & 63);
                 scnt = 0;
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
             }
         };
         // box of this pass and box already scanned (empty at first)
@@ -280,16 +280,16 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                     nspans += (unsigned int)__popcll(occ);
                     total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 unsigned int next_span = 0, carry_span = 0;  // wave-uniform
                 for (unsigned int B = 0; B < total; B += 64) {
                     win[lane] = 0u;
-                    __builtin_amdgcn_wave_barrier();
+                    wave_lds_sync();
                     const unsigned int r = next_span + lane;
                     const bool starts = r < nspans && tab_o[r] < B + 64;  // offsets are strictly increasing
                     if (starts) win[tab_o[r] - B] = r + 1;
                     next_span += (unsigned int)__popcll(__ballot(starts));
-                    __builtin_amdgcn_wave_barrier();
+                    wave_lds_sync();
                     unsigned int v = wave_incl_scan_max(win[lane]);
                     v = max(v, carry_span);
                     carry_span = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
@@ -594,6 +594,69 @@ __device__ __noinline__ void sort_long_row(unsigned long long* row, unsigned int
     }
 }
 
+// ---- rows in LDS: bucket + rank sort ------------------------------------------------------------------------
+// The hits of a radius search all lie below r^2, roughly evenly over [0, r^2) (surface: evenly; volume: ~sqrt): 128
+// buckets of equal width in d2 take one or two keys each.  Count (LDS atomics), scan the 128 counts over the lanes,
+// scatter the keys to their bucket's range, and give every key its rank among the few of its bucket: position =
+// bucket start + number of smaller keys there.  The bucket is a monotone function of d2 alone, so bucket-then-key
+// order IS key order.  ~110 VALU instructions for a row of 83 against ~390 of the bitonic network over 128 slots,
+// which moves every key through 28 compare-exchange steps wherever it started.  A bucket holding more than
+// BUCKET_FULL keys (lattices: few distinct distances) sends the row to the network instead.
+constexpr unsigned int BUCKET_ROW_MAX = 256, BUCKET_N = 128, BUCKET_FULL = 24;
+constexpr unsigned int ROW_LDS_MAX = 256;  // rows the fused fill keeps on the chip (longer ones: keys in memory, k_sort_rows)
+static_assert(ROW_LDS_MAX <= BUCKET_ROW_MAX, "every row kept in LDS can take the bucket sort");
+__device__ __forceinline__ unsigned int bucket_of(unsigned long long key, float scale) {
+    return (unsigned int)fminf(__uint_as_float((unsigned int)(key >> 32)) * scale, (float)(BUCKET_N - 1));
+}
+// (nothing is carried in registers from phase to phase: a key is read again and its bucket recomputed -- one DS read and
+// three VALU instructions per key and phase against 12 more live registers, which cost the whole kernel a wave per SIMD)
+template <int R>
+__device__ __forceinline__ bool bucket_sort_lds(unsigned long long* stage, unsigned long long* tmp, unsigned int* bk,
+                                                unsigned int have, float scale, unsigned int lane) {
+    // bk[0] = 0, bk[1 + b] = count, then fill pointer, then END of bucket b
+    bk[1 + 2 * lane] = 0u;
+    bk[2 + 2 * lane] = 0u;
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int e = (unsigned int)(r * 64) + lane;
+        if (e < have) atomicAdd(&bk[1 + bucket_of(stage[e], scale)], 1u);
+    }
+    wave_lds_sync();
+    const unsigned int c0 = bk[1 + 2 * lane], c1 = bk[2 + 2 * lane];
+    if (__ballot(max(c0, c1) > BUCKET_FULL) != 0ull) return false;
+    const unsigned int sum = c0 + c1;
+    const unsigned int ex = wave_incl_scan_add(sum) - sum;
+    wave_lds_sync();
+    if (lane == 0) bk[0] = 0u;
+    bk[1 + 2 * lane] = ex;
+    bk[2 + 2 * lane] = ex + c0;
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int e = (unsigned int)(r * 64) + lane;
+        if (e < have) {
+            const unsigned long long k = stage[e];
+            tmp[atomicAdd(&bk[1 + bucket_of(k, scale)], 1u)] = k;
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int e = (unsigned int)(r * 64) + lane;
+        if (e < have) {
+            const unsigned long long k = tmp[e];
+            const unsigned int bb = bucket_of(k, scale);
+            const unsigned int lo = bk[bb], hi = bk[bb + 1];
+            unsigned int pos = lo;
+            for (unsigned int j = lo; j < hi; ++j) pos += tmp[j] < k ? 1u : 0u;
+            stage[pos] = k;
+        }
+    }
+    wave_lds_sync();
+    return true;
+}
+
 // ---- wave-cooperative fill ------------------------------------------------------------------------
 // One WAVE per query for the fill pass: the rows of cells the r-ball touches go into an LDS table (lanes over
 // rows), their points are taken 64 at a time across row boundaries (as in k_grid_knn_wave), tested, and the hits
@@ -602,31 +665,42 @@ __device__ __noinline__ void sort_long_row(unsigned long long* row, unsigned int
 // 5M x 83 search.
 constexpr int RAD_ROWCAP = 11 * 11;
 constexpr unsigned int RAD_FLAT_CAP = 4 * 2048;  // flat candidates the span-end bits cover (4 planes of 64 words)
-__global__ void __launch_bounds__(256)
+// (8 waves per SIMD: the kernel waits on dependent loads most of its time -- 5.6 -> 4.9 ms at 5M x 83 against 6 waves; the
+// rows kept in LDS were halved to 256 and three registers spill to make room)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                         const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
                         const unsigned int* __restrict__ n_sorted_ptr, float r, float r2, const int64_t* __restrict__ offsets,
                         unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
                         int sorted) {
-    // FUSED (idx_out / d2_out given): a row of up to ROW_SORT_MAX neighbours never leaves the chip between the search and
+    // FUSED (idx_out / d2_out given): a row of up to ROW_LDS_MAX neighbours never leaves the chip between the search and
     // the caller's arrays -- its hits gather in LDS, are sorted in registers (PCL's sorted results) and go out as index
     // and squared distance in two coalesced stores.  Before: keys to memory (8 B), sorted in place by a second kernel
     // (16 B), unpacked by a third (16 B).  Longer rows keep that route (k_finish_long_rows).
-    __shared__ unsigned long long stage_all[4][ROW_SORT_MAX];
-    __shared__ unsigned int tab_s_all[4][RAD_ROWCAP], tab_o_all[4][RAD_ROWCAP], win_all[4][64], endb_all[4][4][64];
-    unsigned int (*endb)[64] = endb_all[threadIdx.x >> 6];
+    // per wave: the row tables of the search (dead once the last window is through) double as the bucket sort's second
+    // buffer, and its 130 counters sit in the upper half of the stage (rows it sorts fill at most the lower half)
+    struct alignas(8) Tables { unsigned int tab_s[RAD_ROWCAP + 1], tab_o[RAD_ROWCAP + 1], win[64], endb[4][64]; };
+    static_assert(sizeof(Tables) >= BUCKET_ROW_MAX * sizeof(unsigned long long), "the tables must hold the sort's second buffer");
+    __shared__ unsigned long long stage_all[4][ROW_LDS_MAX + (BUCKET_N + 2) / 2 + 1];
+    __shared__ Tables tables_all[4];
+    Tables& tb = tables_all[threadIdx.x >> 6];
+    unsigned int (*endb)[64] = tb.endb;
     unsigned long long* stage = stage_all[threadIdx.x >> 6];
     const bool fused = idx_out != nullptr || d2_out != nullptr;
-    unsigned int* tab_s = tab_s_all[threadIdx.x >> 6];
-    unsigned int* tab_o = tab_o_all[threadIdx.x >> 6];
-    unsigned int* win = win_all[threadIdx.x >> 6];
+    unsigned int* tab_s = tb.tab_s;
+    unsigned int* tab_o = tb.tab_o;
+    unsigned int* win = tb.win;
     const GridParams g = gd->g;
     const float slack = gd->slack;
     const unsigned int ns = *n_sorted_ptr;
     const unsigned int lane = threadIdx.x & 63;
+    // (tried and measured no gain, 5M x 83: a launch of exactly the resident workgroups so that the waves form a band
+    // marching through the cell-sorted queries, with or without one eighth of the order per XCD; 2 / 8 / 16 waves per
+    // workgroup for more L1 sharing between neighbouring queries; streaming stores)
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float bscale = (float)BUCKET_N / r2;
     for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
@@ -638,7 +712,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
         cell_range(qz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
         const int64_t row_beg = offsets[qi];
         const unsigned int row_len = (unsigned int)(offsets[qi + 1] - row_beg);
-        const bool in_lds = fused && row_len <= ROW_SORT_MAX;
+        const bool in_lds = fused && row_len <= ROW_LDS_MAX;
         unsigned long long* row_out = in_lds ? stage : keys + row_beg;
         unsigned int written = 0;  // wave-uniform
         const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
@@ -646,34 +720,29 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
         for (int rbase = 0; rbase < nrow; rbase += RAD_ROWCAP) {
             const int rchunk = min(RAD_ROWCAP, nrow - rbase);
             unsigned int nspans = 0, total = 0;
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             if (lane < 64) { endb[0][lane] = 0u; endb[1][lane] = 0u; endb[2][lane] = 0u; endb[3][lane] = 0u; }
-            __builtin_amdgcn_wave_barrier();
-            for (int base = 0; base < rchunk; base += 64) {
-                const int rr_i = base + (int)lane;
-                unsigned int s0 = 0, cnt = 0;
-                if (rr_i < rchunk) {
-                    // the row's cells the BALL reaches: a row whose y/z gap leaves nothing of r^2 is skipped, the others are
-                    // clipped to the chord (same slack as the cell range above; boundary rows of the grid are open-ended)
-                    const int rrow = rbase + rr_i;
-                    const int z = z0 + rrow / ny, y = y0 + rrow % ny;
-                    const float gy = fmaxf(fmaxf((y == 0 ? -__builtin_inff() : g.org[1] + y * g.h) - qy,
-                                                 qy - (y == g.dim[1] - 1 ? __builtin_inff() : g.org[1] + (y + 1) * g.h)) - slack, 0.f);
-                    const float gz = fmaxf(fmaxf((z == 0 ? -__builtin_inff() : g.org[2] + z * g.h) - qz,
-                                                 qz - (z == g.dim[2] - 1 ? __builtin_inff() : g.org[2] + (z + 1) * g.h)) - slack, 0.f);
-                    const float rem = rr * rr - (gy * gy + gz * gz) * 0.9999f;
-                    if (rem >= 0.f) {
-                        int xa, xb;
-                        cell_range(qx, sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
-                        xa = max(xa, x0);
-                        xb = min(xb, x1);
-                        if (xa <= xb) {
-                            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
-                            s0 = cell_start[row + xa];
-                            cnt = cell_start[row + xb + 1] - s0;
-                        }
+            wave_lds_sync();
+            // a row's cells the BALL reaches, given the squares of its y and z gaps: none if they leave nothing of r^2,
+            // else clipped to the chord (same slack as the cell range above).  (v_sqrt_f32 itself, 1 ulp: the factor
+            // 1.00001 and the slack absorb it; the libm form spends 20 instructions on the last bit)
+            auto span_of = [&](bool valid, int y, int z, float g2sum, unsigned int& s0, unsigned int& cnt) {
+                s0 = 0;
+                cnt = 0;
+                const float rem = rr * rr - g2sum * 0.9999f;
+                if (valid && rem >= 0.f) {
+                    int xa, xb;
+                    cell_range(qx, __builtin_amdgcn_sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
+                    xa = max(xa, x0);
+                    xb = min(xb, x1);
+                    if (xa <= xb) {
+                        const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                        s0 = cell_start[row + xa];
+                        cnt = cell_start[row + xb + 1] - s0;
                     }
                 }
+            };
+            auto record = [&](unsigned int s0, unsigned int cnt) {
                 const unsigned int incl = wave_incl_scan_add(cnt);
                 const unsigned long long occ = __ballot(cnt != 0);
                 if (cnt) {
@@ -688,8 +757,37 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 }
                 nspans += (unsigned int)__popcll(occ);
                 total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+            };
+            // gap of the coordinate v to cell c of an axis, shrunk by the slack (boundary cells of the grid are open-ended)
+            auto gap_of = [&](float v, int c, int dim, float org) {
+                return fmaxf(fmaxf((c == 0 ? -__builtin_inff() : org + c * g.h) - v,
+                                   v - (c == dim - 1 ? __builtin_inff() : org + (c + 1) * g.h)) - slack, 0.f);
+            };
+            if (ny <= 8 && nrow <= 8 * ny) {
+                // up to 8 x 8 rows (the usual radius: a few cells): lane = 8 * z + y, no division; the gaps depend on one
+                // axis each, so lanes 0-7 work out the y gaps, lanes 8-15 the z gaps -- one evaluation -- and every lane
+                // picks up its two (ds_bpermute).  Same values, same row order as the general form below.
+                const bool zlane = (lane & 8u) != 0u;
+                const float gp = gap_of(zlane ? qz : qy, (zlane ? z0 : y0) + (int)(lane & 7u), zlane ? g.dim[2] : g.dim[1],
+                                        zlane ? g.org[2] : g.org[1]);
+                const int g2 = __float_as_int(gp * gp);
+                const float gy2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane & 7u) << 2), g2));
+                const float gz2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((8u + (lane >> 3)) << 2), g2));
+                const int yi = (int)(lane & 7u), zi = (int)(lane >> 3);
+                unsigned int s0, cnt;
+                span_of(yi < ny && zi * ny < nrow, y0 + yi, z0 + zi, gy2 + gz2, s0, cnt);
+                record(s0, cnt);
+            } else
+            for (int base = 0; base < rchunk; base += 64) {
+                const int rr_i = base + (int)lane;
+                const int rrow = rbase + rr_i;
+                const int z = z0 + rrow / ny, y = y0 + rrow % ny;
+                const float gy = gap_of(qy, y, g.dim[1], g.org[1]), gz = gap_of(qz, z, g.dim[2], g.org[2]);
+                unsigned int s0, cnt;
+                span_of(rr_i < rchunk, y, z, gy * gy + gz * gz, s0, cnt);
+                record(s0, cnt);
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             if (total <= RAD_FLAT_CAP) {
                 // (four windows with their loads in flight together measured 5.6 against 5.3 ms at 5M x 83: the registers
                 // cost more occupancy than the overlap buys -- 28 resident waves per CU hide a single load already)
@@ -711,7 +809,10 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                     }
                     const unsigned long long mask = __ballot(hit);
                     const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
-                    if (hit && (!in_lds || slot < ROW_SORT_MAX)) row_out[slot] = key;
+                    if (hit) {
+                        if (in_lds) { if (slot < ROW_LDS_MAX) stage[slot] = key; }
+                        else keys[row_beg + slot] = key;
+                    }
                     written += (unsigned int)__popcll(mask);
                 }
                 continue;
@@ -719,12 +820,12 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
             unsigned int next_span = 0, carry_span = 0;
             for (unsigned int B = 0; B < total; B += 64) {
                 win[lane] = 0u;
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 const unsigned int sp = next_span + lane;
                 const bool starts = sp < nspans && tab_o[sp] < B + 64;
                 if (starts) win[tab_o[sp] - B] = sp + 1;
                 next_span += (unsigned int)__popcll(__ballot(starts));
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 unsigned int v = wave_incl_scan_max(win[lane]);
                 v = max(v, carry_span);
                 carry_span = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
@@ -741,19 +842,24 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 const unsigned long long mask = __ballot(hit);
                 // (a fill can only find what the count found -- same arithmetic --; the bound is belt and braces)
                 const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
-                if (hit && (!in_lds || slot < ROW_SORT_MAX)) row_out[slot] = key;
+                if (hit && (!in_lds || slot < ROW_LDS_MAX)) row_out[slot] = key;
                 written += (unsigned int)__popcll(mask);
             }
         }
         if (in_lds) {
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             const unsigned int have = written < row_len ? written : row_len;
             auto emit = [&](auto rc) {
                 constexpr int R = decltype(rc)::value;
+                bool in_order = !sorted || have < 2;
+                if constexpr (R * 64 <= (int)BUCKET_ROW_MAX) {
+                    if (!in_order)
+                        in_order = bucket_sort_lds<R>(stage, reinterpret_cast<unsigned long long*>(&tb), reinterpret_cast<unsigned int*>(stage + ROW_LDS_MAX), have, bscale, lane);
+                }
                 unsigned long long v[R];
 #pragma unroll
                 for (int rr_ = 0; rr_ < R; ++rr_) v[rr_] = (unsigned int)(rr_ * 64) + lane < have ? stage[rr_ * 64 + lane] : ~0ull;
-                if (sorted) bitonic_sort_regs<R>(v, lane);
+                if (!in_order) bitonic_sort_regs<R>(v, lane);
 #pragma unroll
                 for (int rr_ = 0; rr_ < R; ++rr_) {
                     const unsigned int e = (unsigned int)(rr_ * 64) + lane;
@@ -766,9 +872,8 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
             };
             if (row_len <= 64) emit(std::integral_constant<int, 1>{});
             else if (row_len <= 128) emit(std::integral_constant<int, 2>{});
-            else if (row_len <= 256) emit(std::integral_constant<int, 4>{});
-            else emit(std::integral_constant<int, 8>{});
-            __builtin_amdgcn_wave_barrier();
+            else emit(std::integral_constant<int, 4>{});
+            wave_lds_sync();
         }
     }
 }
@@ -825,7 +930,7 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
                            fused ? idx_out : nullptr, fused ? d2_out : nullptr, sorted);
         PCC_HIP(hipGetLastError());
         if (fused) {  // what is left: rows beyond the register sort, still as keys in memory
-            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, ROW_SORT_MAX + 1, sorted, idx_out, d2_out);
+            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, ROW_LDS_MAX + 1, sorted, idx_out, d2_out);
             PCC_HIP(hipGetLastError());
             *delivered = true;
         } else if (sorted) {

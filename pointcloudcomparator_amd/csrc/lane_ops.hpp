@@ -9,6 +9,17 @@
 
 namespace pcc {
 
+// Lanes of ONE wave exchanging data through LDS: the DS operations of a wave execute in issue order, so no hardware
+// barrier is needed -- but the compiler must keep that order and must not forward a lane's own store to its later load
+// of the same address when another lane's store or atomic may have landed in between (it reasons per thread:
+// __builtin_amdgcn_wave_barrier alone is "no memory effect" to it, and a load was seen sunk into the branch of the
+// lane's own atomic).  Release / acquire fences at wavefront scope emit no instruction and say exactly that.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // value of lane (lane ^ m); m must fold to a constant in {1, 2, 4, 8, 16, 32}
 __device__ __forceinline__ unsigned int xor_lane_u32(unsigned int x, int m, unsigned int lane) {
     switch (m) {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pcc_internal.hpp"
+#include "lane_ops.hpp"
 #include "grid_device.hpp"
 #include "plane_fit.hpp"
 
@@ -44,7 +45,7 @@ k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict_
         bool open = have;  // row not exhausted yet
         for (int c0 = 0; c0 < K; c0 += NR_KC) {
             const int kc = min(NR_KC, K - c0);
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             for (int r = 0; r < 64; ++r) {
                 const unsigned int rr = base + r;
                 if (rr >= n_valid) break;  // wave-uniform
@@ -55,7 +56,7 @@ k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict_
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             for (int j = 0; j < kc; ++j) {
                 const unsigned int idx = open ? tile[lane][j] : 0xffffffffu;
                 if (idx == 0xffffffffu) { open = false; continue; }

@@ -364,13 +364,13 @@ k_sor_mean_staged(const unsigned long long* __restrict__ keys, size_t n, int K, 
         const unsigned int rows = (unsigned int)min((size_t)64, n - base);
         const unsigned int total = rows * (unsigned int)K;
         const unsigned long long* src = keys + base * (size_t)K;
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         for (unsigned int f = lane; f < total; f += 64) {
             const unsigned int r = f / (unsigned int)K, c = f - r * (unsigned int)K;
             tile[r * (K + 1) + c] = (unsigned int)(src[f] >> 32);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         if (lane < rows) {
             const unsigned int* row = tile + lane * (K + 1);
             if (row[K - 1] < 0x7f7fffffu) {  // else: invalid point or fewer than K neighbours (key_none), distance stays 0
