@@ -143,8 +143,10 @@ enum pcc_option {
     PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query; 1 rows drained with lanes over candidates (default);
                                     2 / 3 the same with the open lanes always listed for a second kernel / always finished in place */
     PCC_OPT_FLANN_SPLIT = 10,    /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
-    PCC_OPT_NN1_DENSE_MIN = 11   /* flat k = 1 kernel: a wave whose queries' own cells hold at least this many references on average
+    PCC_OPT_NN1_DENSE_MIN = 11,  /* flat k = 1 kernel: a wave whose queries' own cells hold at least this many references on average
                                     takes its first bound from the own cell instead of the own row (default 4) */
+    PCC_OPT_KNN_KERNEL = 12      /* k-NN, k <= 128: 1 = selection by distance buckets, the merge network only for the queries it
+                                    hands back (default); 0 = the merge network for every query */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -38,6 +38,7 @@ void Options::from_env() {
     nn1_kernel = (int)num("PCC_NN1_KERNEL", nn1_kernel);
     flann_split = (int)num("PCC_FLANN_SPLIT", flann_split);
     nn1_dense_min = (int)num("PCC_NN1_DENSE_MIN", nn1_dense_min);
+    knn_kernel = (int)num("PCC_KNN_KERNEL", knn_kernel);
 }
 
 int DevBuf::reserve(size_t bytes) {
@@ -225,7 +226,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -474,6 +475,7 @@ static double* option_slot(pcc_index* ix, int option, int** as_int) {
         case PCC_OPT_NN1_KERNEL: *as_int = &o.nn1_kernel; return nullptr;
         case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
         case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
+        case PCC_OPT_KNN_KERNEL: *as_int = &o.knn_kernel; return nullptr;
         default: return nullptr;
     }
 }
@@ -581,9 +583,6 @@ int pcc_knn(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, q, nq, stride, mem));
-    PCC_TRY(ix->out_packed.reserve(nq * (size_t)k * sizeof(unsigned long long)));
-    auto* keys = ix->out_packed.as<unsigned long long>();
-    PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, k, keys));
     int32_t* didx = idx;
     float* dd2 = d2;
     if (mem == PCC_MEM_HOST) {
@@ -592,8 +591,16 @@ int pcc_knn(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
         dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
     }
-    // rows of invalid queries were never touched (all ~0) and unpack to -1 / +inf
-    PCC_TRY(launch_unpack(ix->stream, keys, nullptr, nq * (size_t)k, didx, dd2));
+    if (grid_knn_delivers(k)) {
+        // the search writes indices and distances itself (no key array, no unpack pass)
+        PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, k, nullptr, didx, dd2));
+    } else {
+        PCC_TRY(ix->out_packed.reserve(nq * (size_t)k * sizeof(unsigned long long)));
+        auto* keys = ix->out_packed.as<unsigned long long>();
+        PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, k, keys));
+        // rows of invalid queries were never touched (all ~0) and unpack to -1 / +inf
+        PCC_TRY(launch_unpack(ix->stream, keys, nullptr, nq * (size_t)k, didx, dd2));
+    }
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq * (size_t)k, mem));

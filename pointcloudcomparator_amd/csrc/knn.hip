@@ -100,6 +100,7 @@ k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     }
 }
 
+constexpr unsigned int RAD_FLAT_CAP = 4 * 2048;  // flat candidates the span-end bits cover (4 planes of 64 words)
 constexpr int KNN_BOX_MAX = 64;  // half-width (cells) up to which a box is walked (row by row beyond the LDS table); past it: whole grid
 
 // ---- wave-cooperative k-NN (K <= 512) ---------------------------------------------------------
@@ -154,11 +155,35 @@ __device__ __forceinline__ void topk_merge(unsigned long long (&top)[KR], unsign
     }
 }
 
+// where a k-NN row goes: the key array (internal consumers: SOR, normals, region growing) or straight into the caller's
+// index / distance arrays (pcc_knn: no key array, no unpack pass over K entries per query)
+struct KnnOut {
+    unsigned long long* keys;
+    int32_t* idx;
+    float* d2;
+};
+__device__ __forceinline__ void knn_emit(const KnnOut& o, size_t p, unsigned long long key) {
+    if (o.keys) {
+        o.keys[p] = key;
+    } else {
+        const bool none = key_none(key);
+        if (o.idx) o.idx[p] = none ? -1 : (int32_t)(unsigned int)key;
+        if (o.d2) o.d2[p] = none ? __builtin_inff() : __uint_as_float((unsigned int)(key >> 32));
+    }
+}
+// rows of non-finite queries (flagged w < 0 by the pack; the searches never see them): "nothing found" throughout
+__global__ void __launch_bounds__(256)
+k_knn_fill_invalid(const float4* __restrict__ q, unsigned int nq, int K, KnnOut out) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq || __float_as_int(q[i].w) >= 0) return;
+    for (int e = 0; e < K; ++e) knn_emit(out, (size_t)i * K + e, ~0ull);
+}
+
 template <int KR>
 __global__ void __launch_bounds__(256)
 k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                 const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-                const unsigned int* __restrict__ n_sorted_ptr, int K, unsigned long long* __restrict__ keys) {
+                const unsigned int* __restrict__ n_sorted_ptr, int K, KnnOut out) {
     static_assert(KR == 1 || KR == 2 || KR == 4 || KR == 8, "top list: 64 * KR keys in KR registers per lane");
     __shared__ unsigned long long stage_all[4][128];
     // two spans per row; boxes of up to 11 x 11 rows take the flat walk -- up to the largest cube (19 x 19) for
@@ -362,28 +387,425 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 tau = ~0ull;
             }
         }
-        unsigned long long* list = keys + (size_t)qi * K;
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
             const int e = r * 64 + (int)lane;
-            if (e < K) list[e] = top[r];
+            if (e < K) knn_emit(out, (size_t)qi * K + e, top[r]);
         }
     }
 }
 
-int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys) {
+// ---- sorting the rows of a filled radius search ---------------------------------------------------
+// pcl::KdTreeFLANN::radiusSearch returns its neighbours ascending by distance.  One WAVE per row: the row's
+// keys live in R registers per lane (element e = r * 64 + lane), a bitonic network sorts them -- exchanges at
+// distance < 64 cross lanes (DPP / permlane, lane_ops.hpp), larger distances pair registers of the same lane --
+// and the row is written back.  The one-lane insertion sort this replaces was O(len^2) global-memory moves:
+// 127 ms of a 141 ms search (5M queries, 83 neighbours each).
+template <int R>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&v)[R], unsigned int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int jr = j >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int rp = r ^ jr;
+                    if (rp > r) {
+                        const bool up = ((r * 64) & k) == 0;  // k > j >= 64: decided by the register index
+                        const unsigned long long a = v[r], b = v[rp];
+                        const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+                        v[r] = up ? lo : hi;
+                        v[rp] = up ? hi : lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool up = (((unsigned int)(r * 64) + lane) & (unsigned int)k) == 0;
+                    v[r] = cmpx(v[r], j, ((lane & (unsigned int)j) == 0) == up, lane);
+                }
+            }
+        }
+    }
+}
+
+// ---- rows in LDS: bucket + rank sort ------------------------------------------------------------------------
+// The hits of a radius search all lie below r^2, roughly evenly over [0, r^2) (surface: evenly; volume: ~sqrt): 128
+// buckets of equal width in d2 take one or two keys each.  Count (LDS atomics), scan the 128 counts over the lanes,
+// scatter the keys to their bucket's range, and give every key its rank among the few of its bucket: position =
+// bucket start + number of smaller keys there.  The bucket is a monotone function of d2 alone, so bucket-then-key
+// order IS key order.  ~110 VALU instructions for a row of 83 against ~390 of the bitonic network over 128 slots,
+// which moves every key through 28 compare-exchange steps wherever it started.  A bucket holding more than
+// BUCKET_FULL keys (lattices: few distinct distances) sends the row to the network instead.
+constexpr unsigned int BUCKET_ROW_MAX = 256, BUCKET_N = 128, BUCKET_FULL = 24;
+constexpr unsigned int ROW_LDS_MAX = 256;  // rows the fused fill keeps on the chip (longer ones: keys in memory, k_sort_rows)
+static_assert(ROW_LDS_MAX <= BUCKET_ROW_MAX, "every row kept in LDS can take the bucket sort");
+__device__ __forceinline__ unsigned int bucket_of(unsigned long long key, float scale) {
+    return (unsigned int)fminf(__uint_as_float((unsigned int)(key >> 32)) * scale, (float)(BUCKET_N - 1));
+}
+// (nothing is carried in registers from phase to phase: a key is read again and its bucket recomputed -- one DS read and
+// three VALU instructions per key and phase against 12 more live registers, which cost the whole kernel a wave per SIMD)
+template <int R>
+__device__ __forceinline__ bool bucket_sort_lds(unsigned long long* stage, unsigned long long* tmp, unsigned int* bk,
+                                                unsigned int have, float scale, unsigned int lane) {
+    // bk[0] = 0, bk[1 + b] = count, then fill pointer, then END of bucket b
+    bk[1 + 2 * lane] = 0u;
+    bk[2 + 2 * lane] = 0u;
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int e = (unsigned int)(r * 64) + lane;
+        if (e < have) atomicAdd(&bk[1 + bucket_of(stage[e], scale)], 1u);
+    }
+    wave_lds_sync();
+    const unsigned int c0 = bk[1 + 2 * lane], c1 = bk[2 + 2 * lane];
+    if (__ballot(max(c0, c1) > BUCKET_FULL) != 0ull) return false;
+    const unsigned int sum = c0 + c1;
+    const unsigned int ex = wave_incl_scan_add(sum) - sum;
+    wave_lds_sync();
+    if (lane == 0) bk[0] = 0u;
+    bk[1 + 2 * lane] = ex;
+    bk[2 + 2 * lane] = ex + c0;
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int e = (unsigned int)(r * 64) + lane;
+        if (e < have) {
+            const unsigned long long k = stage[e];
+            tmp[atomicAdd(&bk[1 + bucket_of(k, scale)], 1u)] = k;
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned int e = (unsigned int)(r * 64) + lane;
+        if (e < have) {
+            const unsigned long long k = tmp[e];
+            const unsigned int bb = bucket_of(k, scale);
+            const unsigned int lo = bk[bb], hi = bk[bb + 1];
+            unsigned int pos = lo;
+            for (unsigned int j = lo; j < hi; ++j) pos += tmp[j] < k ? 1u : 0u;
+            stage[pos] = k;
+        }
+    }
+    wave_lds_sync();
+    return true;
+}
+
+// ---- k-NN by selection (K <= 128) ------------------------------------------------------------------------------
+// The merge network above is the whole cost of the kernel (VALU 118 % busy, ~1400 instructions per query at K = 51,
+// ~1000 of them compare-exchanges): every 64 survivors are sorted and merged into the running list.  Here nothing is
+// merged.  Pass 1 walks the same cube (>= 2K points), keeps every candidate key in LDS and counts d2 into 128 buckets
+// over the cube's d2 range; a scan of the counts names the bucket b* that holds the K-th -- so the K nearest all
+// have bucket <= b*, and (b* + 1) / scale is an upper bound of the K-th distance.  The kept keys with bucket <= b* are
+// compacted in place, pass 2 adds what the ball of that bound holds outside the cube (same filter), and the few more
+// than K survivors are ordered by the bucket + rank sort (finer buckets over [0, bound]); the first K leave.  Same
+// set, same order as the network: both are the K smallest (d2, index) keys of a candidate set that covers the ball of
+// the K-th.  A query that does not fit -- cube beyond the tables, more candidates than LDS holds, more survivors than
+// the sort takes (many equal distances), bound in the clamped last bucket (queries far outside the grid), fewer than
+// K points around -- goes on a list that k_grid_knn_wave works off afterwards.
+template <int CAP, bool STORE>
+__global__ void __launch_bounds__(256)
+k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
+               const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+               const unsigned int* __restrict__ n_sorted_ptr, int K, KnnOut out,
+               unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    constexpr unsigned int SCAP = BUCKET_ROW_MAX;  // survivors the final sort takes
+    constexpr int ROWCAP = 11 * 11, SPANCAP = 2 * ROWCAP;
+    static_assert(CAP >= 2 * (int)SCAP, "the sort's second buffer is the upper part of the candidate buffer");
+    struct alignas(8) WaveLds {
+        unsigned long long cand[CAP];
+        unsigned int bk[BUCKET_N + 2], tab_s[SPANCAP], endb[64];
+        unsigned short tab_o[SPANCAP];  // (flat offsets stay below SEL_FLAT_CAP)
+    };
+    constexpr unsigned int SEL_FLAT_CAP = 2048;  // candidates of one pass: one plane of span-end bits (25 KB of LDS: 6 waves per SIMD)
+    __shared__ WaveLds lds_all[4];
+    WaveLds& L = lds_all[threadIdx.x >> 6];
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    const unsigned int n_valid = gd->n_valid;
+    const unsigned int ns = *n_sorted_ptr;
+    if (n_valid == 0) return;
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
+        const unsigned int qi = order[t];
+        const float4 qv = q[qi];
+        const float qx = qv.x, qy = qv.y, qz = qv.z;
+        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+        auto give_up = [&]() {
+            if (lane == 0) fb_list[atomicAdd(fb_count, 1u)] = qi;
+        };
+        // the smallest cube that holds at least 2 x `want` points (as k_grid_knn_wave).  A lane looks after rows `lane` and
+        // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1
+        int k = 1;
+        unsigned int cnt = 0, rs0[2], rc[2];
+        for (;; ++k) {
+            const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+            const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+            const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+            const float inv_ny = 1.0f / (float)ny;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (int)lane + 64 * i;
+                rs0[i] = 0;
+                rc[i] = 0;
+                if (r < nrow) {
+                    const int zi = (int)(((float)r + 0.5f) * inv_ny);  // r / ny (exact: r < 128, ny <= 11)
+                    const unsigned int row = ((unsigned int)(z0 + zi) * g.dim[1] + (y0 + (r - zi * ny))) * g.dim[0];
+                    rs0[i] = cell_start[row + x0];
+                    rc[i] = cell_start[row + x1 + 1] - rs0[i];
+                }
+            }
+            cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(rc[0] + rc[1]), 63);
+            if (cnt >= 2u * (unsigned int)want || k >= 5) break;  // (k = 5: 11 x 11 rows, the table)
+        }
+        if (cnt < (unsigned int)want || cnt > (STORE ? (unsigned int)CAP : SEL_FLAT_CAP)) { give_up(); continue; }
+        int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+        int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+        int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+        int ix0 = 1, ix1 = 0, iy0 = 1, iy1 = 0, iz0 = 1, iz1 = 0;  // box already scanned (none yet)
+        // span table: (start in cell_refs, flat offset) per non-empty span, and one bit per span END over the flat candidate
+        // positions, transposed as in k_grid_radius_fill_wave
+        unsigned int nspans = 0, total = 0;  // wave-uniform
+        auto table_reset = [&]() {
+            nspans = 0;
+            total = 0;
+            wave_lds_sync();
+            L.endb[lane] = 0u;
+            wave_lds_sync();
+        };
+        auto table_add = [&](unsigned int s0, unsigned int c) {
+            const unsigned int incl = wave_incl_scan_add(c);
+            const unsigned long long occ = __ballot(c != 0);
+            if (c) {
+                const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
+                const unsigned int off = total + incl - c;
+                L.tab_s[slot] = s0;
+                const unsigned int e = off + c - 1;
+                if (e < SEL_FLAT_CAP) {
+                    L.tab_o[slot] = (unsigned short)off;
+                    atomicOr(&L.endb[e & 63], 1u << (e >> 6));
+                }
+            }
+            nspans += (unsigned int)__popcll(occ);
+            total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+        };
+        // the box minus the box already scanned: a row crossing it gives its left and its right part
+        auto build_table = [&]() {
+            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+            const float inv_ny = 1.0f / (float)ny;
+            table_reset();
+            for (int base = 0; base < nrow; base += 64) {
+                const int r = base + (int)lane;
+                unsigned int s0 = 0, c0 = 0, s1 = 0, c1 = 0;
+                if (r < nrow) {
+                    const int zi = (int)(((float)r + 0.5f) * inv_ny);
+                    const int z = z0 + zi, y = y0 + (r - zi * ny);
+                    const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                    if (y >= iy0 && y <= iy1 && z >= iz0 && z <= iz1) {
+                        if (x0 < ix0) { s0 = cell_start[row + x0]; c0 = cell_start[row + ix0] - s0; }
+                        if (ix1 < x1) { s1 = cell_start[row + ix1 + 1]; c1 = cell_start[row + x1 + 1] - s1; }
+                    } else {
+                        s0 = cell_start[row + x0];
+                        c0 = cell_start[row + x1 + 1] - s0;
+                    }
+                }
+                table_add(s0, c0);
+                if (__ballot(c1 != 0) != 0ull) table_add(s1, c1);
+            }
+            wave_lds_sync();
+        };
+        // the table's candidates 64 at a time: fn(flat position, key, in range)
+        auto walk = [&](auto&& fn) {
+            unsigned int before = 0, word = 0;
+            // two windows per turn, both loads in flight before the first is used
+            for (unsigned int B = 0; B < total; B += 128) {
+                unsigned int my[2], c[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned int w = (B >> 6) + (unsigned int)u;
+                    if (w == 0u) word = L.endb[lane];
+                    const unsigned long long m = __ballot(((word >> (w & 31u)) & 1u) != 0u);  // (w < 32: total <= SEL_FLAT_CAP)
+                    my[u] = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
+                    before += (unsigned int)__popcll(m);
+                    c[u] = B + 64u * (unsigned int)u + lane;
+                }
+                float4 r4[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned int cc = min(c[u], total - 1u), mm = min(my[u], nspans - 1u);
+                    r4[u] = cell_refs[L.tab_s[mm] + (cc - (unsigned int)L.tab_o[mm])];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && B + 64u >= total) break;
+                    fn(c[u], make_key(dist2(qx, qy, qz, r4[u]), r4[u]), c[u] < total);
+                }
+            }
+        };
+        // ---- pass 1: every candidate of the cube kept, d2 counted into buckets over the cube's d2 range
+        {
+            const float reach = (float)(k + 1) * g.h;
+            const float scale1 = (float)BUCKET_N / (3.03f * reach * reach);
+            table_reset();
+            table_add(rs0[0], rc[0]);
+            if ((2 * k + 1) * (2 * k + 1) > 64) table_add(rs0[1], rc[1]);
+            L.bk[1 + 2 * lane] = 0u;
+            L.bk[2 + 2 * lane] = 0u;
+            wave_lds_sync();
+            // (STORE: the keys are kept for the compaction below; otherwise -- K > 64, cubes of up to a thousand points, whose
+            // keys would cost half the resident waves -- the cube is walked a second time)
+            walk([&](unsigned int c, unsigned long long key, bool in) {
+                if (in) {
+                    if constexpr (STORE) L.cand[c] = key;
+                    atomicAdd(&L.bk[1 + bucket_of(key, scale1)], 1u);
+                }
+            });
+            wave_lds_sync();
+            // the bucket that holds the `want`-th: first one whose running count reaches it
+            const unsigned int c0 = L.bk[1 + 2 * lane], c1 = L.bk[2 + 2 * lane];
+            const unsigned int incl = wave_incl_scan_add(c0 + c1);
+            const unsigned long long reached = __ballot(incl >= (unsigned int)want);
+            // (total >= want, so some lane has reached it)
+            const int fl = __builtin_ctzll(reached);
+            const unsigned int i_fl = (unsigned int)__builtin_amdgcn_readlane((int)incl, fl);
+            const unsigned int c0_fl = (unsigned int)__builtin_amdgcn_readlane((int)c0, fl);
+            const unsigned int c1_fl = (unsigned int)__builtin_amdgcn_readlane((int)c1, fl);
+            const bool first_half = i_fl - c1_fl >= (unsigned int)want;
+            const unsigned int bstar = 2u * (unsigned int)fl + (first_half ? 0u : 1u);
+            const unsigned int s1 = first_half ? i_fl - c1_fl : i_fl;  // cube candidates with bucket <= b*
+            (void)c0_fl;
+            if (bstar >= BUCKET_N - 1 || s1 > SCAP) { give_up(); continue; }
+            const float bound = (float)(bstar + 1) / scale1 * 1.00001f;  // every d2 >= bound has a bucket > b*
+            // the kept keys with bucket <= b*, compacted to the front of the buffer (in place: a window is read whole
+            // before its survivors are written, and they land at or before their own position)
+            unsigned int scnt = 0;
+            // a window's keys with bucket <= b* appended to the survivors
+            auto keep = [&](unsigned int, unsigned long long key, bool in) {
+                const bool pass = in && bucket_of(key, scale1) <= bstar;
+                const unsigned long long mask = __ballot(pass);
+                const unsigned int slot = scnt + (unsigned int)__popcll(mask & lt_mask);
+                if (pass && slot < SCAP) L.cand[slot] = key;
+                scnt += (unsigned int)__popcll(mask);
+            };
+            if constexpr (STORE) {
+                for (unsigned int B = 0; B < total; B += 64) {
+                    const unsigned int c = B + lane;
+                    const unsigned long long key = c < total ? L.cand[c] : ~0ull;
+                    const bool pass = c < total && bucket_of(key, scale1) <= bstar;
+                    const unsigned long long mask = __ballot(pass);
+                    wave_lds_sync();
+                    if (pass) L.cand[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+                    scnt += (unsigned int)__popcll(mask);
+                    wave_lds_sync();
+                }
+            } else {
+                walk(keep);  // (s1 <= SCAP: they all fit)
+                wave_lds_sync();
+            }
+            // ---- pass 2: what the ball of the bound holds outside the cube
+            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+            bool fits = true;
+            if (!(bound < lb2)) {
+                const float rb = sqrtf(bound) * 1.00001f + slack;
+                int a0, a1, b0, b1, e0, e1;
+                cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
+                cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
+                cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], e0, e1);
+                ix0 = x0; ix1 = x1; iy0 = y0; iy1 = y1; iz0 = z0; iz1 = z1;
+                x0 = min(x0, a0); x1 = max(x1, a1); y0 = min(y0, b0); y1 = max(y1, b1); z0 = min(z0, e0); z1 = max(z1, e1);
+                if ((y1 - y0 + 1) * (z1 - z0 + 1) > ROWCAP) fits = false;
+                if (fits) {
+                    build_table();
+                    if (total > SEL_FLAT_CAP) fits = false;
+                }
+                if (fits) {
+                    walk(keep);
+                    wave_lds_sync();
+                    if (scnt > SCAP) fits = false;
+                }
+            }
+            if (!fits) { give_up(); continue; }
+            // ---- the survivors in order: finer buckets over [0, bound]; a crowded bucket (equal distances) -> the network
+            const float scale2 = (float)BUCKET_N / bound;
+            unsigned long long* tmp = L.cand + SCAP;
+            bool in_order = scnt < 2;
+            if (!in_order) {
+                if (scnt <= 64) in_order = bucket_sort_lds<1>(L.cand, tmp, L.bk, scnt, scale2, lane);
+                else if (scnt <= 128) in_order = bucket_sort_lds<2>(L.cand, tmp, L.bk, scnt, scale2, lane);
+                else in_order = bucket_sort_lds<4>(L.cand, tmp, L.bk, scnt, scale2, lane);
+            }
+            // (entries past `want` -- K beyond the number of valid references -- are "nothing found")
+            const size_t row0 = (size_t)qi * K;
+            if (in_order) {
+                for (unsigned int e = lane; e < (unsigned int)K; e += 64) knn_emit(out, row0 + e, e < (unsigned int)want ? L.cand[e] : ~0ull);
+            } else {
+                unsigned long long v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (unsigned int)(r * 64) + lane < scnt ? L.cand[r * 64 + lane] : ~0ull;
+                bitonic_sort_regs<4>(v, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned int e = (unsigned int)(r * 64) + lane;
+                    if (e < (unsigned int)K) knn_emit(out, row0 + e, e < (unsigned int)want ? v[r] : ~0ull);
+                }
+            }
+        }
+    }
+}
+
+// keys: the rows as search keys; or keys == nullptr and idx_out / d2_out (either may be null): the rows delivered as
+// indices and squared distances (K <= 512 only -- check with grid_knn_delivers)
+bool grid_knn_delivers(int K) { return K <= 512; }
+int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys, int32_t* idx_out, float* d2_out) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)nq;
-    PCC_HIP(hipMemsetAsync(keys, 0xff, nq * (size_t)K * sizeof(unsigned long long), s));
+    const KnnOut out{keys, keys ? nullptr : idx_out, keys ? nullptr : d2_out};
+    if (K > 512) {
+        if (!keys) { set_error("grid_knn: K > 512 needs the key array"); return PCC_ERR_INVALID; }
+        PCC_HIP(hipMemsetAsync(keys, 0xff, nq * (size_t)K * sizeof(unsigned long long), s));
+    } else {
+        // (the wave kernels write every entry of every valid query's row; only the rows of non-finite queries are left)
+        hipLaunchKernelGGL(k_knn_fill_invalid, dim3((n + 255) / 256), dim3(256), 0, s, q, n, K, out);
+        PCC_HIP(hipGetLastError());
+    }
     unsigned int *order = nullptr, *n_sorted = nullptr;
     PCC_TRY(grid_sort_queries(ix, q, nq, &order, &n_sorted));
     ev_mark(ix, EV_MAIN0);
     if (K <= 512) {
         unsigned int gw = (n + 3) / 4;  // one wave per query, 4 waves per workgroup, waves loop
         if (gw > 8192) gw = 8192;
+        // K <= 128: selection kernel first; the queries it hands back are worked off by the merge kernel below
+        const unsigned int* work = order;
+        const unsigned int* n_work = n_sorted;
+        if (K <= 128 && ix->opt.knn_kernel != 0) {
+            // (K > 64: keeping a thousand keys per wave leaves 3 waves per SIMD and the VALU 60 % busy -- 2.66 ms at 1M x K = 100;
+            // the 512-key form first and only its returns through a 1024-key one: 3.18 ms -- half the cubes hold more than 512)
+            PCC_TRY(ix->knn_fb.reserve((nq + 1) * sizeof(unsigned int)));
+            unsigned int* fb = ix->knn_fb.as<unsigned int>();
+            PCC_HIP(hipMemsetAsync(fb + nq, 0, sizeof(unsigned int), s));
+            if (K <= 64)
+                hipLaunchKernelGGL((k_grid_knn_sel<512, true>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                                   ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq);
+            else
+                hipLaunchKernelGGL((k_grid_knn_sel<512, false>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                                   ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq);
+            PCC_HIP(hipGetLastError());
+            work = fb;
+            n_work = fb + nq;
+        }
 #define PCC_LAUNCH_KNN(KR)                                                                                         \
     hipLaunchKernelGGL((k_grid_knn_wave<KR>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),               \
-                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, keys)
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, work, n_work, K, out)
         if (K <= 64) PCC_LAUNCH_KNN(1);
         else if (K <= 128) PCC_LAUNCH_KNN(2);
         else if (K <= 256) PCC_LAUNCH_KNN(4);
@@ -491,42 +913,6 @@ int grid_first_within(pcc_index* ix, const float4* q, size_t nq, double radius, 
     return PCC_OK;
 }
 
-// ---- sorting the rows of a filled radius search ---------------------------------------------------
-// pcl::KdTreeFLANN::radiusSearch returns its neighbours ascending by distance.  One WAVE per row: the row's
-// keys live in R registers per lane (element e = r * 64 + lane), a bitonic network sorts them -- exchanges at
-// distance < 64 cross lanes (DPP / permlane, lane_ops.hpp), larger distances pair registers of the same lane --
-// and the row is written back.  The one-lane insertion sort this replaces was O(len^2) global-memory moves:
-// 127 ms of a 141 ms search (5M queries, 83 neighbours each).
-template <int R>
-__device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&v)[R], unsigned int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64 * R; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const int jr = j >> 6;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int rp = r ^ jr;
-                    if (rp > r) {
-                        const bool up = ((r * 64) & k) == 0;  // k > j >= 64: decided by the register index
-                        const unsigned long long a = v[r], b = v[rp];
-                        const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
-                        v[r] = up ? lo : hi;
-                        v[rp] = up ? hi : lo;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const bool up = (((unsigned int)(r * 64) + lane) & (unsigned int)k) == 0;
-                    v[r] = cmpx(v[r], j, ((lane & (unsigned int)j) == 0) == up, lane);
-                }
-            }
-        }
-    }
-}
-
 template <int R>
 __device__ __forceinline__ void sort_row(unsigned long long* __restrict__ row, unsigned int len, unsigned int lane) {
     unsigned long long v[R];
@@ -594,69 +980,6 @@ __device__ __noinline__ void sort_long_row(unsigned long long* row, unsigned int
     }
 }
 
-// ---- rows in LDS: bucket + rank sort ------------------------------------------------------------------------
-// The hits of a radius search all lie below r^2, roughly evenly over [0, r^2) (surface: evenly; volume: ~sqrt): 128
-// buckets of equal width in d2 take one or two keys each.  Count (LDS atomics), scan the 128 counts over the lanes,
-// scatter the keys to their bucket's range, and give every key its rank among the few of its bucket: position =
-// bucket start + number of smaller keys there.  The bucket is a monotone function of d2 alone, so bucket-then-key
-// order IS key order.  ~110 VALU instructions for a row of 83 against ~390 of the bitonic network over 128 slots,
-// which moves every key through 28 compare-exchange steps wherever it started.  A bucket holding more than
-// BUCKET_FULL keys (lattices: few distinct distances) sends the row to the network instead.
-constexpr unsigned int BUCKET_ROW_MAX = 256, BUCKET_N = 128, BUCKET_FULL = 24;
-constexpr unsigned int ROW_LDS_MAX = 256;  // rows the fused fill keeps on the chip (longer ones: keys in memory, k_sort_rows)
-static_assert(ROW_LDS_MAX <= BUCKET_ROW_MAX, "every row kept in LDS can take the bucket sort");
-__device__ __forceinline__ unsigned int bucket_of(unsigned long long key, float scale) {
-    return (unsigned int)fminf(__uint_as_float((unsigned int)(key >> 32)) * scale, (float)(BUCKET_N - 1));
-}
-// (nothing is carried in registers from phase to phase: a key is read again and its bucket recomputed -- one DS read and
-// three VALU instructions per key and phase against 12 more live registers, which cost the whole kernel a wave per SIMD)
-template <int R>
-__device__ __forceinline__ bool bucket_sort_lds(unsigned long long* stage, unsigned long long* tmp, unsigned int* bk,
-                                                unsigned int have, float scale, unsigned int lane) {
-    // bk[0] = 0, bk[1 + b] = count, then fill pointer, then END of bucket b
-    bk[1 + 2 * lane] = 0u;
-    bk[2 + 2 * lane] = 0u;
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned int e = (unsigned int)(r * 64) + lane;
-        if (e < have) atomicAdd(&bk[1 + bucket_of(stage[e], scale)], 1u);
-    }
-    wave_lds_sync();
-    const unsigned int c0 = bk[1 + 2 * lane], c1 = bk[2 + 2 * lane];
-    if (__ballot(max(c0, c1) > BUCKET_FULL) != 0ull) return false;
-    const unsigned int sum = c0 + c1;
-    const unsigned int ex = wave_incl_scan_add(sum) - sum;
-    wave_lds_sync();
-    if (lane == 0) bk[0] = 0u;
-    bk[1 + 2 * lane] = ex;
-    bk[2 + 2 * lane] = ex + c0;
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned int e = (unsigned int)(r * 64) + lane;
-        if (e < have) {
-            const unsigned long long k = stage[e];
-            tmp[atomicAdd(&bk[1 + bucket_of(k, scale)], 1u)] = k;
-        }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned int e = (unsigned int)(r * 64) + lane;
-        if (e < have) {
-            const unsigned long long k = tmp[e];
-            const unsigned int bb = bucket_of(k, scale);
-            const unsigned int lo = bk[bb], hi = bk[bb + 1];
-            unsigned int pos = lo;
-            for (unsigned int j = lo; j < hi; ++j) pos += tmp[j] < k ? 1u : 0u;
-            stage[pos] = k;
-        }
-    }
-    wave_lds_sync();
-    return true;
-}
-
 // ---- wave-cooperative fill ------------------------------------------------------------------------
 // One WAVE per query for the fill pass: the rows of cells the r-ball touches go into an LDS table (lanes over
 // rows), their points are taken 64 at a time across row boundaries (as in k_grid_knn_wave), tested, and the hits
@@ -664,7 +987,6 @@ __device__ __forceinline__ bool bucket_sort_lds(unsigned long long* stage, unsig
 // alone and scattered 8-byte stores over 64 different rows per instruction: 10 of the 13.7 ms of an unsorted
 // 5M x 83 search.
 constexpr int RAD_ROWCAP = 11 * 11;
-constexpr unsigned int RAD_FLAT_CAP = 4 * 2048;  // flat candidates the span-end bits cover (4 planes of 64 words)
 // (8 waves per SIMD: the kernel waits on dependent loads most of its time -- 5.6 -> 4.9 ms at 5M x 83 against 6 waves; the
 // rows kept in LDS were halved to 256 and three registers spill to make room)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))

@@ -97,6 +97,7 @@ struct Options {
     double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
     double sort_mp_min_q = 5e6;     // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds
     int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 rows drained flat, lanes over candidates (2 / 3: open lanes listed / in place)
+    int knn_kernel = 1;             // PCC_OPT_KNN_KERNEL: 1 selection kernel for k <= 128, 0 merge network only
     int nn1_dense_min = 4;          // PCC_OPT_NN1_DENSE_MIN: references per own cell from which a wave starts with the own cell alone
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     void from_env();
@@ -153,6 +154,7 @@ struct pcc_index {
     pcc::FlannTree flann;
     bool flann_valid = false;
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
+    pcc::DevBuf knn_fb;  // queries the k-NN selection kernel hands back (+ their count)
     bool ties_pending = false;                    // the tie counters of the last search are still on the device
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
@@ -251,7 +253,9 @@ int voxel_grid(pcc_index* ctx, const void* pts, size_t n, size_t stride, int mem
                void* out, size_t out_stride, size_t* out_n);
 // ---- knn.hip: k-NN, radius search (GRID engine) ----------------------------------------
 // keys[nq][K] (pre-set to ~0) receive the K smallest (d2, position) keys ascending
-int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys);
+int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long long* keys, int32_t* idx_out = nullptr,
+             float* d2_out = nullptr);
+bool grid_knn_delivers(int K);
 // counts[i] = #refs with d2 < r2; with fill != 0 also writes keys at offsets[i]..
 // idx_out / d2_out / delivered (fill only): when given, a fill that takes the wave-per-query route writes the caller's
 // arrays itself (sorted in registers) and sets *delivered

@@ -51,6 +51,35 @@ def test_knn_duplicates_order(gpu):
     assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
 
 
+@pytest.mark.parametrize("k", [1, 7, 51, 64, 65, 100, 128])
+def test_knn_selection_kernel_and_merge_kernel_agree_with_the_oracle(gpu, k):
+    """k <= 128 runs the bucket-selection kernel (PCC_OPT_KNN_KERNEL = 1, default) and hands queries it cannot take to
+    the merge network; option 0 is the network alone.  Both must give the exhaustive oracle's rows bit for bit on a scene
+    that exercises the hand-backs: a lattice (hundreds of equal distances: crowded buckets, survivors beyond the sort),
+    dense blobs (cubes beyond the candidate buffer), far and non-finite queries, and a device-resident call."""
+    import torch
+    rng = np.random.default_rng(5)
+    lattice = np.stack(np.meshgrid(*[np.arange(12, dtype=np.float32) * np.float32(0.05)] * 3), -1).reshape(-1, 3)
+    blob = (rng.normal(0, 0.004, (6000, 3)) + np.array([2.0, 0.3, 0.3])).astype(np.float32)
+    a = np.ascontiguousarray(np.concatenate([_scene(20000), lattice + np.float32(1.0), blob])[rng.permutation(27728)])
+    q = np.concatenate([_scene(1500, synth.SEED_B), lattice[::3] + np.float32(1.0), blob[:300] + np.float32(0.001),
+                        _scene(50, synth.SEED_B) + np.float32(60.0)]).astype(np.float32)
+    q[11, 1] = np.nan
+    q = np.ascontiguousarray(q)
+    oi, od = oracle.knn_exhaustive(a, q, k)
+    with capi.Index(a) as ix:
+        for form in (1, 0):
+            ix.set_option(capi.OPT_KNN_KERNEL, form)
+            idx, d2 = ix.knn(q, k)
+            assert (idx == oi).all() and (_bits(d2) == _bits(od)).all(), form
+            assert (idx[11] == -1).all() and np.isinf(d2[11]).all()
+        ix.set_option(capi.OPT_KNN_KERNEL, 1)
+        di, dd = ix.knn(torch.from_numpy(q).cuda(), k)
+        assert (di.cpu().numpy() == oi).all() and (_bits(dd.cpu().numpy()) == _bits(od)).all()
+        with pytest.raises(capi.PccError):
+            ix.set_option(capi.OPT_KNN_KERNEL, 2)
+
+
 @pytest.mark.parametrize("radius", [0.05, 0.2])
 def test_radius_count_and_fill(gpu, radius):
     a = _scene(40000)

@@ -151,6 +151,7 @@ def main():
                 # the forms of the pruned k = 1 kernel: one lane per query / rows drained flat (open lanes finished in
                 # place or listed for a second kernel)
                 ix.set_option(capi.OPT_NN1_KERNEL, int(rng.integers(0, 4)))
+                ix.set_option(capi.OPT_KNN_KERNEL, int(rng.random() < 0.8))
                 if rng.random() < 0.2:
                     ix.set_option(capi.OPT_NN1_DENSE_MIN, int(rng.choice([1, 2, 1000000])))
                 idx, d2 = ix.nn1(q)
