@@ -35,19 +35,19 @@ def run(out_path):
     ix = capi.Index(a, auto_sync=False)
     for K in (51, 100):
         t, _ = timed(lambda: (ix.knn(a, K), ix.sync()))
-        add(f"k-NN K={K} (self query)", f"{n} x {n} corridor", t, 16.0 * n + 16.0 * n + 8.0 * K * n + 8.0 * K * n,
-            ["k_grid_knn_wave", "k_unpack"], "refs + queries once (16 B packed), K keys per query written and unpacked; the kernel is "
-            "selection-network (VALU / cross-lane) bound, the byte figure is what 8d asks for")
+        add(f"k-NN K={K} (self query)", f"{n} x {n} corridor", t, 16.0 * n + 16.0 * n + 8.0 * K * n,
+            ["k_grid_knn_sel", "k_grid_knn_wave", "k_knn_fill_invalid"], "refs + queries once (16 B packed), K (index, distance) pairs per query written; the kernel is "
+            "VALU-bound (bucket selection, ~625 instructions per query at K = 51), the byte figure is what 8d asks for")
     t, _ = timed(lambda: ix.sor(50, 1.5))
-    add("SOR mean_k=50 (-n noise pass)", f"{n} points", t, 32.0 * n + 8.0 * 51 * n + 4.0 * n, ["k_grid_knn_wave", "k_sor_mean_staged"],
+    add("SOR mean_k=50 (-n noise pass)", f"{n} points", t, 32.0 * n + 8.0 * 51 * n + 4.0 * n, ["k_grid_knn_sel", "k_grid_knn_wave", "k_knn_fill_invalid", "k_sor_mean_staged"],
         "includes PCL's in-order host reduction (D2H of the means)")
     t, _ = timed(lambda: (ix.radius_count(a, 0.05), ix.sync()))
     add("radius count r=0.05", f"{n} x {n} corridor", t, 32.0 * n + 4.0 * n, ["k_grid_radius"])
     nrm = None
     t, nrm = timed(lambda: ix.normals(50, device="cuda:0"))
-    add("normals K=50", f"{n} points", t, 32.0 * n + 8.0 * 50 * n + 16.0 * n, ["k_grid_knn_wave", "k_normals"])
+    add("normals K=50", f"{n} points", t, 32.0 * n + 8.0 * 50 * n + 16.0 * n, ["k_grid_knn_sel", "k_grid_knn_wave", "k_knn_fill_invalid", "k_normals"])
     t, _ = timed(lambda: ix.region_growing(nrm, k=100), reps=2)
-    add("region growing K=100", f"{n} points", t, 32.0 * n + 8.0 * 100 * n + 16.0 * n + 4.0 * n, ["k_grid_knn_wave", "k_rg_"])
+    add("region growing K=100", f"{n} points", t, 32.0 * n + 8.0 * 100 * n + 16.0 * n + 4.0 * n, ["k_grid_knn_sel", "k_grid_knn_wave", "k_knn_fill_invalid", "k_rg_"])
     ix.close()
     # radius search with materialised lists: the object layer, r = 0.05 (rows of ~80 neighbours)
     m = 5_000_000
