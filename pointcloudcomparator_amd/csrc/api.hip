@@ -492,6 +492,7 @@ int pcc_index_set_option(pcc_index* ix, int option, double value) {
         case PCC_OPT_FAR_MODE: ok = value >= -1 && value <= 1; break;
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
         case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 3; break;
+        case PCC_OPT_EC_CELLS: ok = value >= 0 && value <= 2; break;
         case PCC_OPT_NN1_DENSE_MIN: ok = value >= 1 && value <= 1000000; break;
         case PCC_OPT_FLANN_SPLIT: ok = value >= 0 && value <= 2; break;
         default: ok = value == 0 || value == 1; break;

@@ -108,6 +108,72 @@ k_uf_link_cells(const float4* __restrict__ cr2, const unsigned int* __restrict__
     }
 }
 
+// The same links with the lanes over a cell's NEIGHBOURS.  In the kernel above a lane owns a point and walks its share of
+// the 62 forward neighbour cells one after the other, each step a chain of dependent L2 round trips (cell bounds -> first
+// point -> two root walks -> points): 10 of 64 lanes active, 86 % of the wave time waiting, 3.5 ms at 5M points.  Here a
+// wave takes the cells that START among its 64 points one at a time and gives each of the 62 neighbour cells to a lane:
+// the 62 chains run side by side, the neighbour offsets are per-lane constants (no division in the loop), and the
+// bounds of 5 x-adjacent neighbour cells share a cache line: 3.48 -> 2.24 ms.  What is left is the "linked already?" walk
+// of 84M cell pairs through agent-scope loads (the per-XCD L2s are not coherent, so each is a trip past them; the head
+// loop with the bounds alone is 0.3 ms, with the neighbour's first point 0.6): ~170M uncached 4-byte loads in ~1.6 ms
+// is what the fabric gives.  A pre-check through the caches (stale parents prove a link when equal) changed nothing.
+// Same unions offered (a pair of cells is linked by the first
+// pair of points within r it finds, or skipped when the roots already agree), same components.
+__global__ void __launch_bounds__(256)
+k_uf_link_cells_wave(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2,
+                     float r2, unsigned int* __restrict__ parent) {
+    const GridParams g = gd2->g;
+    const unsigned int n_valid = gd2->n_valid;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= n_valid) return;  // wave-uniform
+    const bool have = t < n_valid;
+    int cx = 0, cy = 0, cz = 0;
+    unsigned int a0 = 0, a1 = 0, first = 0;
+    if (have) {
+        const float4 me = cr2[t];
+        cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+        const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+        a0 = cs2[c];
+        a1 = cs2[c + 1];
+        first = (unsigned int)__float_as_int(cr2[a0].w);
+        if (t != a0) uf_union(parent, (unsigned int)__float_as_int(me.w), first);  // same cell: within r by construction
+    }
+    // this lane's forward neighbour in the 5 x 5 x 5 numbering (62 = the own cell; forward = beyond it)
+    const int lin = (int)lane + 63;
+    const int dz = lin / 25 - 2, dy = (lin / 5) % 5 - 2, dx = lin % 5 - 2;
+    unsigned long long heads = __ballot(have && t == a0);
+    while (heads) {
+        const int h = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const int hx = __builtin_amdgcn_readlane(cx, h), hy = __builtin_amdgcn_readlane(cy, h), hz = __builtin_amdgcn_readlane(cz, h);
+        const unsigned int ha0 = (unsigned int)__builtin_amdgcn_readlane((int)a0, h);
+        const unsigned int ha1 = (unsigned int)__builtin_amdgcn_readlane((int)a1, h);
+        const unsigned int hfirst = (unsigned int)__builtin_amdgcn_readlane((int)first, h);
+        const int x = hx + dx, y = hy + dy, z = hz + dz;
+        if (lane >= 62 || x < 0 || x >= g.dim[0] || y < 0 || y >= g.dim[1] || z >= g.dim[2]) continue;
+        const unsigned int cb = ((unsigned int)z * g.dim[1] + y) * g.dim[0] + x;
+        const unsigned int b0 = cs2[cb], b1 = cs2[cb + 1];
+        if (b0 == b1) continue;
+        const unsigned int other = (unsigned int)__float_as_int(cr2[b0].w);
+        if (uf_linked(parent, hfirst, other)) continue;  // linked already (through anything)
+        bool linked = false;
+        for (unsigned int pb = b0; pb < b1 && !linked; ++pb) {
+            const float4 o = cr2[pb];
+            for (unsigned int pa = ha0; pa < ha1; ++pa) {
+                const float4 m = cr2[pa];
+                if (dist2(m.x, m.y, m.z, o) < r2) {
+                    uf_union(parent, (unsigned int)__float_as_int(m.w), (unsigned int)__float_as_int(o.w));
+                    linked = true;
+                    break;
+                }
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_uf_flatten_count(const float4* __restrict__ refs, unsigned int* __restrict__ parent, unsigned int n,
                    unsigned int* __restrict__ size) {
@@ -229,8 +295,12 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
     PCC_HIP(hipMemsetAsync(d_count, 0, 4, s));
     PCC_HIP(hipMemsetAsync(labels_dev, 0xff, ix->n_orig * sizeof(int32_t), s));
     if (cells_ok) {
-        hipLaunchKernelGGL(k_uf_link_cells, dim3((n + 255) / 256), dim3(256), 0, s, ix->vox_a.as<float4>(),
-                           ix->vox_c.as<unsigned int>(), ix->vox_b.as<GridDev>(), r2, parent);
+        if (ix->opt.ec_cells == 2)  // (the lane-per-point form, kept for comparison)
+            hipLaunchKernelGGL(k_uf_link_cells, dim3((n + 255) / 256), dim3(256), 0, s, ix->vox_a.as<float4>(),
+                               ix->vox_c.as<unsigned int>(), ix->vox_b.as<GridDev>(), r2, parent);
+        else
+            hipLaunchKernelGGL(k_uf_link_cells_wave, dim3((n + 255) / 256), dim3(256), 0, s, ix->vox_a.as<float4>(),
+                               ix->vox_c.as<unsigned int>(), ix->vox_b.as<GridDev>(), r2, parent);
     } else {
         hipLaunchKernelGGL(k_uf_link, dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), r, r2, parent);

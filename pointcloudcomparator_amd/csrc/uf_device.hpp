@@ -16,6 +16,25 @@ __device__ __forceinline__ unsigned int uf_find(unsigned int* __restrict__ paren
         x = p;
     }
 }
+// are a and b in one component (now)?  Both walks advance together -- their loads are in flight at the same time -- and
+// stop as soon as they meet: a parent is an ancestor, and a common ancestor proves the link before either root is reached
+// (already-linked points one step below their root, the usual case late in a pass, cost ONE round trip instead of six).
+__device__ __forceinline__ bool uf_linked(unsigned int* __restrict__ parent, unsigned int a, unsigned int b) {
+    for (;;) {
+        if (a == b) return true;
+        const unsigned int pa = __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int pb = __hip_atomic_load(&parent[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pa == pb || pa == b || pb == a) return true;
+        const bool ra = pa == a, rb = pb == b;
+        if (ra && rb) return false;  // two different roots
+        const unsigned int gpa = __hip_atomic_load(&parent[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int gpb = __hip_atomic_load(&parent[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ra && gpa != pa) atomicMin(&parent[a], gpa);  // path halving, as in uf_find
+        if (!rb && gpb != pb) atomicMin(&parent[b], gpb);
+        a = pa;
+        b = pb;
+    }
+}
 __device__ __forceinline__ void uf_union(unsigned int* __restrict__ parent, unsigned int a, unsigned int b) {
     for (;;) {
         a = uf_find(parent, a);

@@ -152,6 +152,7 @@ def main():
                 # place or listed for a second kernel)
                 ix.set_option(capi.OPT_NN1_KERNEL, int(rng.integers(0, 4)))
                 ix.set_option(capi.OPT_KNN_KERNEL, int(rng.random() < 0.8))
+                ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([1, 1, 2, 0])))
                 if rng.random() < 0.2:
                     ix.set_option(capi.OPT_NN1_DENSE_MIN, int(rng.choice([1, 2, 1000000])))
                 idx, d2 = ix.nn1(q)
