@@ -72,6 +72,7 @@ static int exercise_oracle(const std::vector<float>& a, const std::vector<float>
                 float fd = 0.f;
                 const int32_t fi = ft.nearest(&q[j * 3], &fd);
                 REQUIRE(fi == ti[j] && memcmp(&fd, &td[j], 4) == 0);
+                REQUIRE(ft.nearest_tied(&q[j * 3], fd) == fi);  // the short walk for a known minimum distance (what the device runs)
             }
         }
         int32_t ki[16];
