@@ -994,7 +994,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                         const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
                         const unsigned int* __restrict__ n_sorted_ptr, float r, float r2, const int64_t* __restrict__ offsets,
                         unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
-                        int sorted) {
+                        int sorted, unsigned int* __restrict__ long_list, unsigned int* __restrict__ long_count) {
     // FUSED (idx_out / d2_out given): a row of up to ROW_LDS_MAX neighbours never leaves the chip between the search and
     // the caller's arrays -- its hits gather in LDS, are sorted in registers (PCL's sorted results) and go out as index
     // and squared distance in two coalesced stores.  Before: keys to memory (8 B), sorted in place by a second kernel
@@ -1019,22 +1019,47 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
     // (tried and measured no gain, 5M x 83: a launch of exactly the resident workgroups so that the waves form a band
     // marching through the cell-sorted queries, with or without one eighth of the order per XCD; 2 / 8 / 16 waves per
     // workgroup for more L1 sharing between neighbouring queries; streaming stores)
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // (wave-uniform by construction; said to the compiler, the per-query header -- order, query, offsets -- goes through
+    // scalar loads and scalar address arithmetic)
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float bscale = (float)BUCKET_N / r2;
-    for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
-        const unsigned int qi = order[t];
+    // The per-query header (query index, packed query, two row offsets) is a chain of two dependent loads at the head of a
+    // chain of five more (bounds, windows) -- and the kernel waits most of its time.  It is fetched one query ahead instead:
+    // at the top of a query's turn ONE vector load picks up the next query's header (lanes 0-3 its packed coordinates, 4-7
+    // its two offsets) and, in lane 8, the query index two turns ahead; it lands while this query's rows are walked and is
+    // read out with v_readlane at the end of the turn.  Being older than every load of the turn it also never waits behind
+    // the previous row's stores (gfx9: loads and stores share vmcnt, in order).
+    unsigned int t = wave;
+    if (t >= ns) return;
+    unsigned int qi = order[t];
+    unsigned int qi_n = order[min(t + nwaves, ns - 1u)];
+    float qx, qy, qz;
+    int64_t row_beg, row_end;
+    {
         const float4 qv = q[qi];
-        const float qx = qv.x, qy = qv.y, qz = qv.z;
+        qx = qv.x; qy = qv.y; qz = qv.z;
+        row_beg = offsets[qi];
+        row_end = offsets[qi + 1];
+    }
+    for (;;) {  // wave-uniform
+        unsigned int hv = 0u;
+        {
+            const unsigned int t2 = min(t + 2u * nwaves, ns - 1u);
+            const unsigned int* hp = lane < 4 ? reinterpret_cast<const unsigned int*>(q + qi_n) + lane
+                                   : lane < 8 ? reinterpret_cast<const unsigned int*>(offsets + qi_n) + (lane - 4)
+                                              : order + t2;
+            if (lane < 9) hv = *hp;
+        }
         int x0, x1, y0, y1, z0, z1;
         const float rr = r + slack;
         cell_range(qx, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
         cell_range(qy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
         cell_range(qz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
-        const int64_t row_beg = offsets[qi];
-        const unsigned int row_len = (unsigned int)(offsets[qi + 1] - row_beg);
+        const unsigned int row_len = (unsigned int)(row_end - row_beg);
         const bool in_lds = fused && row_len <= ROW_LDS_MAX;
+        if (fused && !in_lds && lane == 0) long_list[atomicAdd(long_count, 1u)] = qi;  // left as keys for k_sort_rows
         unsigned long long* row_out = in_lds ? stage : keys + row_beg;
         unsigned int written = 0;  // wave-uniform
         const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
@@ -1111,31 +1136,39 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
             }
             wave_lds_sync();
             if (total <= RAD_FLAT_CAP) {
-                // (four windows with their loads in flight together measured 5.6 against 5.3 ms at 5M x 83: the registers
-                // cost more occupancy than the overlap buys -- 28 resident waves per CU hide a single load already)
+                // two windows per turn, both loads in flight before the first is used (four measured slower: registers)
                 unsigned int before = 0, word = 0;
-                for (unsigned int B = 0; B < total; B += 64) {
-                    const unsigned int w = B >> 6;
-                    if ((w & 31u) == 0u) word = endb[w >> 5][lane];
-                    const unsigned long long m = __ballot(((word >> (w & 31u)) & 1u) != 0u);
-                    const unsigned int my = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
-                    before += (unsigned int)__popcll(m);
-                    const unsigned int c = B + lane;
-                    bool hit = false;
-                    unsigned long long key = 0;
-                    if (c < total) {
-                        const float4 r4 = cell_refs[tab_s[my] + (c - tab_o[my])];
-                        const float d = dist2(qx, qy, qz, r4);
-                        hit = d < r2;
-                        key = make_key(d, r4);
+                for (unsigned int B = 0; B < total; B += 128) {
+                    unsigned int my[2], c[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned int w = (B >> 6) + (unsigned int)u;
+                        if ((w & 31u) == 0u) word = endb[(w >> 5) & 3u][lane];
+                        const unsigned long long m = __ballot(((word >> (w & 31u)) & 1u) != 0u);
+                        my[u] = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
+                        before += (unsigned int)__popcll(m);
+                        c[u] = B + 64u * (unsigned int)u + lane;
                     }
-                    const unsigned long long mask = __ballot(hit);
-                    const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
-                    if (hit) {
-                        if (in_lds) { if (slot < ROW_LDS_MAX) stage[slot] = key; }
-                        else keys[row_beg + slot] = key;
+                    float4 r4[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned int cc = min(c[u], total - 1u), mm = min(my[u], nspans - 1u);
+                        r4[u] = cell_refs[tab_s[mm] + (cc - tab_o[mm])];
                     }
-                    written += (unsigned int)__popcll(mask);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (u == 1 && B + 64u >= total) break;
+                        const float d = dist2(qx, qy, qz, r4[u]);
+                        const bool hit = c[u] < total && d < r2;
+                        const unsigned long long key = make_key(d, r4[u]);
+                        const unsigned long long mask = __ballot(hit);
+                        const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
+                        if (hit) {
+                            if (in_lds) { if (slot < ROW_LDS_MAX) stage[slot] = key; }
+                            else keys[row_beg + slot] = key;
+                        }
+                        written += (unsigned int)__popcll(mask);
+                    }
                 }
                 continue;
             }
@@ -1197,6 +1230,15 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
             else emit(std::integral_constant<int, 4>{});
             wave_lds_sync();
         }
+        t += nwaves;
+        if (t >= ns) break;
+        qi = qi_n;
+        qx = __int_as_float(__builtin_amdgcn_readlane((int)hv, 0));
+        qy = __int_as_float(__builtin_amdgcn_readlane((int)hv, 1));
+        qz = __int_as_float(__builtin_amdgcn_readlane((int)hv, 2));
+        row_beg = (int64_t)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hv, 5) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)hv, 4));
+        row_end = (int64_t)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hv, 7) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)hv, 6));
+        qi_n = (unsigned int)__builtin_amdgcn_readlane((int)hv, 8);
     }
 }
 
@@ -1204,10 +1246,15 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
 // rows handled here are also unpacked into the caller's arrays (the long rows of a fused fill).
 __global__ void __launch_bounds__(256)
 k_sort_rows(const int64_t* __restrict__ offsets, unsigned int nq, unsigned long long* __restrict__ keys, unsigned int min_len,
-            int sorted, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+            int sorted, int32_t* __restrict__ idx_out, float* __restrict__ d2_out, const unsigned int* __restrict__ list,
+            const unsigned int* __restrict__ list_count) {
+    // list (nullable): the rows to look at (the fused fill names the rows it left as keys: a wave per row just to skip
+    // 5M short ones took 0.44 ms)
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nq; i += nwaves) {  // wave-uniform
+    if (list) nq = *list_count;
+    for (unsigned int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; j < nq; j += nwaves) {  // wave-uniform
+        const unsigned int i = list ? list[j] : j;
         const int64_t beg = offsets[i];
         const unsigned int len = (unsigned int)(offsets[i + 1] - beg);
         unsigned long long* row = keys + beg;
@@ -1247,16 +1294,25 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
     if (gw > 8192) gw = 8192;
     if (keys && total >= 24 * nq) {  // long rows: a wave per query (short rows leave most of its lanes idle)
         const bool fused = delivered != nullptr && (idx_out || d2_out);
+        unsigned int *long_list = nullptr, *long_count = nullptr;
+        if (fused) {
+            PCC_TRY(ix->knn_fb.reserve((nq + 1) * sizeof(unsigned int)));
+            long_list = ix->knn_fb.as<unsigned int>();
+            long_count = long_list + nq;
+            PCC_HIP(hipMemsetAsync(long_count, 0, sizeof(unsigned int), s));
+        }
         hipLaunchKernelGGL(k_grid_radius_fill_wave, dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, r, r2, offsets, keys,
-                           fused ? idx_out : nullptr, fused ? d2_out : nullptr, sorted);
+                           fused ? idx_out : nullptr, fused ? d2_out : nullptr, sorted, long_list, long_count);
         PCC_HIP(hipGetLastError());
-        if (fused) {  // what is left: rows beyond the register sort, still as keys in memory
-            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, ROW_LDS_MAX + 1, sorted, idx_out, d2_out);
+        if (fused) {  // what is left: rows beyond the LDS stage, still as keys in memory
+            hipLaunchKernelGGL(k_sort_rows, dim3(1024), dim3(256), 0, s, offsets, n, keys, ROW_LDS_MAX + 1, sorted, idx_out, d2_out,
+                               (const unsigned int*)long_list, (const unsigned int*)long_count);
             PCC_HIP(hipGetLastError());
             *delivered = true;
         } else if (sorted) {
-            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr,
+                               (const unsigned int*)nullptr, (const unsigned int*)nullptr);
             PCC_HIP(hipGetLastError());
         }
         ev_mark(ix, EV_MAIN1);
@@ -1272,7 +1328,8 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
                            offsets, keys, sorted);
     PCC_HIP(hipGetLastError());
     if (keys && sorted) {
-        hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr,
+                           (const unsigned int*)nullptr, (const unsigned int*)nullptr);
         PCC_HIP(hipGetLastError());
     }
     ev_mark(ix, EV_MAIN1);
