@@ -200,7 +200,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
     if (n_valid == 0) return;
     const unsigned int lane = threadIdx.x & 63;
     unsigned long long* stage = stage_all[threadIdx.x >> 6];
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));  // (uniform: scalar header loads)
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -529,7 +529,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     const unsigned int ns = *n_sorted_ptr;
     if (n_valid == 0) return;
     const unsigned int lane = threadIdx.x & 63;
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));  // (uniform: scalar header loads)
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
