@@ -825,17 +825,38 @@ constexpr unsigned int ROW_SORT_MAX = 512;  // rows up to this length are sorted
 // FILL = false: counts[i] = #refs with d2 < r2 (strict).
 // FILL = true : keys written at offsets[i]; with sorted the row is then ordered by (d2, position)
 //               with an in-place insertion sort (rows are short: tens to a few hundred entries).
+// which count kernel serves a radius: a wave per query pays when the ball's box holds hundreds of candidates -- cells of
+// the box x the filling of an OCCUPIED cell (n_valid / non-empty cells: a scan's points pile up on surfaces, an average
+// over the bounding box says nothing about where the queries are).  Decided on the device -- cell size and cell count are
+// computed there and the host does not wait for them: both kernels are launched, one of them returns at once.
+// (5M object-layer points, r = 0.05, 83 hits: 2.9 against 3.5 ms; 1M corridor, r = 0.2, 210 hits: 0.75 against 1.13;
+// 1M corridor, r = 0.05, 5.5 hits: 0.40 against 0.25 -- the lane form keeps those)
+__device__ __forceinline__ bool radius_count_by_wave(const GridDev* gd, float r, const unsigned int* occupied) {
+    const float c = 2.f * r * gd->g.inv_h + 1.f;
+    const unsigned int occ = *occupied;
+    return c * c * c * ((float)gd->n_valid / (float)(occ ? occ : 1u)) >= 200.f;
+}
+__global__ void __launch_bounds__(256)
+k_count_occupied(const unsigned int* __restrict__ cell_start, const GridDev* __restrict__ gd, unsigned int* __restrict__ out) {
+    const unsigned int nc = (unsigned int)gd->g.ncells;
+    unsigned int mine = 0;
+    for (unsigned int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x)
+        mine += cell_start[c + 1] > cell_start[c] ? 1u : 0u;
+    mine = wave_incl_scan_add(mine);
+    if ((threadIdx.x & 63) == 63 && mine) atomicAdd(out, mine);
+}
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_grid_radius(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
               const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
               const unsigned int* __restrict__ n_sorted_ptr, unsigned int /*n*/, float r, float r2,
               int32_t* __restrict__ counts, const int64_t* __restrict__ offsets,
-              unsigned long long* __restrict__ keys, int /*sorted*/) {
+              unsigned long long* __restrict__ keys, int /*sorted*/, const unsigned int* __restrict__ occupied) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *n_sorted_ptr) return;
+    if (!FILL && radius_count_by_wave(gd, r, occupied)) return;  // (k_grid_radius_fill_wave<true> counts)
     const unsigned int qi = order[t];
     const float4 qv = q[qi];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
@@ -989,12 +1010,16 @@ __device__ __noinline__ void sort_long_row(unsigned long long* row, unsigned int
 constexpr int RAD_ROWCAP = 11 * 11;
 // (8 waves per SIMD: the kernel waits on dependent loads most of its time -- 5.6 -> 4.9 ms at 5M x 83 against 6 waves; the
 // rows kept in LDS were halved to 256 and three registers spill to make room)
+// COUNT: the same walk, hits only counted (counts[query]; no offsets, no rows) -- the count pass of a search whose balls
+// hold hundreds of candidates, where one lane per query walks them alone
+template <bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                         const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
                         const unsigned int* __restrict__ n_sorted_ptr, float r, float r2, const int64_t* __restrict__ offsets,
                         unsigned long long* __restrict__ keys, int32_t* __restrict__ idx_out, float* __restrict__ d2_out,
-                        int sorted, unsigned int* __restrict__ long_list, unsigned int* __restrict__ long_count) {
+                        int sorted, unsigned int* __restrict__ long_list, unsigned int* __restrict__ long_count,
+                        int32_t* __restrict__ counts, const unsigned int* __restrict__ occupied) {
     // FUSED (idx_out / d2_out given): a row of up to ROW_LDS_MAX neighbours never leaves the chip between the search and
     // the caller's arrays -- its hits gather in LDS, are sorted in registers (PCL's sorted results) and go out as index
     // and squared distance in two coalesced stores.  Before: keys to memory (8 B), sorted in place by a second kernel
@@ -1008,13 +1033,14 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
     Tables& tb = tables_all[threadIdx.x >> 6];
     unsigned int (*endb)[64] = tb.endb;
     unsigned long long* stage = stage_all[threadIdx.x >> 6];
-    const bool fused = idx_out != nullptr || d2_out != nullptr;
+    const bool fused = !COUNT && (idx_out != nullptr || d2_out != nullptr);
     unsigned int* tab_s = tb.tab_s;
     unsigned int* tab_o = tb.tab_o;
     unsigned int* win = tb.win;
     const GridParams g = gd->g;
     const float slack = gd->slack;
     const unsigned int ns = *n_sorted_ptr;
+    if (COUNT && !radius_count_by_wave(gd, r, occupied)) return;  // (k_grid_radius<false> counts)
     const unsigned int lane = threadIdx.x & 63;
     // (tried and measured no gain, 5M x 83: a launch of exactly the resident workgroups so that the waves form a band
     // marching through the cell-sorted queries, with or without one eighth of the order per XCD; 2 / 8 / 16 waves per
@@ -1036,12 +1062,14 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
     unsigned int qi = order[t];
     unsigned int qi_n = order[min(t + nwaves, ns - 1u)];
     float qx, qy, qz;
-    int64_t row_beg, row_end;
+    int64_t row_beg = 0, row_end = 0;
     {
         const float4 qv = q[qi];
         qx = qv.x; qy = qv.y; qz = qv.z;
-        row_beg = offsets[qi];
-        row_end = offsets[qi + 1];
+        if constexpr (!COUNT) {
+            row_beg = offsets[qi];
+            row_end = offsets[qi + 1];
+        }
     }
     for (;;) {  // wave-uniform
         unsigned int hv = 0u;
@@ -1050,7 +1078,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
             const unsigned int* hp = lane < 4 ? reinterpret_cast<const unsigned int*>(q + qi_n) + lane
                                    : lane < 8 ? reinterpret_cast<const unsigned int*>(offsets + qi_n) + (lane - 4)
                                               : order + t2;
-            if (lane < 9) hv = *hp;
+            if (lane < 9 && !(COUNT && lane >= 4 && lane < 8)) hv = *hp;
         }
         int x0, x1, y0, y1, z0, z1;
         const float rr = r + slack;
@@ -1163,7 +1191,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                         const unsigned long long key = make_key(d, r4[u]);
                         const unsigned long long mask = __ballot(hit);
                         const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
-                        if (hit) {
+                        if (!COUNT && hit) {
                             if (in_lds) { if (slot < ROW_LDS_MAX) stage[slot] = key; }
                             else keys[row_beg + slot] = key;
                         }
@@ -1197,7 +1225,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 const unsigned long long mask = __ballot(hit);
                 // (a fill can only find what the count found -- same arithmetic --; the bound is belt and braces)
                 const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
-                if (hit && (!in_lds || slot < ROW_LDS_MAX)) row_out[slot] = key;
+                if (!COUNT && hit && (!in_lds || slot < ROW_LDS_MAX)) row_out[slot] = key;
                 written += (unsigned int)__popcll(mask);
             }
         }
@@ -1230,6 +1258,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
             else emit(std::integral_constant<int, 4>{});
             wave_lds_sync();
         }
+        if (COUNT && lane == 0) counts[qi] = (int32_t)written;
         t += nwaves;
         if (t >= ns) break;
         qi = qi_n;
@@ -1301,9 +1330,9 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
             long_count = long_list + nq;
             PCC_HIP(hipMemsetAsync(long_count, 0, sizeof(unsigned int), s));
         }
-        hipLaunchKernelGGL(k_grid_radius_fill_wave, dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+        hipLaunchKernelGGL((k_grid_radius_fill_wave<false>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, r, r2, offsets, keys,
-                           fused ? idx_out : nullptr, fused ? d2_out : nullptr, sorted, long_list, long_count);
+                           fused ? idx_out : nullptr, fused ? d2_out : nullptr, sorted, long_list, long_count, (int32_t*)nullptr, (const unsigned int*)nullptr);
         PCC_HIP(hipGetLastError());
         if (fused) {  // what is left: rows beyond the LDS stage, still as keys in memory
             hipLaunchKernelGGL(k_sort_rows, dim3(1024), dim3(256), 0, s, offsets, n, keys, ROW_LDS_MAX + 1, sorted, idx_out, d2_out,
@@ -1318,14 +1347,30 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
         ev_mark(ix, EV_MAIN1);
         return PCC_OK;
     }
+    const unsigned int* occupied = nullptr;
+    if (!keys) {  // count pass, wave form (returns at once unless the balls hold hundreds of candidates)
+        PCC_TRY(ix->occ.reserve(sizeof(unsigned int)));
+        if (!ix->occ_valid) {  // non-empty cells of this grid: once per indexed cloud
+            PCC_HIP(hipMemsetAsync(ix->occ.p, 0, sizeof(unsigned int), s));
+            hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, s, ix->cell_start.as<unsigned int>(), gd, ix->occ.as<unsigned int>());
+            PCC_HIP(hipGetLastError());
+            ix->occ_valid = true;
+        }
+        occupied = ix->occ.as<unsigned int>();
+        hipLaunchKernelGGL((k_grid_radius_fill_wave<true>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
+                           ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, r, r2, (const int64_t*)nullptr,
+                           (unsigned long long*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (unsigned int*)nullptr,
+                           (unsigned int*)nullptr, counts, occupied);
+        PCC_HIP(hipGetLastError());
+    }
     if (keys)
         hipLaunchKernelGGL((k_grid_radius<true>), dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, n, r, r2, counts,
-                           offsets, keys, sorted);
+                           offsets, keys, sorted, occupied);
     else
         hipLaunchKernelGGL((k_grid_radius<false>), dim3((n + 255) / 256), dim3(256), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), gd, q, order, n_sorted, n, r, r2, counts,
-                           offsets, keys, sorted);
+                           offsets, keys, sorted, occupied);
     PCC_HIP(hipGetLastError());
     if (keys && sorted) {
         hipLaunchKernelGGL(k_sort_rows, dim3(gw), dim3(256), 0, s, offsets, n, keys, 0u, 1, (int32_t*)nullptr, (float*)nullptr,

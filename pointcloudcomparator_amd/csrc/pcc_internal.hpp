@@ -153,6 +153,8 @@ struct pcc_index {
     int tie_mode = PCC_TIES_LOWEST_INDEX;
     pcc::FlannTree flann;
     bool flann_valid = false;
+    bool occ_valid = false;   // occ (device word): number of non-empty cells of the current grid, counted at the first radius count
+    pcc::DevBuf occ;
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
     pcc::DevBuf knn_fb;  // queries the k-NN selection kernel hands back (+ their count)
     bool ties_pending = false;                    // the tie counters of the last search are still on the device

@@ -80,7 +80,7 @@ def test_knn_selection_kernel_and_merge_kernel_agree_with_the_oracle(gpu, k):
             ix.set_option(capi.OPT_KNN_KERNEL, 2)
 
 
-@pytest.mark.parametrize("radius", [0.05, 0.2])
+@pytest.mark.parametrize("radius", [0.05, 0.2, 0.7])  # (0.7: balls of hundreds of candidates -- the count pass takes its wave form)
 def test_radius_count_and_fill(gpu, radius):
     a = _scene(40000)
     b = _scene(3000, synth.SEED_B)
