@@ -128,12 +128,19 @@ __global__ void __launch_bounds__(256)
 k_rg_sweep(const unsigned long long* __restrict__ keys, const float4* __restrict__ normals,
            const float4* __restrict__ cell_refs, const GridDev* __restrict__ gd, int K, float cos_thr,
            const unsigned int* __restrict__ parent, unsigned long long* __restrict__ comp_label,
-           unsigned char* __restrict__ has_cross, unsigned int* __restrict__ changed) {
-    const unsigned int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+           unsigned char* __restrict__ has_cross, unsigned int* __restrict__ changed, unsigned int* __restrict__ cross_list,
+           unsigned int* __restrict__ cross_count, unsigned int list_n) {
+    // FIRST: a wave per point; the points with an edge into another component are LISTED, and the later sweeps are
+    // launched over that list alone (a million waves that look up has_cross and leave cost 116 us a sweep, nine times)
+    unsigned int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned int lane = threadIdx.x & 63;
-    if (w >= gd->n_valid) return;
+    if (FIRST) {
+        if (w >= gd->n_valid) return;
+    } else {
+        if (w >= list_n) return;
+        w = cross_list[w];
+    }
     const unsigned int u = (unsigned int)__float_as_int(cell_refs[w].w);
-    if (!FIRST && !has_cross[u]) return;
     const float4 nu = normals[u];
     const unsigned int ru = parent[u];
     const unsigned long long lu = __hip_atomic_load(&comp_label[ru], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -152,7 +159,10 @@ k_rg_sweep(const unsigned long long* __restrict__ keys, const float4* __restrict
     }
     if (FIRST) {
         const bool any_cross = __ballot(cross) != 0ull;
-        if (lane == 0 && any_cross) has_cross[u] = 1;
+        if (lane == 0 && any_cross) {
+            has_cross[u] = 1;
+            cross_list[atomicAdd(cross_count, 1u)] = w;
+        }
     }
     if (__ballot(moved) != 0ull && lane == 0) atomicOr(changed, 1u);
 }
@@ -269,10 +279,10 @@ int grid_region_growing(pcc_index* ix, const unsigned long long* keys, const flo
     auto* id_of_seed = ix->scratch_e.as<int>();
     auto* kth = ix->scratch_f.as<unsigned long long>();
     auto* has_cross = ix->scratch_g.as<unsigned char>();
-    unsigned int* d_words = ix->small.as<unsigned int>() + 40;  // [0] no-spread count, [1] changed, [2] list count
+    unsigned int* d_words = ix->small.as<unsigned int>() + 40;  // [0] no-spread count, [1] changed, [2] list count, [3] points with a cross edge
     unsigned int* h = static_cast<unsigned int*>(ix->pinned);
     ev_mark(ix, EV_MAIN0);
-    PCC_HIP(hipMemsetAsync(d_words, 0, 12, s));
+    PCC_HIP(hipMemsetAsync(d_words, 0, 16, s));
     hipLaunchKernelGGL(k_rg_prepare, dim3(g1(n)), dim3(256), 0, s, keys, normals, n, K, curvature_threshold, parent,
                        comp_label, kth, size, id_of_seed, has_cross, d_words);
     PCC_HIP(hipGetLastError());
@@ -310,19 +320,26 @@ int grid_region_growing(pcc_index* ix, const unsigned long long* keys, const flo
             if (h[0] == 0) break;
         }
         PCC_HIP(hipMemcpyAsync(comp_label, lab[cur], (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-    } else
-    for (int sweep = 0;; ++sweep) {
-        PCC_HIP(hipMemsetAsync(d_words + 1, 0, 4, s));
-        if (sweep == 0)
-            hipLaunchKernelGGL(k_rg_sweep<true>, dim3(wave_blocks), dim3(256), 0, s, keys, normals, ix->cell_refs.as<float4>(),
-                               ix->d_grid.as<GridDev>(), K, cos_thr, parent, comp_label, has_cross, d_words + 1);
-        else
-            hipLaunchKernelGGL(k_rg_sweep<false>, dim3(wave_blocks), dim3(256), 0, s, keys, normals, ix->cell_refs.as<float4>(),
-                               ix->d_grid.as<GridDev>(), K, cos_thr, parent, comp_label, has_cross, d_words + 1);
-        PCC_HIP(hipGetLastError());
-        PCC_HIP(hipMemcpyAsync(h, d_words + 1, 4, hipMemcpyDeviceToHost, s));
-        PCC_HIP(hipStreamSynchronize(s));
-        if (h[0] == 0) break;
+    } else {
+        PCC_TRY(ix->knn_fb.reserve(((size_t)n + 1) * sizeof(unsigned int)));  // (free here: the rows were searched before)
+        unsigned int* cross_list = ix->knn_fb.as<unsigned int>();
+        unsigned int n_cross = 0;
+        for (int sweep = 0;; ++sweep) {
+            PCC_HIP(hipMemsetAsync(d_words + 1, 0, 4, s));
+            if (sweep == 0)
+                hipLaunchKernelGGL(k_rg_sweep<true>, dim3(wave_blocks), dim3(256), 0, s, keys, normals, ix->cell_refs.as<float4>(),
+                                   ix->d_grid.as<GridDev>(), K, cos_thr, parent, comp_label, has_cross, d_words + 1, cross_list,
+                                   d_words + 3, 0u);
+            else if (n_cross)
+                hipLaunchKernelGGL(k_rg_sweep<false>, dim3((n_cross + 3) / 4), dim3(256), 0, s, keys, normals,
+                                   ix->cell_refs.as<float4>(), ix->d_grid.as<GridDev>(), K, cos_thr, parent, comp_label, has_cross,
+                                   d_words + 1, cross_list, d_words + 3, n_cross);
+            PCC_HIP(hipGetLastError());
+            PCC_HIP(hipMemcpyAsync(h, d_words + 1, 12, hipMemcpyDeviceToHost, s));  // changed, (list count of collect), cross count
+            PCC_HIP(hipStreamSynchronize(s));
+            if (sweep == 0) n_cross = h[2];
+            if (h[0] == 0 || n_cross == 0) break;
+        }
     }
     hipLaunchKernelGGL(k_rg_count, dim3(g1(n)), dim3(256), 0, s, comp_label, n, parent, size);
     hipLaunchKernelGGL(k_rg_collect, dim3(g1(n)), dim3(256), 0, s, normals, size, n, min_size, max_size, list, d_words + 2, cap);
