@@ -146,7 +146,7 @@ enum pcc_option {
     PCC_OPT_FLANN_SPLIT = 10,    /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
     PCC_OPT_NN1_DENSE_MIN = 11,  /* flat k = 1 kernel: a wave whose queries' own cells hold at least this many references on average
                                     takes its first bound from the own cell instead of the own row (default 4) */
-    PCC_OPT_KNN_KERNEL = 12      /* k-NN, k <= 128: 1 = selection by distance buckets, the merge network only for the queries it
+    PCC_OPT_KNN_KERNEL = 12      /* k-NN, k <= 512: 1 = selection by distance buckets, the merge network only for the queries it
                                     hands back (default); 0 = the merge network for every query */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);

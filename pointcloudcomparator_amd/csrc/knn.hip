@@ -506,21 +506,28 @@ __device__ __forceinline__ bool bucket_sort_lds(unsigned long long* stage, unsig
 // the K-th.  A query that does not fit -- cube beyond the tables, more candidates than LDS holds, more survivors than
 // the sort takes (many equal distances), bound in the clamped last bucket (queries far outside the grid), fewer than
 // K points around -- goes on a list that k_grid_knn_wave works off afterwards.
-template <int CAP, bool STORE>
+// SCAP_: survivors the final sort takes (K + the K-th's bucket + what pass 2 adds); the candidate buffer is twice that (the
+// sort's second half).  256 for K <= 128, 384 for K <= 256, 768 for K <= 512 -- those two also take cubes of 13 x 13 rows.
+template <int SCAP_, bool STORE>
 __global__ void __launch_bounds__(256)
 k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
                const unsigned int* __restrict__ n_sorted_ptr, int K, KnnOut out,
                unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
-    constexpr unsigned int SCAP = BUCKET_ROW_MAX;  // survivors the final sort takes
-    constexpr int ROWCAP = 11 * 11, SPANCAP = 2 * ROWCAP;
-    static_assert(CAP >= 2 * (int)SCAP, "the sort's second buffer is the upper part of the candidate buffer");
+    constexpr unsigned int SCAP = SCAP_;
+    constexpr int CAP = 2 * SCAP_;
+    constexpr bool BIG = SCAP_ > 256;
+    constexpr int KSEL = BIG ? 6 : 5;  // largest cube half-width: 11 x 11 or 13 x 13 rows
+    constexpr int ROWCAP = (2 * KSEL + 1) * (2 * KSEL + 1), SPANCAP = 2 * ROWCAP;
+    constexpr int RL = (ROWCAP + 63) / 64;  // rows of the cube a lane looks after
+    // candidates of one pass: one (two) planes of span-end bits; K <= 128: 25 KB of LDS, 6 waves per SIMD
+    constexpr unsigned int SEL_FLAT_CAP = BIG ? 4096 : 2048;
+    constexpr int PLANES = SEL_FLAT_CAP / 2048;
     struct alignas(8) WaveLds {
         unsigned long long cand[CAP];
-        unsigned int bk[BUCKET_N + 2], tab_s[SPANCAP], endb[64];
+        unsigned int bk[BUCKET_N + 2], tab_s[SPANCAP], endb[PLANES][64];
         unsigned short tab_o[SPANCAP];  // (flat offsets stay below SEL_FLAT_CAP)
     };
-    constexpr unsigned int SEL_FLAT_CAP = 2048;  // candidates of one pass: one plane of span-end bits (25 KB of LDS: 6 waves per SIMD)
     __shared__ WaveLds lds_all[4];
     WaveLds& L = lds_all[threadIdx.x >> 6];
     const GridParams g = gd->g;
@@ -546,27 +553,29 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         // the smallest cube that holds at least 2 x `want` points (as k_grid_knn_wave).  A lane looks after rows `lane` and
         // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1
         int k = 1;
-        unsigned int cnt = 0, rs0[2], rc[2];
+        unsigned int cnt = 0, rs0[RL], rc[RL];
         for (;; ++k) {
             const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
             const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
             const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
             const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
             const float inv_ny = 1.0f / (float)ny;
+            unsigned int mine = 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RL; ++i) {
                 const int r = (int)lane + 64 * i;
                 rs0[i] = 0;
                 rc[i] = 0;
                 if (r < nrow) {
-                    const int zi = (int)(((float)r + 0.5f) * inv_ny);  // r / ny (exact: r < 128, ny <= 11)
+                    const int zi = (int)(((float)r + 0.5f) * inv_ny);  // r / ny (exact: r < 192, ny <= 13)
                     const unsigned int row = ((unsigned int)(z0 + zi) * g.dim[1] + (y0 + (r - zi * ny))) * g.dim[0];
                     rs0[i] = cell_start[row + x0];
                     rc[i] = cell_start[row + x1 + 1] - rs0[i];
                 }
+                mine += rc[i];
             }
-            cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(rc[0] + rc[1]), 63);
-            if (cnt >= 2u * (unsigned int)want || k >= 5) break;  // (k = 5: 11 x 11 rows, the table)
+            cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(mine), 63);
+            if (cnt >= 2u * (unsigned int)want || k >= KSEL) break;  // (the table's rows)
         }
         if (cnt < (unsigned int)want || cnt > (STORE ? (unsigned int)CAP : SEL_FLAT_CAP)) { give_up(); continue; }
         int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
@@ -580,7 +589,8 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             nspans = 0;
             total = 0;
             wave_lds_sync();
-            L.endb[lane] = 0u;
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) L.endb[p][lane] = 0u;
             wave_lds_sync();
         };
         auto table_add = [&](unsigned int s0, unsigned int c) {
@@ -593,7 +603,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 const unsigned int e = off + c - 1;
                 if (e < SEL_FLAT_CAP) {
                     L.tab_o[slot] = (unsigned short)off;
-                    atomicOr(&L.endb[e & 63], 1u << (e >> 6));
+                    atomicOr(&L.endb[e >> 11][e & 63], 1u << ((e >> 6) & 31));
                 }
             }
             nspans += (unsigned int)__popcll(occ);
@@ -633,8 +643,8 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const unsigned int w = (B >> 6) + (unsigned int)u;
-                    if (w == 0u) word = L.endb[lane];
-                    const unsigned long long m = __ballot(((word >> (w & 31u)) & 1u) != 0u);  // (w < 32: total <= SEL_FLAT_CAP)
+                    if ((w & 31u) == 0u) word = L.endb[(w >> 5) % PLANES][lane];
+                    const unsigned long long m = __ballot(((word >> (w & 31u)) & 1u) != 0u);
                     my[u] = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, before));
                     before += (unsigned int)__popcll(m);
                     c[u] = B + 64u * (unsigned int)u + lane;
@@ -657,8 +667,9 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             const float reach = (float)(k + 1) * g.h;
             const float scale1 = (float)BUCKET_N / (3.03f * reach * reach);
             table_reset();
-            table_add(rs0[0], rc[0]);
-            if ((2 * k + 1) * (2 * k + 1) > 64) table_add(rs0[1], rc[1]);
+#pragma unroll
+            for (int i = 0; i < RL; ++i)
+                if (i == 0 || (2 * k + 1) * (2 * k + 1) > 64 * i) table_add(rs0[i], rc[i]);
             L.bk[1 + 2 * lane] = 0u;
             L.bk[2 + 2 * lane] = 0u;
             wave_lds_sync();
@@ -742,12 +753,16 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             if (!in_order) {
                 if (scnt <= 64) in_order = bucket_sort_lds<1>(L.cand, tmp, L.bk, scnt, scale2, lane);
                 else if (scnt <= 128) in_order = bucket_sort_lds<2>(L.cand, tmp, L.bk, scnt, scale2, lane);
-                else in_order = bucket_sort_lds<4>(L.cand, tmp, L.bk, scnt, scale2, lane);
+                else if (scnt <= 256) in_order = bucket_sort_lds<4>(L.cand, tmp, L.bk, scnt, scale2, lane);
+                else if constexpr (BIG) in_order = bucket_sort_lds<(int)SCAP / 64>(L.cand, tmp, L.bk, scnt, scale2, lane);
             }
             // (entries past `want` -- K beyond the number of valid references -- are "nothing found")
             const size_t row0 = (size_t)qi * K;
             if (in_order) {
                 for (unsigned int e = lane; e < (unsigned int)K; e += 64) knn_emit(out, row0 + e, e < (unsigned int)want ? L.cand[e] : ~0ull);
+            } else if constexpr (BIG) {
+                give_up();  // (a crowded bucket among more keys than four registers per lane hold: the merge kernel's)
+                continue;
             } else {
                 unsigned long long v[4];
 #pragma unroll
@@ -784,21 +799,23 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
     if (K <= 512) {
         unsigned int gw = (n + 3) / 4;  // one wave per query, 4 waves per workgroup, waves loop
         if (gw > 8192) gw = 8192;
-        // K <= 128: selection kernel first; the queries it hands back are worked off by the merge kernel below
+        // selection kernel first; the queries it hands back are worked off by the merge kernel below
         const unsigned int* work = order;
         const unsigned int* n_work = n_sorted;
-        if (K <= 128 && ix->opt.knn_kernel != 0) {
+        if (ix->opt.knn_kernel != 0) {
             // (K > 64: keeping a thousand keys per wave leaves 3 waves per SIMD and the VALU 60 % busy -- 2.66 ms at 1M x K = 100;
             // the 512-key form first and only its returns through a 1024-key one: 3.18 ms -- half the cubes hold more than 512)
             PCC_TRY(ix->knn_fb.reserve((nq + 1) * sizeof(unsigned int)));
             unsigned int* fb = ix->knn_fb.as<unsigned int>();
             PCC_HIP(hipMemsetAsync(fb + nq, 0, sizeof(unsigned int), s));
-            if (K <= 64)
-                hipLaunchKernelGGL((k_grid_knn_sel<512, true>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                                   ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq);
-            else
-                hipLaunchKernelGGL((k_grid_knn_sel<512, false>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),
-                                   ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq);
+#define PCC_LAUNCH_SEL(SCAP_, STORE_)                                                                                     \
+    hipLaunchKernelGGL((k_grid_knn_sel<SCAP_, STORE_>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),            \
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq)
+            if (K <= 64) PCC_LAUNCH_SEL(256, true);
+            else if (K <= 128) PCC_LAUNCH_SEL(256, false);
+            else if (K <= 256) PCC_LAUNCH_SEL(384, false);
+            else PCC_LAUNCH_SEL(768, false);
+#undef PCC_LAUNCH_SEL
             PCC_HIP(hipGetLastError());
             work = fb;
             n_work = fb + nq;

@@ -51,9 +51,9 @@ def test_knn_duplicates_order(gpu):
     assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
 
 
-@pytest.mark.parametrize("k", [1, 7, 51, 64, 65, 100, 128])
+@pytest.mark.parametrize("k", [1, 7, 51, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512])
 def test_knn_selection_kernel_and_merge_kernel_agree_with_the_oracle(gpu, k):
-    """k <= 128 runs the bucket-selection kernel (PCC_OPT_KNN_KERNEL = 1, default) and hands queries it cannot take to
+    """k <= 512 runs the bucket-selection kernel (PCC_OPT_KNN_KERNEL = 1, default) and hands queries it cannot take to
     the merge network; option 0 is the network alone.  Both must give the exhaustive oracle's rows bit for bit on a scene
     that exercises the hand-backs: a lattice (hundreds of equal distances: crowded buckets, survivors beyond the sort),
     dense blobs (cubes beyond the candidate buffer), far and non-finite queries, and a device-resident call."""
