@@ -156,7 +156,8 @@ struct pcc_index {
     bool occ_valid = false;   // occ (device word): number of non-empty cells of the current grid, counted at the first radius count
     pcc::DevBuf occ;
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
-    pcc::DevBuf knn_fb;  // queries the k-NN selection kernel hands back (+ their count)
+    pcc::DevBuf knn_fb;  // a list of up to n indices + its count, one user at a time: queries the k-NN selection kernel hands back,
+                         // rows a fused radius fill leaves to k_sort_rows, region growing's points with a cross edge
     bool ties_pending = false;                    // the tie counters of the last search are still on the device
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
