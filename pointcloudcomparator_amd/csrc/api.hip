@@ -883,13 +883,17 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     const int K = mean_k + 1;
     // self query: the packed references ARE the queries (non-finite points are flagged, are
     // skipped by the search and keep distance 0, as in PCL's applyFilterIndices)
-    PCC_TRY(ix->out_packed.reserve(n * (size_t)K * sizeof(unsigned long long)));
-    auto* keys = ix->out_packed.as<unsigned long long>();
-    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, K, keys));
+    // the mean needs the distances only: the search delivers rows of d2 (4 bytes an entry) where its wave kernels serve K
+    // and the staged mean kernel's tile fits LDS (K <= 126), rows of keys otherwise
+    const bool d2_only = grid_knn_delivers(K) && (size_t)2 * 64 * (K + 1) * sizeof(unsigned int) <= 64 * 1024;
+    PCC_TRY(ix->out_packed.reserve(n * (size_t)K * (d2_only ? sizeof(float) : sizeof(unsigned long long))));
+    auto* keys = d2_only ? nullptr : ix->out_packed.as<unsigned long long>();
+    float* d2_rows = d2_only ? ix->out_packed.as<float>() : nullptr;
+    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, K, keys, nullptr, d2_rows));
     PCC_TRY(ix->out_d2.reserve(no * sizeof(float)));
     float* dmean = ix->out_d2.as<float>();
     PCC_HIP(hipMemsetAsync(dmean, 0, no * sizeof(float), ix->stream));
-    PCC_TRY(launch_sor_mean(ix->stream, keys, ix->refs.as<float4>(), n, K, dmean));
+    PCC_TRY(launch_sor_mean(ix->stream, keys, ix->refs.as<float4>(), n, K, dmean, d2_rows));
     ev_mark(ix, EV_CALL1);
     PCC_TRY(ix->host_a.reserve(no * sizeof(float)));
     PCC_TRY(ix->host_b.reserve(no));

@@ -354,8 +354,11 @@ k_sor_mean(const unsigned long long* __restrict__ keys, const float4* __restrict
 // the same through LDS: a wave's 64 rows are contiguous in memory, so it streams them with fully coalesced
 // loads (lanes over the flat key index), parks the d2 words in LDS and every lane then sums its own row in
 // order.  Lane-per-row reads touched 64 different lines per load: 0.8 ms at 1M x 51 against 0.4 GB of keys.
+// (E = unsigned long long: rows of search keys; E = unsigned int: rows of squared distances as the k-NN kernels deliver
+// them when nobody needs the indices -- half the bytes written and read)
+template <class E>
 __global__ void __launch_bounds__(256)
-k_sor_mean_staged(const unsigned long long* __restrict__ keys, size_t n, int K, float* __restrict__ mean_dist) {
+k_sor_mean_staged(const E* __restrict__ keys, size_t n, int K, float* __restrict__ mean_dist) {
     extern __shared__ unsigned int sor_tile[];
     const unsigned int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     unsigned int* tile = sor_tile + (size_t)wave_in_block * 64 * (K + 1);
@@ -363,11 +366,12 @@ k_sor_mean_staged(const unsigned long long* __restrict__ keys, size_t n, int K, 
     for (size_t base = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; base < n; base += nwaves * 64) {
         const unsigned int rows = (unsigned int)min((size_t)64, n - base);
         const unsigned int total = rows * (unsigned int)K;
-        const unsigned long long* src = keys + base * (size_t)K;
+        const E* src = keys + base * (size_t)K;
         wave_lds_sync();
         for (unsigned int f = lane; f < total; f += 64) {
             const unsigned int r = f / (unsigned int)K, c = f - r * (unsigned int)K;
-            tile[r * (K + 1) + c] = (unsigned int)(src[f] >> 32);
+            if constexpr (sizeof(E) == 8) tile[r * (K + 1) + c] = (unsigned int)(src[f] >> 32);
+            else tile[r * (K + 1) + c] = (unsigned int)src[f];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         wave_lds_sync();
@@ -382,8 +386,9 @@ k_sor_mean_staged(const unsigned long long* __restrict__ keys, size_t n, int K, 
     }
 }
 
+// keys, or d2_rows (rows of K squared distances, float bits) when keys == nullptr
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
-                    float* mean_dist) {
+                    float* mean_dist, const float* d2_rows) {
     if (n == 0) return PCC_OK;
     // four waves per workgroup while their tiles fit 64 KB of LDS (K <= 62; PCL's default mean_k = 50 gives K = 51:
     // 53 KB), two up to K = 126
@@ -392,8 +397,11 @@ int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4*
     if (lds <= 64 * 1024) {
         const int bs = waves * 64;
         const int blocks = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
-        hipLaunchKernelGGL(k_sor_mean_staged, dim3(blocks), dim3(bs), lds, s, keys, n, K, mean_dist);
+        if (keys) hipLaunchKernelGGL((k_sor_mean_staged<unsigned long long>), dim3(blocks), dim3(bs), lds, s, keys, n, K, mean_dist);
+        else hipLaunchKernelGGL((k_sor_mean_staged<unsigned int>), dim3(blocks), dim3(bs), lds, s,
+                                reinterpret_cast<const unsigned int*>(d2_rows), n, K, mean_dist);
     } else {
+        if (!keys) { set_error("launch_sor_mean: rows of distances need the staged kernel"); return PCC_ERR_INVALID; }
         hipLaunchKernelGGL(k_sor_mean, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, refs, n, K, mean_dist);
     }
     PCC_HIP(hipGetLastError());

@@ -221,7 +221,7 @@ int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n);
 // SOR: mean_dist[orig(i)] = float(sum_{j=1..K-1} sqrt(double(d2_j)) / (K-1)) from the K-NN keys of
 // the self query; rows with fewer than K neighbours keep 0
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
-                    float* mean_dist);
+                    float* mean_dist, const float* d2_rows = nullptr);
 
 // ---- exhaustive engine (nn1_brute.hip) -------------------------------------------
 // For every query q[i] (float4, w<0 = invalid) min over refs[0..m) of the unfused
