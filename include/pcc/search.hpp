@@ -9,6 +9,7 @@
 #pragma once
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "pcc_nn.h"
 #include "pcc/point_types.hpp"
@@ -78,6 +79,7 @@ public:
             if (st == PCC_ERR_EMPTY) { index_ = nullptr; return; }
             check(st);
             if (ties_ != PCC_TIES_LOWEST_INDEX) check(pcc_index_set_tie_order(index_, ties_));
+            for (const auto& o : options_) check(pcc_index_set_option(index_, o.first, o.second));
             valid_ = true;
             return;
         }
@@ -91,6 +93,13 @@ public:
     void setTieOrder(int ties) {
         ties_ = ties;
         if (index_) check(pcc_index_set_tie_order(index_, ties_));
+    }
+    // a per-handle implementation choice (enum pcc_option, include/pcc_nn.h); none changes a result bit.  E.g.
+    // setOption(PCC_OPT_KNN_CACHE_K, 100) before NormalEstimation(50) + RegionGrowing(100) on this tree: one search, not two
+    void setOption(int option, double value) {  // (kept and applied to the handle once a cloud has created it)
+        for (auto& o : options_) if (o.first == option) { o.second = value; option = -1; break; }
+        if (option >= 0) options_.emplace_back(option, value);
+        if (index_) for (const auto& o : options_) check(pcc_index_set_option(index_, o.first, o.second));
     }
     CloudConstPtr getInputCloud() const { return input_; }
     IndicesConstPtr getIndices() const { return indices_; }
@@ -165,6 +174,7 @@ private:
     int device_, engine_;
     CloudConstPtr input_;
     pcc_index* index_ = nullptr;
+    std::vector<std::pair<int, double>> options_;
     bool valid_ = false;  // index_ holds at least one finite point of input_
 };
 

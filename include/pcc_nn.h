@@ -146,8 +146,13 @@ enum pcc_option {
     PCC_OPT_FLANN_SPLIT = 10,    /* PCC_TIES_FLANN: split rule replayed, 0 = middleSplit_ (FLANN 1.8.x divideTree), 1 = middleSplit */
     PCC_OPT_NN1_DENSE_MIN = 11,  /* flat k = 1 kernel: a wave whose queries' own cells hold at least this many references on average
                                     takes its first bound from the own cell instead of the own row (default 4) */
-    PCC_OPT_KNN_KERNEL = 12      /* k-NN, k <= 512: 1 = selection by distance buckets, the merge network only for the queries it
+    PCC_OPT_KNN_KERNEL = 12,     /* k-NN, k <= 512: 1 = selection by distance buckets, the merge network only for the queries it
                                     hands back (default); 0 = the merge network for every query */
+    PCC_OPT_KNN_CACHE_K = 13     /* 0 (default): off.  K > 0: the self k-NN rows behind pcc_normals / pcc_region_growing are searched
+                                    with at least K neighbours and KEPT on the device until the next pcc_index_set_input; a later call
+                                    that needs no more than the kept rows hold takes their prefix instead of searching again (the
+                                    reference's default segmentation: normals with 50, then region growing with 100 neighbours of the
+                                    same cloud -- one search instead of two).  Costs n x K x 8 bytes of device memory */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -39,6 +39,7 @@ void Options::from_env() {
     flann_split = (int)num("PCC_FLANN_SPLIT", flann_split);
     nn1_dense_min = (int)num("PCC_NN1_DENSE_MIN", nn1_dense_min);
     knn_kernel = (int)num("PCC_KNN_KERNEL", knn_kernel);
+    knn_cache_k = (int)num("PCC_KNN_CACHE_K", knn_cache_k);
 }
 
 int DevBuf::reserve(size_t bytes) {
@@ -197,6 +198,7 @@ static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, in
     ix->order_valid = false;
     ix->flann_valid = false;
     ix->occ_valid = false;
+    ix->self_rows_k = 0;
     ix->n_orig = n;  // the build steps size their launches from it
     const int st = set_input_impl(ix, pts, n, stride, mem);
     if (st != PCC_OK) { ix->n_orig = 0; ix->has_grid = false; }
@@ -227,7 +229,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -477,6 +479,7 @@ static double* option_slot(pcc_index* ix, int option, int** as_int) {
         case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
         case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
         case PCC_OPT_KNN_KERNEL: *as_int = &o.knn_kernel; return nullptr;
+        case PCC_OPT_KNN_CACHE_K: *as_int = &o.knn_cache_k; return nullptr;
         default: return nullptr;
     }
 }
@@ -494,6 +497,7 @@ int pcc_index_set_option(pcc_index* ix, int option, double value) {
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
         case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 3; break;
         case PCC_OPT_EC_CELLS: ok = value >= 0 && value <= 2; break;
+        case PCC_OPT_KNN_CACHE_K: ok = value >= 0 && value <= 512; break;
         case PCC_OPT_NN1_DENSE_MIN: ok = value >= 1 && value <= 1000000; break;
         case PCC_OPT_FLANN_SPLIT: ok = value >= 0 && value <= 2; break;
         default: ok = value == 0 || value == 1; break;
@@ -746,6 +750,32 @@ int pcc_sac_plane(pcc_index* ix, const void* pts, size_t n, size_t stride, int m
     return PCC_OK;
 }
 
+// The self k-NN rows (keys) of the indexed cloud with k neighbours, for pcc_normals / pcc_region_growing.  With
+// PCC_OPT_KNN_CACHE_K the rows are searched with at least that many neighbours and kept until the next set_input; a request
+// the kept rows cover is their prefix (k-NN rows are ascending), copied row by row -- 0.15 ms at 1M x 50 against a 1.1 ms search.
+static int self_knn_keys(pcc_index* ix, int k, const unsigned long long** keys) {
+    const size_t n = ix->n_orig;
+    const int want_kept = ix->opt.knn_cache_k > 0 ? std::max(k, ix->opt.knn_cache_k) : 0;
+    if (ix->self_rows_k < k && want_kept > 0 && want_kept <= PCC_KNN_MAX_K) {
+        ix->self_rows_k = 0;
+        PCC_TRY(ix->self_rows.reserve(n * (size_t)want_kept * sizeof(unsigned long long)));
+        PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, want_kept, ix->self_rows.as<unsigned long long>()));
+        ix->self_rows_k = want_kept;
+    }
+    if (ix->self_rows_k >= k) {
+        if (ix->self_rows_k == k) { *keys = ix->self_rows.as<unsigned long long>(); return PCC_OK; }
+        PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
+        PCC_TRY(launch_copy_row_prefix(ix->stream, ix->self_rows.as<unsigned long long>(), ix->self_rows_k,
+                                       ix->out_packed.as<unsigned long long>(), k, n));
+        *keys = ix->out_packed.as<unsigned long long>();
+        return PCC_OK;
+    }
+    PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
+    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, ix->out_packed.as<unsigned long long>()));
+    *keys = ix->out_packed.as<unsigned long long>();
+    return PCC_OK;
+}
+
 int pcc_normals(pcc_index* ix, int k, const float viewpoint[3], int mem, float* out) {
     PCC_ENTER(ix);
     if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
@@ -757,9 +787,8 @@ int pcc_normals(pcc_index* ix, int k, const float viewpoint[3], int mem, float* 
     const size_t n = ix->n_orig;
     const float origin[3] = {0.f, 0.f, 0.f};
     // self query on the packed references, as pcc_sor does
-    PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
-    auto* keys = ix->out_packed.as<unsigned long long>();
-    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, keys));
+    const unsigned long long* keys = nullptr;
+    PCC_TRY(self_knn_keys(ix, k, &keys));
     float4* dout = reinterpret_cast<float4*>(out);
     if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_d2.reserve(n * sizeof(float4))); dout = ix->out_d2.as<float4>(); }
     PCC_TRY(launch_normals(ix->stream, keys, ix->refs.as<float4>(), ix->cell_refs.as<float4>(), ix->d_grid.as<GridDev>(), n, k,
@@ -805,9 +834,8 @@ int pcc_region_growing(pcc_index* ix, const float* normals, int mem, int k, floa
     ev_mark(ix, EV_CALL0);
     const size_t n = ix->n_orig;
     // findPointNeighbours: one batched self k-NN over the packed references
-    PCC_TRY(ix->out_packed.reserve(n * (size_t)k * sizeof(unsigned long long)));
-    auto* keys = ix->out_packed.as<unsigned long long>();
-    PCC_TRY(grid_knn(ix, ix->refs.as<float4>(), n, k, keys));
+    const unsigned long long* keys = nullptr;
+    PCC_TRY(self_knn_keys(ix, k, &keys));
     const float4* dn = reinterpret_cast<const float4*>(normals);
     int32_t* dl = labels;
     if (mem == PCC_MEM_HOST) {

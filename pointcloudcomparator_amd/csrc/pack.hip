@@ -386,6 +386,22 @@ k_sor_mean_staged(const E* __restrict__ keys, size_t n, int K, float* __restrict
     }
 }
 
+// the first k_dst entries of every row of k_src (k-NN rows are ascending: the prefix of a longer row IS the shorter row)
+__global__ void __launch_bounds__(256)
+k_copy_row_prefix(const unsigned long long* __restrict__ src, int k_src, unsigned long long* __restrict__ dst, int k_dst, size_t total) {
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = f / (size_t)k_dst;
+        dst[f] = src[r * (size_t)k_src + (f - r * (size_t)k_dst)];
+    }
+}
+int launch_copy_row_prefix(hipStream_t s, const unsigned long long* src, int k_src, unsigned long long* dst, int k_dst, size_t n) {
+    const size_t total = n * (size_t)k_dst;
+    if (total == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_copy_row_prefix, dim3(grid_for(total, 256)), dim3(256), 0, s, src, k_src, dst, k_dst, total);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
 // keys, or d2_rows (rows of K squared distances, float bits) when keys == nullptr
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
                     float* mean_dist, const float* d2_rows) {

@@ -97,6 +97,7 @@ struct Options {
     double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
     double sort_mp_min_q = 5e6;     // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds
     int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 rows drained flat, lanes over candidates (2 / 3: open lanes listed / in place)
+    int knn_cache_k = 0;            // PCC_OPT_KNN_CACHE_K: self k-NN rows searched with at least this K and kept (0: off)
     int knn_kernel = 1;             // PCC_OPT_KNN_KERNEL: 1 selection kernel for k <= 128, 0 merge network only
     int nn1_dense_min = 4;          // PCC_OPT_NN1_DENSE_MIN: references per own cell from which a wave starts with the own cell alone
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
@@ -153,6 +154,8 @@ struct pcc_index {
     int tie_mode = PCC_TIES_LOWEST_INDEX;
     pcc::FlannTree flann;
     bool flann_valid = false;
+    int self_rows_k = 0;      // self_rows holds the self k-NN rows of the indexed cloud with this many neighbours (0: nothing kept)
+    pcc::DevBuf self_rows;
     bool occ_valid = false;   // occ (device word): number of non-empty cells of the current grid, counted at the first radius count
     pcc::DevBuf occ;
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
@@ -222,6 +225,7 @@ int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n);
 // the self query; rows with fewer than K neighbours keep 0
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
                     float* mean_dist, const float* d2_rows = nullptr);
+int launch_copy_row_prefix(hipStream_t s, const unsigned long long* src, int k_src, unsigned long long* dst, int k_dst, size_t n);
 
 // ---- exhaustive engine (nn1_brute.hip) -------------------------------------------
 // For every query q[i] (float4, w<0 = invalid) min over refs[0..m) of the unfused

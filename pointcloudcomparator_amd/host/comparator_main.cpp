@@ -116,6 +116,7 @@ static std::vector<PointCloud<PointXYZRGB>::Ptr> region_growing_segmentation(con
     vg.filter(*cloud_filtered);
     std::cout << "PointCloud after filtering has: " << cloud_filtered->points.size() << " data points." << std::endl;
     search::KdTree<PointXYZRGB>::Ptr tree(new search::KdTree<PointXYZRGB>);
+    tree->setOption(PCC_OPT_KNN_CACHE_K, 100);  // normals (50) and region growing (100) share one 100-neighbour search
     PointCloud<Normal>::Ptr normals(new PointCloud<Normal>);
     NormalEstimation<PointXYZRGB, Normal> normal_estimator;
     normal_estimator.setSearchMethod(tree);

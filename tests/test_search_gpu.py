@@ -135,6 +135,33 @@ def test_euclidean_clusters_filters_and_nonfinite(gpu):
     assert labels[10] == -1
 
 
+def test_kept_self_knn_rows_serve_normals_and_region_growing(gpu):
+    """PCC_OPT_KNN_CACHE_K: the self k-NN rows are searched once with K neighbours and kept; normals (50) takes their
+    prefix, region growing (100) the rows themselves; a larger request searches again; a new cloud drops them.  Every
+    result must equal the uncached one bit for bit."""
+    pts = _scene(40000)
+    other = _scene(30000, synth.SEED_B)
+    with capi.Index(pts) as ix:
+        n0 = ix.normals(50)
+        l0, c0 = ix.region_growing(n0, k=100)
+        l1, c1 = ix.region_growing(n0, k=120)
+        ix.set_option(capi.OPT_KNN_CACHE_K, 100)
+        n2 = ix.normals(50)                       # searches 100, takes the prefix
+        l2, c2 = ix.region_growing(n0, k=100)     # the kept rows as they are
+        n3 = ix.normals(30)                       # prefix again
+        l3, c3 = ix.region_growing(n0, k=120)     # more than kept: searched again (and kept)
+        n4 = ix.normals(50)
+        assert (_bits(n2) == _bits(n0)).all() and (_bits(n4) == _bits(n0)).all()
+        assert c2 == c0 and (l2 == l0).all() and c3 == c1 and (l3 == l1).all()
+        ix.set_option(capi.OPT_KNN_CACHE_K, 0)
+        assert (_bits(ix.normals(30)) == _bits(n3)).all()
+        ix.set_option(capi.OPT_KNN_CACHE_K, 64)
+        ix.set_input(other)                       # a new cloud: nothing kept may survive
+        na = ix.normals(50)
+    with capi.Index(other) as ix:
+        assert (_bits(ix.normals(50)) == _bits(na)).all()
+
+
 def test_sor_matches_oracle(gpu):
     pts = _scene(30000)
     pts[100] = np.nan
