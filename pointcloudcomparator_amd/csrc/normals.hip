@@ -26,6 +26,7 @@ namespace {
 // so the neighbour gathers of adjacent lanes overlap in L1 (in index order every gather was a miss and every
 // 8-byte row read touched its own line: 1.5 ms at 1M x K = 50 against 0.3 ms of useful traffic).
 constexpr int NR_KC = 32;
+constexpr int NR_U = 8;
 
 __global__ void __launch_bounds__(256)
 k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict__ refs, const float4* __restrict__ cell_refs,
@@ -46,25 +47,42 @@ k_normals(const unsigned long long* __restrict__ keys, const float4* __restrict_
         for (int c0 = 0; c0 < K; c0 += NR_KC) {
             const int kc = min(NR_KC, K - c0);
             wave_lds_sync();
-            for (int r = 0; r < 64; ++r) {
-                const unsigned int rr = base + r;
-                if (rr >= n_valid) break;  // wave-uniform
-                const size_t row = (size_t)(unsigned int)__float_as_int(cell_refs[rr].w);
-                if ((int)lane < kc) {
-                    const unsigned long long key = keys[row * (size_t)K + c0 + lane];
-                    tile[r][lane] = key_none(key) ? 0xffffffffu : (unsigned int)key;
+            // (the 64 row numbers are the lanes' own point indices: read out with v_readlane, eight rows' loads in flight (sixteen measured the same) --
+            // one row at a time, each behind a load of its row number, was 128 dependent round trips per tile)
+            for (int r0 = 0; r0 < 64; r0 += 8) {
+                if (base + (unsigned int)r0 >= n_valid) break;  // wave-uniform
+                unsigned long long kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const size_t row = (size_t)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)i, r0 + u);
+                    kk[u] = ~0ull;
+                    if (base + (unsigned int)(r0 + u) < n_valid && (int)lane < kc) kk[u] = keys[row * (size_t)K + c0 + lane];
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + (unsigned int)(r0 + u) < n_valid && (int)lane < kc)
+                        tile[r0 + u][lane] = key_none(kk[u]) ? 0xffffffffu : (unsigned int)kk[u];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             wave_lds_sync();
-            for (int j = 0; j < kc; ++j) {
-                const unsigned int idx = open ? tile[lane][j] : 0xffffffffu;
-                if (idx == 0xffffffffu) { open = false; continue; }
-                const float4 p = refs[idx];
-                ++cnt;
-                a0 += p.x * p.x; a1 += p.x * p.y; a2 += p.x * p.z;
-                a3 += p.y * p.y; a4 += p.y * p.z; a5 += p.z * p.z;
-                a6 += p.x; a7 += p.y; a8 += p.z;
+            // NR_U neighbours at a time: their gathers are issued together, the sums then take them in row order (PCL's
+            // order of accumulation).  One gather per trip of the loop left the kernel waiting 92 % of its time.
+            for (int j0 = 0; j0 < kc; j0 += NR_U) {
+                unsigned int id[NR_U];
+                float4 p[NR_U];
+#pragma unroll
+                for (int u = 0; u < NR_U; ++u) id[u] = (open && j0 + u < kc) ? tile[lane][j0 + u] : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < NR_U; ++u)
+                    if (id[u] != 0xffffffffu) p[u] = refs[id[u]];
+#pragma unroll
+                for (int u = 0; u < NR_U; ++u) {
+                    if (id[u] == 0xffffffffu) { open = false; continue; }  // (rows are ascending: nothing follows a missing entry)
+                    ++cnt;
+                    a0 += p[u].x * p[u].x; a1 += p[u].x * p[u].y; a2 += p[u].x * p[u].z;
+                    a3 += p[u].y * p[u].y; a4 += p[u].y * p[u].z; a5 += p[u].z * p[u].z;
+                    a6 += p[u].x; a7 += p[u].y; a8 += p[u].z;
+                }
             }
         }
         if (!have) continue;
