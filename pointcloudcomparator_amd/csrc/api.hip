@@ -1115,7 +1115,10 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
                                         ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
                                         static_cast<unsigned int*>(ix->pinned) + 40, center_dev));
                 PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed, center_dev));
-                PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4)));
+                // (the transform also zeroes the counters of the next pass's search)
+                unsigned int* zw = ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr;
+                PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4), zw));
+                if (zw && n > 0) ix->fb_zeroed = true;
                 ev_mark(ix, EV_CALL1);
             }
             PCC_HIP(hipMemcpyAsync(&h1, ix->icp_state.p, sizeof(h1), hipMemcpyDeviceToHost, ix->stream));

@@ -1021,7 +1021,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     if (far) {
         unsigned int* fb2_list = fb_list + n + 64;
         unsigned int* fb2_count = ix->small.as<unsigned int>() + 33;
-        PCC_HIP(hipMemsetAsync(fb2_count, 0, 4, s));
+        // (fb2_count is the second of the two words zeroed at the top of this call -- or by the pack / transform kernel before it)
         const size_t n_seeds = (ix->n_orig + SEED_STRIDE - 1) / SEED_STRIDE;
         // (a warm-started query brings its bound along: no seed scan)
         if (!warm) PCC_TRY(launch_nn1_brute(s, ix->seeds.as<float4>(), n_seeds, q, n, out, fb_list, fb_count, n, true));

@@ -286,7 +286,11 @@ int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4*
 struct Mat34 { float m[12]; };
 __global__ void __launch_bounds__(256)
 k_transform(Mat34 T, const float* __restrict__ Tdev, const char* __restrict__ src, size_t n,
-            size_t sstride, char* __restrict__ dst, size_t dstride) {
+            size_t sstride, char* __restrict__ dst, size_t dstride, unsigned int* __restrict__ zero_word) {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x < 64) {  // counters of the search that follows (as k_pack does): an ICP pass
+        if (threadIdx.x < 2) zero_word[threadIdx.x] = 0u;     // otherwise spends three 4-us memset nodes on them
+        zero_word[PCC_OPEN_CTR0 - 32 + threadIdx.x * PCC_OPEN_CTR_STRIDE] = 0u;
+    }
     float m[12];
     for (int k = 0; k < 12; ++k) m[k] = Tdev ? Tdev[k] : T.m[k];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -301,12 +305,12 @@ k_transform(Mat34 T, const float* __restrict__ Tdev, const char* __restrict__ sr
     }
 }
 int launch_transform(hipStream_t s, const float* Tdev, const float T[16], const void* src, size_t n,
-                     size_t sstride, void* dst, size_t dstride) {
+                     size_t sstride, void* dst, size_t dstride, unsigned int* zero_word) {
     if (n == 0) return PCC_OK;
     Mat34 M;
     for (int k = 0; k < 12; ++k) M.m[k] = T ? T[k] : 0.f;
     hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 256)), dim3(256), 0, s, M, Tdev, (const char*)src, n,
-                       sstride, (char*)dst, dstride);
+                       sstride, (char*)dst, dstride, zero_word);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

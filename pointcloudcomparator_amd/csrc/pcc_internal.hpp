@@ -216,7 +216,7 @@ int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& t
 int launch_unpack(hipStream_t s, const unsigned long long* packed, const float4* q, size_t n,
                   int32_t* idx, float* d2, const unsigned int* mirror_dev = nullptr, unsigned int* mirror_host = nullptr);
 int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[16],
-                     const void* src, size_t n, size_t sstride, void* dst, size_t dstride);
+                     const void* src, size_t n, size_t sstride, void* dst, size_t dstride, unsigned int* zero_word = nullptr);
 // packed points whose w flags them invalid get NaN coordinates again (in place): what a raw cloud looked like
 int launch_nanify(hipStream_t s, float4* pts, size_t n);
 // dst[i].w = src[i].w (validity flags of packed points)
