@@ -25,6 +25,17 @@ def test_header_symbols_are_exported():
     assert sorted(capi.SYMBOLS) == declared
 
 
+def test_option_constants_of_the_binding_match_the_header():
+    """enum pcc_option in include/pcc_nn.h <-> capi.OPT_*: same names, same values, none missing on either side"""
+    from pointcloudcomparator_amd import capi
+    text = (ROOT / "include" / "pcc_nn.h").read_text()
+    body = re.search(r"enum pcc_option\s*\{(.*?)\};", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"PCC_(OPT_[A-Z0-9_]+)\s*=\s*(\d+)", body)}
+    binding = {k: v for k, v in vars(capi).items() if k.startswith("OPT_")}
+    assert len(header) >= 13 and header == binding
+
+
 def test_version_and_error_string():
     from pointcloudcomparator_amd import capi
     assert capi.LIB.pcc_version() == 100
