@@ -261,6 +261,20 @@ def test_room_scan_surface_sampled_scene(gpu):
         ix.set_option(capi.OPT_NN1_KERNEL, 1)
         sel = np.sort(np.random.default_rng(5).choice(n, 200, replace=False))
         ki, kd = ix.knn(np.ascontiguousarray(b[sel]), 51)
+        # radius search on a surface scan: the points pile up in the cells the surfaces cross, so the count pass takes its
+        # wave form (the rule looks at the filling of OCCUPIED cells); counts of every query, rows of the sample
+        cnt = ix.radius_count(tb, 0.05)
+        ix.sync()
+        cnt = cnt.cpu().numpy()
+        ro, ri, rd = ix.radius_search(np.ascontiguousarray(b[sel]), 0.05, sorted=True)
+    ecnt = oracle.radius_count_exhaustive(a, np.ascontiguousarray(b[sel]), 0.05)
+    assert (cnt[sel] == ecnt).all() and (np.diff(ro) == ecnt).all() and cnt.mean() > 50
+    for j in range(0, 200, 20):
+        dd = ((a - b[sel[j]]) ** 2).astype(np.float32)
+        want = (dd[:, 0] + dd[:, 1]) + dd[:, 2]
+        inside = np.nonzero(want < np.float32(0.05 * 0.05))[0]
+        order = np.lexsort((inside, want[inside]))
+        assert (ri[ro[j]:ro[j + 1]] == inside[order]).all() and (_bits(rd[ro[j]:ro[j + 1]]) == _bits(want[inside][order])).all()
     for idx, d2 in res[1:]:
         assert (idx == res[0][0]).all() and (_bits(d2) == _bits(res[0][1])).all()
     _sample_check(a, b, res[0][0], res[0][1])
