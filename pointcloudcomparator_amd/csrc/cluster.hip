@@ -196,9 +196,11 @@ k_uf_flatten_count_runs(const float4* __restrict__ cr2, const GridDev* __restric
     const bool have = t < gd2->n_valid;
     unsigned int r = 0xffffffffu;
     if (have) {
+        // (the links are done: a plain walk and a plain store of the root -- nobody else writes anything but ancestors, and
+        // the root is the smallest of them)
         const unsigned int i = (unsigned int)__float_as_int(cr2[t].w);
-        r = uf_find(parent, i);
-        atomicMin(&parent[i], r);
+        r = uf_find_settled(parent, i);
+        parent[i] = r;
     }
     const unsigned int prev = __shfl_up(r, 1, 64);
     const bool head = have && (lane == 0 || prev != r);

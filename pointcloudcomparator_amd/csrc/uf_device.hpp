@@ -16,6 +16,16 @@ __device__ __forceinline__ unsigned int uf_find(unsigned int* __restrict__ paren
         x = p;
     }
 }
+// the root of x when NO union runs any more (the flatten pass after the links, a kernel of its own): parents only ever
+// move towards the root, so any value a cache still holds is an ancestor and the walk ends at the same root -- plain
+// loads through the caches instead of agent-scope ones past them, no halving writes
+__device__ __forceinline__ unsigned int uf_find_settled(const unsigned int* __restrict__ parent, unsigned int x) {
+    for (;;) {
+        const unsigned int p = parent[x];
+        if (p == x) return x;
+        x = p;
+    }
+}
 // are a and b in one component (now)?  Both walks advance together -- their loads are in flight at the same time -- and
 // stop as soon as they meet: a parent is an ancestor, and a common ancestor proves the link before either root is reached
 // (already-linked points one step below their root, the usual case late in a pass, cost ONE round trip instead of six).
