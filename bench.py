@@ -69,9 +69,22 @@ def parse_args():
     return ap.parse_args()
 
 
+def check_device_count(ranks: int) -> None:
+    """one rank per GPU: a node with fewer devices than ranks is refused before anything is launched or any
+    process group is formed (a hang at the first collective otherwise).  torch.cuda.device_count() does not
+    initialise the GPU on this image.  PCC_BENCH_SHARE_DEVICES=1 keeps the one-GPU rehearsal (ranks share
+    devices, gloo instead of RCCL) possible; it is never the driver's case."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ranks > ndev and os.environ.get("PCC_BENCH_SHARE_DEVICES", "0") != "1":
+        sys.exit(f"bench.py: {ranks} ranks requested but this node has {ndev} GPU(s); one rank per GPU is required "
+                 "(set PCC_BENCH_SHARE_DEVICES=1 for a shared-device rehearsal over gloo)")
+
+
 def launch_ranks(args) -> int:
     """`bench.py --gpus N` outside a torch.distributed environment: start the N ranks as a child process group.
     Nothing here has touched the GPU (no torch.cuda call, libpcc_nn not loaded): the child is a fresh program."""
+    check_device_count(args.gpus)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -123,14 +136,20 @@ def main():
     dist = None
     # one rank per GPU.  Rehearsals on a box with fewer GPUs than ranks share devices; RCCL refuses two
     # ranks on one device, so that case (never the driver's) falls back to gloo and says so.
+    check_device_count(world)
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank % ndev
     backend = os.environ.get("PCC_BENCH_BACKEND", "nccl" if world <= ndev else "gloo")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # PCC_BENCH_FORCE_GROUP=1 forms the process group at world size 1 too: every collective of the N > 1 path
+    # (RCCL broadcast, all_reduce(MAX), per-rank gather, destroy) then runs on a one-GPU box (tests/test_bench_gpu.py)
+    if world > 1 or os.environ.get("PCC_BENCH_FORCE_GROUP", "0") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -138,6 +157,7 @@ def main():
             if rank == 0:
                 print(f"[bench] note: {world} ranks on {ndev} GPU(s): backend {backend}, devices shared", file=sys.stderr)
     n_gpus = dist.get_world_size() if dist is not None else 1  # the ranks the process group actually holds
+    backend_name = dist.get_backend() if dist is not None else "none"
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but the process group has {n_gpus} rank(s); using {n_gpus}", file=sys.stderr)
     bcast_name = "RCCL" if backend == "nccl" else backend
@@ -428,15 +448,15 @@ def main():
         icp = run_icp()
         value, ms_per_step, workload = icp["nn_queries_per_sec"], icp["ms"], icp["workload"]
     else:
-        prim = run_nn(primary_cfg, with_exhaustive=(not args.no_exhaustive and args.config != "auto"),
-                      with_cpu=not args.no_cpu)
+        prim = run_nn(primary_cfg, n_per_rank=(C5_TOTAL_QUERIES // n_gpus if primary_cfg == "c5" else None),
+                      with_exhaustive=(not args.no_exhaustive and args.config != "auto"), with_cpu=not args.no_cpu)
         value, ms_per_step, workload = prim["value"], prim["ms_per_step"], prim["workload"]
 
     out = {
         "metric": "nn_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if primary_cfg == "c5" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "name": primary_cfg,
+        "config": {"workload": workload, "name": primary_cfg, "backend": backend_name,
                    "parallelism": f"query-sharded x{n_gpus}, reference cloud replicated "
                                   f"({bcast_name} broadcast, outside the timed region)"},
     }
@@ -469,11 +489,15 @@ def main():
                                                              "frac_of_hbm": round(o["frac_of_hbm"], 4)} for o in ops]}
                 except Exception:
                     pass
-        else:
-            # BASELINE configs[4]: 32M queries vs 8M references, sharded over the ranks present
-            c5 = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // n_gpus, steps=min(K, 10), warmup=2)
-            c5["scaling"] = "strong (32M queries in total, whatever the rank count)"
-            extra["c5"] = c5
+            # what ONE of eight GPUs does in BASELINE configs[4] (a 4M-query shard vs the 8M references)
+            shard = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // 8, steps=min(K, 10), warmup=2)
+            shard["scaling"] = "one shard of the 8-GPU configuration, measured on one GPU"
+            extra["c5_shard"] = shard
+        # BASELINE configs[4]: 32M queries vs 8M references, sharded over the ranks present -- at EVERY N, one GPU
+        # included (all 32M queries there), so that the strong-scaling curve has its N = 1 anchor
+        c5 = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // n_gpus, steps=min(K, 10), warmup=2)
+        c5["scaling"] = "strong (32M queries in total, whatever the rank count)"
+        extra["c5"] = c5
         out["extra"] = extra
 
     if dist is not None:

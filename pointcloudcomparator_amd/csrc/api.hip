@@ -24,22 +24,61 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+// the range every option value must lie in, whoever sets it (pcc_index_set_option or a PCC_* environment default)
+static bool option_in_range(int option, double value) {
+    if (!std::isfinite(value)) return false;
+    switch (option) {
+        case PCC_OPT_GRID_PPC: return value > 0 && value <= 1024;
+        case PCC_OPT_GRID_TRIM: return value >= 0 && value <= 8;
+        case PCC_OPT_FAR_MODE: return value >= -1 && value <= 1;
+        case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: return value >= 0;
+        case PCC_OPT_NN1_KERNEL: return value >= 0 && value <= 3;
+        case PCC_OPT_EC_CELLS: return value >= 0 && value <= 2;
+        case PCC_OPT_KNN_CACHE_K: return value >= 0 && value <= 512;
+        case PCC_OPT_NN1_DENSE_MIN: return value >= 1 && value <= 1000000;
+        case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
+        default: return value == 0 || value == 1;
+    }
+}
+static double* option_slot(Options& o, int option, int** as_int) {
+    *as_int = nullptr;
+    switch (option) {
+        case PCC_OPT_GRID_PPC: return &o.grid_ppc;
+        case PCC_OPT_SORT_MP_MIN: return &o.sort_mp_min;
+        case PCC_OPT_SORT_MP_MIN_Q: return &o.sort_mp_min_q;
+        case PCC_OPT_GRID_TRIM: *as_int = &o.grid_trim; return nullptr;
+        case PCC_OPT_FAR_MODE: *as_int = &o.far_mode; return nullptr;
+        case PCC_OPT_ICP_WARM: *as_int = &o.icp_warm; return nullptr;
+        case PCC_OPT_ICP_DEVICE_LOOP: *as_int = &o.icp_device_loop; return nullptr;
+        case PCC_OPT_EC_CELLS: *as_int = &o.ec_cells; return nullptr;
+        case PCC_OPT_NN1_KERNEL: *as_int = &o.nn1_kernel; return nullptr;
+        case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
+        case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
+        case PCC_OPT_KNN_KERNEL: *as_int = &o.knn_kernel; return nullptr;
+        case PCC_OPT_KNN_CACHE_K: *as_int = &o.knn_cache_k; return nullptr;
+        default: return nullptr;
+    }
+}
+
+// PCC_* environment variables give a new handle its defaults; a value outside the option's range is ignored (the
+// built-in default stays), exactly what pcc_index_set_option would have refused
 void Options::from_env() {
-    auto num = [](const char* name, double dflt) { const char* v = getenv(name); return v && *v ? atof(v) : dflt; };
-    grid_ppc = num("PCC_GRID_PPC", grid_ppc);
-    if (!(grid_ppc > 0)) grid_ppc = 0.75;
-    grid_trim = (int)num("PCC_GRID_TRIM", grid_trim);
-    far_mode = (int)num("PCC_GRID_FAR", far_mode);
-    icp_warm = (int)num("PCC_ICP_WARM", icp_warm);
-    icp_device_loop = (int)num("PCC_ICP_DEVICE_LOOP", icp_device_loop);
-    ec_cells = (int)num("PCC_EC_CELLS", ec_cells);
-    sort_mp_min = num("PCC_SORT_MP_MIN", sort_mp_min);
-    sort_mp_min_q = num("PCC_SORT_MP_MIN_Q", sort_mp_min_q);
-    nn1_kernel = (int)num("PCC_NN1_KERNEL", nn1_kernel);
-    flann_split = (int)num("PCC_FLANN_SPLIT", flann_split);
-    nn1_dense_min = (int)num("PCC_NN1_DENSE_MIN", nn1_dense_min);
-    knn_kernel = (int)num("PCC_KNN_KERNEL", knn_kernel);
-    knn_cache_k = (int)num("PCC_KNN_CACHE_K", knn_cache_k);
+    static const struct { const char* name; int option; } vars[] = {
+        {"PCC_GRID_PPC", PCC_OPT_GRID_PPC}, {"PCC_GRID_TRIM", PCC_OPT_GRID_TRIM}, {"PCC_GRID_FAR", PCC_OPT_FAR_MODE},
+        {"PCC_ICP_WARM", PCC_OPT_ICP_WARM}, {"PCC_ICP_DEVICE_LOOP", PCC_OPT_ICP_DEVICE_LOOP}, {"PCC_EC_CELLS", PCC_OPT_EC_CELLS},
+        {"PCC_SORT_MP_MIN", PCC_OPT_SORT_MP_MIN}, {"PCC_SORT_MP_MIN_Q", PCC_OPT_SORT_MP_MIN_Q}, {"PCC_NN1_KERNEL", PCC_OPT_NN1_KERNEL},
+        {"PCC_FLANN_SPLIT", PCC_OPT_FLANN_SPLIT}, {"PCC_NN1_DENSE_MIN", PCC_OPT_NN1_DENSE_MIN}, {"PCC_KNN_KERNEL", PCC_OPT_KNN_KERNEL},
+        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}};
+    for (const auto& v : vars) {
+        const char* txt = getenv(v.name);
+        if (!txt || !*txt) continue;
+        char* end = nullptr;
+        const double value = strtod(txt, &end);
+        int* pi = nullptr;
+        double* pd = option_slot(*this, v.option, &pi);
+        if (end == txt || !option_in_range(v.option, pi ? std::trunc(value) : value)) continue;
+        if (pd) *pd = value; else *pi = (int)value;
+    }
 }
 
 int DevBuf::reserve(size_t bytes) {
@@ -463,46 +502,13 @@ int pcc_index_set_tie_order(pcc_index* ix, int ties) {
     ix->tie_mode = ties;
     return PCC_OK;
 }
-static double* option_slot(pcc_index* ix, int option, int** as_int) {
-    *as_int = nullptr;
-    Options& o = ix->opt;
-    switch (option) {
-        case PCC_OPT_GRID_PPC: return &o.grid_ppc;
-        case PCC_OPT_SORT_MP_MIN: return &o.sort_mp_min;
-        case PCC_OPT_SORT_MP_MIN_Q: return &o.sort_mp_min_q;
-        case PCC_OPT_GRID_TRIM: *as_int = &o.grid_trim; return nullptr;
-        case PCC_OPT_FAR_MODE: *as_int = &o.far_mode; return nullptr;
-        case PCC_OPT_ICP_WARM: *as_int = &o.icp_warm; return nullptr;
-        case PCC_OPT_ICP_DEVICE_LOOP: *as_int = &o.icp_device_loop; return nullptr;
-        case PCC_OPT_EC_CELLS: *as_int = &o.ec_cells; return nullptr;
-        case PCC_OPT_NN1_KERNEL: *as_int = &o.nn1_kernel; return nullptr;
-        case PCC_OPT_FLANN_SPLIT: *as_int = &o.flann_split; return nullptr;
-        case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
-        case PCC_OPT_KNN_KERNEL: *as_int = &o.knn_kernel; return nullptr;
-        case PCC_OPT_KNN_CACHE_K: *as_int = &o.knn_cache_k; return nullptr;
-        default: return nullptr;
-    }
-}
 int pcc_index_set_option(pcc_index* ix, int option, double value) {
     PCC_ENTER(ix);
     int* pi = nullptr;
-    double* pd = option_slot(ix, option, &pi);
+    double* pd = option_slot(ix->opt, option, &pi);
     if (!pd && !pi) { set_error("unknown option %d", option); return PCC_ERR_INVALID; }
     if (!std::isfinite(value)) { set_error("option %d: non-finite value", option); return PCC_ERR_INVALID; }
-    bool ok = true;
-    switch (option) {
-        case PCC_OPT_GRID_PPC: ok = value > 0 && value <= 1024; break;
-        case PCC_OPT_GRID_TRIM: ok = value >= 0 && value <= 8; break;
-        case PCC_OPT_FAR_MODE: ok = value >= -1 && value <= 1; break;
-        case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: ok = value >= 0; break;
-        case PCC_OPT_NN1_KERNEL: ok = value >= 0 && value <= 3; break;
-        case PCC_OPT_EC_CELLS: ok = value >= 0 && value <= 2; break;
-        case PCC_OPT_KNN_CACHE_K: ok = value >= 0 && value <= 512; break;
-        case PCC_OPT_NN1_DENSE_MIN: ok = value >= 1 && value <= 1000000; break;
-        case PCC_OPT_FLANN_SPLIT: ok = value >= 0 && value <= 2; break;
-        default: ok = value == 0 || value == 1; break;
-    }
-    if (!ok) { set_error("option %d: value %g out of range", option, value); return PCC_ERR_INVALID; }
+    if (!option_in_range(option, value)) { set_error("option %d: value %g out of range", option, value); return PCC_ERR_INVALID; }
     if (pd) *pd = value; else *pi = (int)value;
     if (option == PCC_OPT_FLANN_SPLIT) ix->flann_valid = false;  // the replayed tree has to be rebuilt with the other rule
     return PCC_OK;
@@ -511,7 +517,7 @@ int pcc_index_get_option(pcc_index* ix, int option, double* value) {
     PCC_ENTER(ix);
     if (!value) { set_error("null value"); return PCC_ERR_INVALID; }
     int* pi = nullptr;
-    double* pd = option_slot(ix, option, &pi);
+    double* pd = option_slot(ix->opt, option, &pi);
     if (!pd && !pi) { set_error("unknown option %d", option); return PCC_ERR_INVALID; }
     *value = pd ? *pd : (double)*pi;
     return PCC_OK;

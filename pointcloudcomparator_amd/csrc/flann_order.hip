@@ -18,11 +18,16 @@ namespace pcc {
 // the tree walk then runs with every lane busy instead of one lane in ten.
 __device__ __forceinline__ void tie_append(bool tie, unsigned int i, unsigned int* __restrict__ list, unsigned int* __restrict__ counters,
                                            unsigned int shard_cap) {
+    // every lane of the wave must arrive here together (the callers do not return before it); the leader is still taken
+    // from the lanes that ARE here -- readfirstlane reads the first active lane -- so a caller that diverged would lose
+    // nothing: lane 0 need not be among them
     const unsigned long long m = __ballot(tie);
     if (m == 0ull) return;
     const unsigned int shard = blockIdx.x % PCC_TIE_SHARDS;
+    const unsigned int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned int leader = (unsigned int)__builtin_ctzll(__ballot(true));
     unsigned int base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(counters + shard * PCC_OPEN_CTR_STRIDE, (unsigned int)__popcll(m));
+    if (lane == leader) base = atomicAdd(counters + shard * PCC_OPEN_CTR_STRIDE, (unsigned int)__popcll(m));
     base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
     if (tie) list[shard * shard_cap + base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = i;
 }
@@ -35,15 +40,19 @@ k_tie_flags_grid(const float4* __restrict__ cell_refs, const unsigned int* __res
     const GridParams g = gd->g;
     const float4 qv = i < n ? q[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     const unsigned long long key = i < n ? keys[i] : ~0ull;
-    if (__float_as_int(qv.w) < 0 || key_none(key)) { tie_append(false, i, list, counters, shard_cap); return; }
+    // a non-finite query or one without a neighbour has no tie; it skips the scan but NOT the wave-wide append below
+    const bool valid = !(__float_as_int(qv.w) < 0 || key_none(key));
     const float bd = __uint_as_float((unsigned int)(key >> 32));
     const unsigned int bi = (unsigned int)key;
-    const float rb = sqrtf(bd) * 1.00001f + gd->slack;
-    int x0, x1, y0, y1, z0, z1;
-    cell_range(qv.x, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
-    cell_range(qv.y, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
-    cell_range(qv.z, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
-    bool tie = !(rb < __builtin_inff()) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 4096;
+    const float rb = valid ? sqrtf(bd) * 1.00001f + gd->slack : 0.f;
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+    bool tie = false;
+    if (valid) {
+        cell_range(qv.x, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
+        cell_range(qv.y, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
+        cell_range(qv.z, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
+        tie = !(rb < __builtin_inff()) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 4096;
+    }
     for (int z = z0; z <= z1 && !tie; ++z)
         for (int y = y0; y <= y1 && !tie; ++y) {
             const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
@@ -64,7 +73,7 @@ k_tie_flags_brute(const float4* __restrict__ refs, unsigned int m, const float4*
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float4 qv = i < n ? q[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     const unsigned long long key = i < n ? keys[i] : ~0ull;
-    if (__float_as_int(qv.w) < 0 || key_none(key)) { tie_append(false, i, list, counters, shard_cap); return; }
+    const bool valid = !(__float_as_int(qv.w) < 0 || key_none(key));  // (no early return: the append below is wave-wide)
     const float bd = __uint_as_float((unsigned int)(key >> 32));
     const unsigned int bi = (unsigned int)key;
     bool tie = false;
@@ -72,7 +81,7 @@ k_tie_flags_brute(const float4* __restrict__ refs, unsigned int m, const float4*
         const float4 r = refs[p];
         if (__float_as_int(r.w) >= 0 && p != bi && dist2(qv.x, qv.y, qv.z, r) == bd) tie = true;
     }
-    tie_append(tie, i, list, counters, shard_cap);
+    tie_append(tie && valid, i, list, counters, shard_cap);
 }
 
 // list: PCC_TIE_SHARDS slices of shard_cap entries; counters[shard * PCC_OPEN_CTR_STRIDE] = entries of the slice (pre-zeroed)
