@@ -148,11 +148,13 @@ enum pcc_option {
                                     takes its first bound from the own cell instead of the own row (default 4) */
     PCC_OPT_KNN_KERNEL = 12,     /* k-NN, k <= 512: 1 = selection by distance buckets, the merge network only for the queries it
                                     hands back (default); 0 = the merge network for every query */
-    PCC_OPT_KNN_CACHE_K = 13     /* 0 (default): off.  K > 0: the self k-NN rows behind pcc_normals / pcc_region_growing are searched
+    PCC_OPT_KNN_CACHE_K = 13,    /* 0 (default): off.  K > 0: the self k-NN rows behind pcc_normals / pcc_region_growing are searched
                                     with at least K neighbours and KEPT on the device until the next pcc_index_set_input; a later call
                                     that needs no more than the kept rows hold takes their prefix instead of searching again (the
                                     reference's default segmentation: normals with 50, then region growing with 100 neighbours of the
                                     same cloud -- one search instead of two).  Costs n x K x 8 bytes of device memory */
+    PCC_OPT_NN1_OPEN_FLAT = 14   /* flat k = 1 kernel, listed open lanes: 1 = their rows drained with lanes over candidates (default),
+                                    0 = one lane per listed query (round 3) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);
@@ -333,7 +335,8 @@ int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t st
  *  stats[0] queries resolved by the GRID engine, [1] queries sent to the BRUTE
  *  fallback, [2] reference points valid, [3] grid cells, [4] pair evaluations
  *  (GRID engine, when counting is compiled in; else 0), [5] queries flagged as tied and [6] indices changed by
- *  the FLANN walk (PCC_TIES_FLANN, last search). */
+ *  the FLANN walk (PCC_TIES_FLANN, last search), [7] queries the 3x3x3 cube of the pruned k = 1 kernel left open
+ *  (last search that listed them: from 2M queries on, or PCC_OPT_NN1_KERNEL = 2). */
 int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
 /* HIP-event timing of the library's own kernels, recorded on the index's stream
  * (events of another stream would not see them).  After enabling, every

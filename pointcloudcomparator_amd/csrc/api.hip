@@ -56,6 +56,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_NN1_DENSE_MIN: *as_int = &o.nn1_dense_min; return nullptr;
         case PCC_OPT_KNN_KERNEL: *as_int = &o.knn_kernel; return nullptr;
         case PCC_OPT_KNN_CACHE_K: *as_int = &o.knn_cache_k; return nullptr;
+        case PCC_OPT_NN1_OPEN_FLAT: *as_int = &o.nn1_open_flat; return nullptr;
         default: return nullptr;
     }
 }
@@ -68,7 +69,7 @@ void Options::from_env() {
         {"PCC_ICP_WARM", PCC_OPT_ICP_WARM}, {"PCC_ICP_DEVICE_LOOP", PCC_OPT_ICP_DEVICE_LOOP}, {"PCC_EC_CELLS", PCC_OPT_EC_CELLS},
         {"PCC_SORT_MP_MIN", PCC_OPT_SORT_MP_MIN}, {"PCC_SORT_MP_MIN_Q", PCC_OPT_SORT_MP_MIN_Q}, {"PCC_NN1_KERNEL", PCC_OPT_NN1_KERNEL},
         {"PCC_FLANN_SPLIT", PCC_OPT_FLANN_SPLIT}, {"PCC_NN1_DENSE_MIN", PCC_OPT_NN1_DENSE_MIN}, {"PCC_KNN_KERNEL", PCC_OPT_KNN_KERNEL},
-        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}};
+        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;
@@ -543,6 +544,14 @@ int pcc_index_stats(const pcc_index* cix, uint64_t stats[8]) {
             ix->ties_changed += h[sh * PCC_OPEN_CTR_STRIDE + 1];
         }
         ix->ties_pending = false;
+    }
+    if (ix->open_pending) {  // lanes the 3x3x3 cube left open in the last listed k = 1 search (sharded counters)
+        unsigned int h[PCC_OPEN_SHARDS * PCC_OPEN_CTR_STRIDE];
+        PCC_HIP(hipMemcpyAsync(h, ix->small.as<unsigned int>() + PCC_OPEN_CTR0, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        ix->stats[7] = 0;
+        for (int sh = 0; sh < PCC_OPEN_SHARDS; ++sh) ix->stats[7] += h[sh * PCC_OPEN_CTR_STRIDE];
+        ix->open_pending = false;
     }
     ix->stats[5] = ix->ties_flagged;
     ix->stats[6] = ix->ties_changed;

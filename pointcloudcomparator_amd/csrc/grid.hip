@@ -336,7 +336,7 @@ __device__ __forceinline__ unsigned long long scan_ball_outside(const float4* __
 // What phase 1 of k_grid_nn1 leaves open, for one query: `best` is its best key over the 3x3x3 cube (~0: empty).
 template <int U>
 __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
-                                           const GridParams& g, float slack, float qx, float qy, float qz, unsigned int qi,
+                                           const GridDev* __restrict__ gd, const GridParams& g, float slack, float qx, float qy, float qz, unsigned int qi,
                                            unsigned long long best, unsigned long long* __restrict__ out,
                                            unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count, bool ball,
                                            const float4* __restrict__ warm_refs) {
@@ -368,13 +368,11 @@ __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs,
     // lower-index) point could live in.  Usually one extra slab of cells on one or two sides,
     // far fewer rows than the next bigger cube.  Exact by construction: no bound test after it.
     if (!give_up) {
-        const float rb = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
-        int x0, x1, y0, y1, z0, z1;
-        cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
-        cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
-        cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
+        // (the ball cut down to what the cloud's bounding box leaves of it: grid_device.hpp)
+        const BallBox bb = ball_box(qx, qy, qz, __uint_as_float((unsigned int)(best >> 32)), gd, g, slack);
+        const int x0 = bb.x0, x1 = bb.x1, y0 = bb.y0, y1 = bb.y1, z0 = bb.z0, z1 = bb.z1;
         const int span = 2 * GRID_KMAX + 1;
-        if (!(rb < __builtin_inff()) || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
+        if (!bb.finite || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
             give_up = true;  // the ball is too big for a cell walk: exhaustive fallback
         } else {
             // the cube of half-width k around the query's cell is done (phase 1, or the last doubling)
@@ -523,7 +521,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         qx = oq.x; qy = oq.y; qz = oq.z;
         qi = __float_as_uint(oq.w);
         best = open_best[j];
-        nn1_finish<2>(cell_refs, cell_start, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk, warm_refs);
+        nn1_finish<2>(cell_refs, cell_start, gd, g, slack, qx, qy, qz, qi, best, out, fb_list, fb_count, ball_walk, warm_refs);
     }
 }
 
@@ -555,17 +553,19 @@ __device__ __forceinline__ void flat_sync() { wave_lds_sync(); }  // (lane_ops.h
 // the own cell, and the other two cells of the row cost 17 candidates per query).  Pass 1 takes everything else -- the
 // rest of the own row and the eight neighbour rows, each skipped or clipped against the bound exactly as in k_grid_nn1.
 constexpr int F2_R = 10;
-struct alignas(16) FlatWave2 {
+template <int SR>
+struct alignas(16) FlatWaveT {
     float4 q[64];                        // the wave's queries (x, y, z, bits of the best d2 when the pass began)
     unsigned long long best[64];         // running (d2 bits << 32 | index) per query
     unsigned int ends[FLAT_PLANES][64];  // span-end bits, transposed (k_grid_nn1_flat)
-    unsigned int span[F2_R * 64];        // non-empty spans in flat order: (first reference - flat offset + FLAT_CAP) << 6 | query slot
+    unsigned int span[SR * 64];          // non-empty spans in flat order: (first reference - flat offset + FLAT_CAP) << 6 | query slot
 };
+using FlatWave2 = FlatWaveT<F2_R>;
 static_assert(sizeof(FlatWave2) == 1024 + 512 + FLAT_PLANES * 256 + F2_R * 256, "LDS budget of k_grid_nn1_flat2");
 constexpr size_t F2_MAX_REFS = (1u << 26) - 2 * FLAT_CAP;  // the packed record holds 26 bits of reference position
 
-template <int R, int U, int B, bool LIVE>
-__device__ __forceinline__ void flat2_pass(FlatWave2& fw, const float4* __restrict__ cell_refs, const unsigned int (&s)[R],
+template <int R, int U, int B, bool LIVE, class FW>
+__device__ __forceinline__ void flat2_pass(FW& fw, const float4* __restrict__ cell_refs, const unsigned int (&s)[R],
                                            const unsigned int (&len)[R], float qx, float qy, float qz, unsigned int lane) {
     static_assert(B == 1 || B == 2 || B == 4 || B == 8, "a batch of windows never straddles a plane of 32");
     unsigned int tot = 0, cnt = 0;
@@ -803,7 +803,7 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
     const unsigned int n_open = open_count;
     for (unsigned int j = threadIdx.x; j < n_open; j += blockDim.x) {
         const float4 oq = open_q[j];
-        nn1_finish<2>(cell_refs, cell_start, g, slack, oq.x, oq.y, oq.z, __float_as_uint(oq.w), open_best[j], out, fb_list,
+        nn1_finish<2>(cell_refs, cell_start, gd, g, slack, oq.x, oq.y, oq.z, __float_as_uint(oq.w), open_best[j], out, fb_list,
                       fb_count, ball_walk, warm_refs);
     }
 }
@@ -824,8 +824,143 @@ k_nn1_open(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const unsigned int k = shard * shard_cap + j;
         const unsigned int qi = open_list[k];
         const float4 qv = q[qi];
-        nn1_finish<2>(cell_refs, cell_start, g, slack, qv.x, qv.y, qv.z, qi, open_keys[k], out, fb_list, fb_count, ball_walk,
+        nn1_finish<2>(cell_refs, cell_start, gd, g, slack, qv.x, qv.y, qv.z, qi, open_keys[k], out, fb_list, fb_count, ball_walk,
                       warm_refs);
+    }
+}
+
+// distance from coordinate v to the interval of cell c along one axis (0 inside), shrunk by slack
+// (the boundary cells are open-ended: they also hold the references that lie beyond the grid's box)
+__device__ __forceinline__ float axis_gap(float v, int c, int dim, float org, float h, float slack) {
+    const float lo = c == 0 ? -__builtin_inff() : org + c * h, hi = c == dim - 1 ? __builtin_inff() : org + (c + 1) * h;
+    return fmaxf(fmaxf(lo - v, v - hi) - slack, 0.f);
+}
+
+// The open lanes again, DRAINED FLAT (round 4).  k_nn1_open gives every listed query a lane that walks the box of its
+// ball row by row: two dependent round trips per row and a wave as slow as its widest box -- 26 of 64 lanes active, and in
+// the ICP configuration (2M x 2M) 150 us a pass against 91 us for the search proper.  Here the lanes only LAY OUT the
+// rows: the ball's rows are taken OR at a time (one z-layer of cells, OR rows of it), every lane clips its rows to the
+// chord of the ball of its CURRENT best distance (same gaps, slack and factors as scan_ball_outside) and the spans of all
+// 64 queries are drained with lanes over candidates by flat2_pass -- the bounds of a layer's rows in flight together, the
+// candidates coalesced, the bound shrinking from layer to layer.  Exact for the same reason the ball walk is: every cell
+// that can hold a reference at or below the best distance is looked at.  Queries without any bound (empty cube, no warm
+// start) or with a ball wider than the cell walk allows keep the lane walk (nn1_finish), which also feeds the far list.
+constexpr int OPEN_NY = 4, OPEN_NZ = 4, OPEN_R = OPEN_NY * OPEN_NZ;  // rows of one flat pass: a 4 x 4 window of the ball's box
+using FlatWaveOpen = FlatWaveT<OPEN_R>;
+template <int U, int B, int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_nn1_open_flat(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start, const GridDev* __restrict__ gd,
+                const float4* __restrict__ q, const unsigned int* __restrict__ open_list,
+                const unsigned long long* __restrict__ open_keys, const unsigned int* __restrict__ open_total,
+                unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count,
+                bool ball_walk, const float4* __restrict__ warm_refs, unsigned int shard_cap) {
+    const GridParams g = gd->g;
+    const float slack = gd->slack;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NW * sizeof(FlatWaveOpen)];
+    FlatWaveOpen& fw = reinterpret_cast<FlatWaveOpen*>(lds_raw)[threadIdx.x >> 6];
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int shard = blockIdx.x % PCC_OPEN_SHARDS, chunk = blockIdx.x / PCC_OPEN_SHARDS, nchunk = gridDim.x / PCC_OPEN_SHARDS;
+    const unsigned int cnt = open_total[shard * PCC_OPEN_CTR_STRIDE];
+    for (unsigned int j0 = chunk * blockDim.x; j0 < cnt; j0 += nchunk * blockDim.x) {  // (block-uniform)
+        const unsigned int j = j0 + threadIdx.x;
+        const bool valid = j < cnt;
+        const unsigned int k = shard * shard_cap + (valid ? j : 0u);
+        const unsigned int qi = valid ? open_list[k] : 0u;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long key = ~0ull;
+        if (valid) { qv = q[qi]; key = open_keys[k]; }
+        const float qx = qv.x, qy = qv.y, qz = qv.z;
+        if (valid && warm_refs && key == ~0ull) {  // (ICP passes after the first: the previous neighbour bounds the ball)
+            const unsigned long long pk = out[qi];
+            if (pk != ~0ull) key = fold(key, qx, qy, qz, warm_refs[(unsigned int)pk]);
+        }
+        int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+        float ex2 = 0.f;
+        bool flat = valid && key != ~0ull;
+        if (flat) {
+            const BallBox bb = ball_box(qx, qy, qz, __uint_as_float((unsigned int)(key >> 32)), gd, g, slack);
+            x0 = bb.x0; x1 = bb.x1; y0 = bb.y0; y1 = bb.y1; z0 = bb.z0; z1 = bb.z1;
+            ex2 = bb.ex2;
+            const int span = 2 * GRID_KMAX + 1;  // (beyond it the lane walk hands the query to the far list)
+            flat = bb.finite && x1 - x0 < span && y1 - y0 < span && z1 - z0 < span;
+        }
+        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+        const bool cube_done = true;  // (every listed query comes from k_grid_nn1_flat2, which has scanned the cube around its cell)
+        const int ny = flat ? y1 - y0 + 1 : 0, nz = flat ? z1 - z0 + 1 : 0;
+        const int max_ny = __builtin_amdgcn_readlane((int)wave_incl_scan_max((unsigned int)ny), 63);
+        const int max_nz = __builtin_amdgcn_readlane((int)wave_incl_scan_max((unsigned int)nz), 63);
+        fw.q[lane] = make_float4(qx, qy, qz, 0.f);
+        fw.best[lane] = key;
+        flat_sync();
+        // One pass takes a 4 x 4 window of rows -- the whole box of a ball up to two cells in radius, i.e. of nearly every
+        // open query of an aligned cloud -- so that a wave's chain is two round trips (bounds, candidates) whatever the ball:
+        // with one z-layer per pass the kernel waited for ten (4.8 waves per SIMD, the VALUs 27 % busy: 152 us at 10M x 10M
+        // against 103 us for the lane walk).  Wider boxes take further windows.
+        for (int zb = 0; zb < max_nz; zb += OPEN_NZ) {  // wave-uniform loops
+            for (int yb = 0; yb < max_ny; yb += OPEN_NY) {
+                const float bd = __uint_as_float(reinterpret_cast<const unsigned int*>(&fw.best[lane])[1]);
+                float gy2[OPEN_NY], gz2[OPEN_NZ];
+#pragma unroll
+                for (int a = 0; a < OPEN_NY; ++a) {
+                    const float gy = axis_gap(qy, min(y0 + yb + a, g.dim[1] - 1), g.dim[1], g.org[1], g.h, slack);
+                    gy2[a] = yb + a < ny ? gy * gy : __builtin_inff();  // (+inf: a row the lane does not have)
+                }
+#pragma unroll
+                for (int a = 0; a < OPEN_NZ; ++a) {
+                    const float gz = axis_gap(qz, min(z0 + zb + a, g.dim[2] - 1), g.dim[2], g.org[2], g.h, slack);
+                    gz2[a] = zb + a < nz ? gz * gz : __builtin_inff();
+                }
+                bool iny[OPEN_NY], inz[OPEN_NZ];  // the row runs through the cube around the query's cell
+#pragma unroll
+                for (int a = 0; a < OPEN_NY; ++a) iny[a] = cube_done && abs(y0 + yb + a - cy) <= 1;
+#pragma unroll
+                for (int a = 0; a < OPEN_NZ; ++a) inz[a] = abs(z0 + zb + a - cz) <= 1;
+                unsigned int sp[OPEN_R], ln[OPEN_R], ea[OPEN_R];
+                int xa[OPEN_R], xb[OPEN_R];
+                bool ok[OPEN_R];
+#pragma unroll
+                for (int r = 0; r < OPEN_R; ++r) {
+                    const float rem = bd - (gy2[r % OPEN_NY] + gz2[r / OPEN_NY]) * 0.9999f;
+                    // (else every reference of the row is strictly farther than the best: the chord does not reach the
+                    // cloud's bounding box, let alone the row; -inf for rows the lane does not have)
+                    ok[r] = rem >= ex2;
+                    cell_range(qx, __builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa[r], xb[r]);
+                    xa[r] = max(xa[r], x0);
+                    xb[r] = min(xb[r], x1);
+                    // a row through the 3x3x3 cube the search kernel has dealt with (what it skipped there was farther than its
+                    // best of that moment, hence than today's): only what sticks out of the cube on ONE side -- the usual open
+                    // query's ball leaves the cube through one face, its cap is a handful of cells; a chord that sticks out on
+                    // both sides (a ball of more than 1.5 cells) is taken whole
+                    if (iny[r % OPEN_NY] && inz[r / OPEN_NY]) {
+                        const bool left = xa[r] < cx - 1, right = xb[r] > cx + 1;
+                        if (left && !right) xb[r] = cx - 2;
+                        if (right && !left) xa[r] = cx + 2;
+                        ok[r] = ok[r] && (left || right);
+                    }
+                    ok[r] = ok[r] && xa[r] <= xb[r];
+                }
+#pragma unroll
+                for (int r = 0; r < OPEN_R; ++r) {  // (the loads alone inside their predicate: all of them in flight together)
+                    sp[r] = 0u;
+                    ea[r] = 0u;
+                    if (ok[r]) {
+                        const unsigned int row = ((unsigned int)(z0 + zb + r / OPEN_NY) * g.dim[1] + (unsigned int)(y0 + yb + r % OPEN_NY)) * g.dim[0];
+                        sp[r] = cell_start[row + xa[r]];
+                        ea[r] = cell_start[row + xb[r] + 1];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < OPEN_R; ++r) ln[r] = ea[r] - sp[r];
+                flat2_pass<OPEN_R, U, B, true>(fw, cell_refs, sp, ln, qx, qy, qz, lane);
+            }
+        }
+        if (flat) out[qi] = fw.best[lane];
+        else if (valid)
+            nn1_finish<2>(cell_refs, cell_start, gd, g, slack, qx, qy, qz, qi, key == ~0ull ? open_keys[k] : key, out, fb_list, fb_count,
+                          ball_walk, warm_refs);
+        flat_sync();  // (the next chunk overwrites the wave's block)
     }
 }
 
@@ -838,12 +973,6 @@ k_nn1_open(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
 //   2. k_grid_far: walk the cells the ball of that radius touches, pruning whole rows by their
 //      y/z distance and clipping every row's x-range to the chord of the (shrinking) ball
 //   3. only if the ball spans more than FAR_SPAN cells per axis: the exhaustive kernel
-// distance from coordinate v to the interval of cell c along one axis (0 inside), shrunk by slack
-// (the boundary cells are open-ended: they also hold the references that lie beyond the grid's box)
-__device__ __forceinline__ float axis_gap(float v, int c, int dim, float org, float h, float slack) {
-    const float lo = c == 0 ? -__builtin_inff() : org + c * h, hi = c == dim - 1 ? __builtin_inff() : org + (c + 1) * h;
-    return fmaxf(fmaxf(lo - v, v - hi) - slack, 0.f);
-}
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -877,6 +1006,8 @@ k_grid_far(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const float qx = qv.x, qy = qv.y, qz = qv.z;
         unsigned long long best = out[qi];  // from the seed scan: a real point, hence a valid upper bound
         bool exhaustive = best == ~0ull;
+        const float exg = fmaxf(fmaxf(gd->lo[0] - qx, qx - gd->hi[0]) - slack, 0.f);  // gap to the cloud's bounding box along x
+        const float ex2 = exg * exg * 0.9999f;
         const float rb0 = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
         if (!exhaustive && !(rb0 * g.inv_h < (float)FAR_SPAN)) exhaustive = true;  // ball too large for a cell walk
         if (!exhaustive) {
@@ -902,7 +1033,8 @@ k_grid_far(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
                     const float gy = axis_gap(qy, y, g.dim[1], g.org[1], g.h, slack), gz = axis_gap(qz, z, g.dim[2], g.org[2], g.h, slack);
                     const float lbd = __uint_as_float((unsigned int)(best >> 32));
                     const float rem = lbd * 1.00002f - (gz * gz + gy * gy);
-                    if (!(rem > 0.f)) continue;  // the whole row is at least as far as the current best
+                    // the whole row is at least as far as the current best -- or its chord ends short of the cloud's bounding box
+                    if (!(rem > 0.f) || rem < ex2) continue;
                     int rx0, rx1;
                     cell_range(qx, sqrtf(rem) + slack, g.org[0], g.inv_h, g.dim[0], rx0, rx1);
                     const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
@@ -989,14 +1121,21 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
         }
 #define PCC_F2_ARGS ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, \
                                fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr, dm, open_list, open_keys, open_total
+        ix->open_pending = listed;
+        if (!listed) ix->stats[7] = 0;
         if (listed) {
             hipLaunchKernelGGL((k_grid_nn1_flat2<4, 4, 2, true>), dim3(f2_grid), dim3(f2_bs), 0, s, PCC_F2_ARGS);
             // (chunks per shard: enough blocks for every listed query to have a lane at once, at most 64)
             unsigned int chunks = (shard_cap / 4 + 255) / 256;
             chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-            hipLaunchKernelGGL(k_nn1_open, dim3(chunks * PCC_OPEN_SHARDS), dim3(256), 0, s, ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(),
-                               ix->d_grid.as<GridDev>(), q, open_list, open_keys, open_total, out, fb_list, fb_count, ball_walk,
-                               warm ? ix->refs.as<float4>() : nullptr, shard_cap);
+            if (ix->opt.nn1_open_flat)
+                hipLaunchKernelGGL((k_nn1_open_flat<4, 4, 2>), dim3(chunks * 2 * PCC_OPEN_SHARDS), dim3(128), 0, s, ix->cell_refs.as<float4>(),
+                                   ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, open_list, open_keys, open_total, out, fb_list,
+                                   fb_count, ball_walk, warm ? ix->refs.as<float4>() : nullptr, shard_cap);
+            else
+                hipLaunchKernelGGL(k_nn1_open, dim3(chunks * PCC_OPEN_SHARDS), dim3(256), 0, s, ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(),
+                                   ix->d_grid.as<GridDev>(), q, open_list, open_keys, open_total, out, fb_list, fb_count, ball_walk,
+                                   warm ? ix->refs.as<float4>() : nullptr, shard_cap);
         } else {
             hipLaunchKernelGGL((k_grid_nn1_flat2<4, 4, 2, false>), dim3(f2_grid), dim3(f2_bs), 0, s, PCC_F2_ARGS);
         }

@@ -69,4 +69,35 @@ __device__ __forceinline__ void cell_range(float v, float r, float org, float in
     c1 = cell_coord(v + r, org, inv_h, dim);
 }
 
+
+// The cells a ball of squared radius bd around q can share with a REFERENCE: every reference lies inside the true
+// bounding box [lo, hi] of the indexed cloud, so along one axis the ball only matters within
+// sqrt(bd - (gap to the box along the other two axes)^2) of q.  For a query inside the box this is the plain ball; for
+// one outside it (an ICP source that is still misaligned, 5 % of the C4 cloud for dozens of passes) the box of cells
+// shrinks from (2 d / h)^3 to the few cells of the cap the ball cuts out of the cloud.  Gaps shrunk by the slack and
+// 1e-4 relative, the radius stretched by 1e-5 and the slack: conservative like every other bound here.
+struct BallBox {
+    int x0, x1, y0, y1, z0, z1;
+    float ex2, ey2, ez2;  // squared (shrunk) gaps from q to the cloud's bounding box, per axis
+    bool finite;          // false: the ball is unbounded (no best yet, or an overflowed distance)
+};
+__device__ __forceinline__ BallBox ball_box(float qx, float qy, float qz, float bd, const GridDev* __restrict__ gd, const GridParams& g,
+                                            float slack) {
+    BallBox b;
+    const float ex = fmaxf(fmaxf(gd->lo[0] - qx, qx - gd->hi[0]) - slack, 0.f);
+    const float ey = fmaxf(fmaxf(gd->lo[1] - qy, qy - gd->hi[1]) - slack, 0.f);
+    const float ez = fmaxf(fmaxf(gd->lo[2] - qz, qz - gd->hi[2]) - slack, 0.f);
+    b.ex2 = ex * ex * 0.9999f;
+    b.ey2 = ey * ey * 0.9999f;
+    b.ez2 = ez * ez * 0.9999f;
+    const float rx = sqrtf(fmaxf(bd - (b.ey2 + b.ez2), 0.f)) * 1.00001f + slack;
+    const float ry = sqrtf(fmaxf(bd - (b.ex2 + b.ez2), 0.f)) * 1.00001f + slack;
+    const float rz = sqrtf(fmaxf(bd - (b.ex2 + b.ey2), 0.f)) * 1.00001f + slack;
+    b.finite = bd < __builtin_inff();  // (false for NaN too)
+    cell_range(qx, rx, g.org[0], g.inv_h, g.dim[0], b.x0, b.x1);
+    cell_range(qy, ry, g.org[1], g.inv_h, g.dim[1], b.y0, b.y1);
+    cell_range(qz, rz, g.org[2], g.inv_h, g.dim[2], b.z0, b.z1);
+    return b;
+}
+
 }  // namespace pcc

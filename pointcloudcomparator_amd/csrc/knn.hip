@@ -173,9 +173,10 @@ __device__ __forceinline__ void knn_emit(const KnnOut& o, size_t p, unsigned lon
 }
 // rows of non-finite queries (flagged w < 0 by the pack; the searches never see them): "nothing found" throughout
 __global__ void __launch_bounds__(256)
-k_knn_fill_invalid(const float4* __restrict__ q, unsigned int nq, int K, KnnOut out) {
+k_knn_fill_invalid(const float4* __restrict__ q, unsigned int nq, int K, KnnOut out, const GridDev* __restrict__ gd) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq || __float_as_int(q[i].w) >= 0) return;
+    // (an index without a finite point -- the API refuses it earlier -- would make the wave kernels leave at once: every row then)
+    if (i >= nq || (__float_as_int(q[i].w) >= 0 && gd->n_valid != 0u)) return;
     for (int e = 0; e < K; ++e) knn_emit(out, (size_t)i * K + e, ~0ull);
 }
 
@@ -790,7 +791,7 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
         PCC_HIP(hipMemsetAsync(keys, 0xff, nq * (size_t)K * sizeof(unsigned long long), s));
     } else {
         // (the wave kernels write every entry of every valid query's row; only the rows of non-finite queries are left)
-        hipLaunchKernelGGL(k_knn_fill_invalid, dim3((n + 255) / 256), dim3(256), 0, s, q, n, K, out);
+        hipLaunchKernelGGL(k_knn_fill_invalid, dim3((n + 255) / 256), dim3(256), 0, s, q, n, K, out, ix->d_grid.as<GridDev>());
         PCC_HIP(hipGetLastError());
     }
     unsigned int *order = nullptr, *n_sorted = nullptr;
@@ -1040,7 +1041,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
     // FUSED (idx_out / d2_out given): a row of up to ROW_LDS_MAX neighbours never leaves the chip between the search and
     // the caller's arrays -- its hits gather in LDS, are sorted in registers (PCL's sorted results) and go out as index
     // and squared distance in two coalesced stores.  Before: keys to memory (8 B), sorted in place by a second kernel
-    // (16 B), unpacked by a third (16 B).  Longer rows keep that route (k_finish_long_rows).
+    // (16 B), unpacked by a third (16 B).  Longer rows keep that route (k_sort_rows).
     // per wave: the row tables of the search (dead once the last window is through) double as the bucket sort's second
     // buffer, and its 130 counters sit in the upper half of the stage (rows it sorts fill at most the lower half)
     struct alignas(8) Tables { unsigned int tab_s[RAD_ROWCAP + 1], tab_o[RAD_ROWCAP + 1], win[64], endb[4][64]; };
@@ -1210,7 +1211,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                         const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
                         if (!COUNT && hit) {
                             if (in_lds) { if (slot < ROW_LDS_MAX) stage[slot] = key; }
-                            else keys[row_beg + slot] = key;
+                            else if (slot < row_len) keys[row_beg + slot] = key;
                         }
                         written += (unsigned int)__popcll(mask);
                     }
@@ -1242,10 +1243,14 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 const unsigned long long mask = __ballot(hit);
                 // (a fill can only find what the count found -- same arithmetic --; the bound is belt and braces)
                 const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
-                if (!COUNT && hit && (!in_lds || slot < ROW_LDS_MAX)) row_out[slot] = key;
+                if (!COUNT && hit && slot < (in_lds ? ROW_LDS_MAX : row_len)) row_out[slot] = key;
                 written += (unsigned int)__popcll(mask);
             }
         }
+        // a row left as keys in memory (beyond the LDS stage) whose offsets promise more than the ball holds: the
+        // rest reads "nothing found" (no memset of the key array precedes a fused fill).  No trip with exact offsets.
+        if (!COUNT && !in_lds)
+            for (unsigned int e = written + lane; e < row_len; e += 64) keys[row_beg + e] = ~0ull;
         if (in_lds) {
             wave_lds_sync();
             const unsigned int have = written < row_len ? written : row_len;

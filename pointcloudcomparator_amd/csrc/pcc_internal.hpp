@@ -100,6 +100,7 @@ struct Options {
     int knn_cache_k = 0;            // PCC_OPT_KNN_CACHE_K: self k-NN rows searched with at least this K and kept (0: off)
     int knn_kernel = 1;             // PCC_OPT_KNN_KERNEL: 1 selection kernel for k <= 128, 0 merge network only
     int nn1_dense_min = 4;          // PCC_OPT_NN1_DENSE_MIN: references per own cell from which a wave starts with the own cell alone
+    int nn1_open_flat = 1;          // PCC_OPT_NN1_OPEN_FLAT: the listed open lanes drained flat (k_nn1_open_flat); 0 = one lane per query
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     void from_env();
 };
@@ -161,6 +162,7 @@ struct pcc_index {
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
     pcc::DevBuf knn_fb;  // a list of up to n indices + its count, one user at a time: queries the k-NN selection kernel hands back,
                          // rows a fused radius fill leaves to k_sort_rows, region growing's points with a cross edge
+    bool open_pending = false;                    // the open-lane counters of the last listed k = 1 search are still on the device
     bool ties_pending = false;                    // the tie counters of the last search are still on the device
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs

@@ -272,3 +272,31 @@ def test_overflowed_distances_are_no_neighbours(gpu, engine):
         _, _, sums = ix.icp_step(q)
         assert sums[16] == 300          # only the near points have a correspondence
 
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_ties_flann_with_non_finite_queries_at_wave_leaders(gpu, engine):
+    """a lattice cloud (every query tied) with NaN / inf queries exactly where a wave's lane 0 sits (indices 0, 64, 128...):
+    the tie list is appended once per wave by a leader lane, which must be taken from the lanes that carry a tie -- not
+    lane 0, which has none here (round-3 advisor finding).  Indices = the kd-tree walk's, counters = the tied queries."""
+    g = np.arange(12, dtype=np.float32) * np.float32(0.25)
+    ref = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rng = np.random.default_rng(11)
+    cells = rng.integers(0, 11, (1024, 3)).astype(np.float32) * np.float32(0.25)
+    q = (cells + np.float32(0.125)).astype(np.float32)          # cell centres: eight references at the same distance
+    bad = np.arange(0, 1024, 64)
+    q[bad[0::2], 0] = np.nan
+    q[bad[1::2], 2] = np.inf
+    good = np.ones(len(q), bool)
+    good[bad] = False
+    fi, fd = oracle.KdTree(ref).nn1_batch(q[good])
+    li, _ = oracle.nn1_exhaustive(ref, q[good])
+    assert (fi != li).any()                                       # FLANN's order differs from lowest-index somewhere
+    with capi.Index(ref, engine=engine) as ix:
+        ix.set_tie_order(capi.TIES_FLANN)
+        idx, d2 = ix.nn1(q)
+        st = ix.stats()
+    assert (idx[bad] == -1).all() and np.isinf(d2[bad]).all()
+    assert (_bits(d2[good]) == _bits(fd)).all()
+    assert (idx[good] == fi).all(), np.nonzero(idx[good] != fi)[0][:8]
+    assert st[5] == good.sum() and st[6] == (fi != li).sum(), (st[5], st[6], good.sum(), (fi != li).sum())

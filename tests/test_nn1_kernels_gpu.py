@@ -46,13 +46,16 @@ def _scenes():
     return out
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 12])
 def test_nn1_kernel_forms_match_the_oracle(gpu, mode):
+    """(12: form 2 with the listed open lanes finished one lane per query -- PCC_OPT_NN1_OPEN_FLAT = 0, round 3's kernel)"""
+    open_flat, mode = (0, 2) if mode == 12 else (1, mode)
     for name, ref, qry in _scenes():
         oi, od = oracle.nn1_exhaustive(ref, qry)
         with capi.Index(ref, engine=capi.ENGINE_GRID) as ix:
             ix.set_option(capi.OPT_NN1_KERNEL, mode)
-            assert ix.get_option(capi.OPT_NN1_KERNEL) == mode
+            ix.set_option(capi.OPT_NN1_OPEN_FLAT, open_flat)
+            assert ix.get_option(capi.OPT_NN1_KERNEL) == mode and ix.get_option(capi.OPT_NN1_OPEN_FLAT) == open_flat
             for _ in range(2):  # (the second call takes the far route where the first had fallbacks)
                 idx, d2 = ix.nn1(qry)
                 assert (_bits(d2) == _bits(od)).all(), (name, mode, np.nonzero(_bits(d2) != _bits(od))[0][:5])
