@@ -11,9 +11,18 @@ LIBDIR     := pointcloudcomparator_amd/lib
 HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/normals.hip $(CSRC)/region.hip $(CSRC)/sac.hip $(CSRC)/flann_order.hip $(CSRC)/cellsort_mp.hip)
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 
-all: lib oracle hosttest cli
+all: lib oracle hosttest cli prof
 
 lib: $(LIBDIR)/libpcc_nn.so
+# the profiling build: same sources with the pair counter compiled in (pcc_index_stats[4]); never the timed library
+prof: $(LIBDIR)/libpcc_nn_prof.so
+PROF_OBJS  := $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(HIP_SRCS))
+build/prof/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
+	@mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DPCC_COUNT_PAIRS $(EXTRA_HIPFLAGS) -c $< -o $@
+$(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(PROF_OBJS)
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu build/ubench_gather
 hosttest: build/test_host_mirror build/test_lane_ops build/test_report
@@ -81,4 +90,4 @@ build/asan/test_flann_tree: tests/cpp/test_flann_tree.cpp $(CSRC)/flann_tree.hpp
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/_build
 
-.PHONY: all lib oracle ubench hosttest cli clean asan
+.PHONY: all lib prof oracle ubench hosttest cli clean asan

@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-exhaustive", action="store_true", help="skip the exhaustive-kernel leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations of the default run")
+    ap.add_argument("--no-pairs", action="store_true", help="skip the pair count by the profiling build (roofline then carries the HBM figure only)")
     return ap.parse_args()
 
 
@@ -94,6 +95,39 @@ def launch_ranks(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def count_pairs(cfgs):
+    """distances evaluated per call, counted by the PROFILING build of the library (libpcc_nn_prof.so, pcc_index_stats[4])
+    in a child process -- the timed library carries no counter.  {} when the profiling build is missing or fails."""
+    prof = ROOT / "pointcloudcomparator_amd" / "lib" / "libpcc_nn_prof.so"
+    if not prof.exists() or not cfgs:
+        return {}
+    env = dict(os.environ)
+    env["PCC_LIB"] = str(prof)
+    try:
+        p = subprocess.run([sys.executable, str(ROOT / "tools" / "count_pairs.py")] + list(cfgs), env=env, capture_output=True,
+                           text=True, timeout=300)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if p.returncode == 0 and line else {}
+    except Exception:
+        return {}
+
+
+def load_nn1_counters(label):
+    """derived PMC metrics of the k = 1 kernels from the committed profiles/*_nn1_counters.json (VALU busy share, lanes per
+    instruction ...): what the counters say bounds the kernel"""
+    for f in sorted((ROOT / "profiles").glob("*nn1_counters.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text()).get(label, {}).get("derived")
+        except Exception:
+            d = None
+        if d:
+            return {"source": "profiles/" + f.name, "valu_busy_fraction": next((v for k, v in d.items() if k.startswith("valu_busy")), None),
+                    "active_lanes_per_valu_instruction": d.get("active_lanes_per_valu_instruction"),
+                    "valu_instructions_per_wave": d.get("valu_instructions_per_wave"),
+                    "wave_time_waiting_fraction": next((v for k, v in d.items() if k.startswith("wave_time_waiting")), None)}
+    return None
 
 
 def source_digest() -> str:
@@ -163,6 +197,7 @@ def main():
     bcast_name = "RCCL" if backend == "nccl" else backend
     engine = {"auto": capi.ENGINE_AUTO, "grid": capi.ENGINE_GRID, "brute": capi.ENGINE_BRUTE}[args.engine]
     K, W = args.steps, args.warmup
+    pairs = {}
 
     def make_cloud(n, seed, floats, start=0, chunk=4_000_000):
         parts = [synth.corridor_cloud(min(chunk, n - o), seed, start=start + o) for o in range(0, n, chunk)]
@@ -265,20 +300,34 @@ def main():
             r["per_rank_ms_per_step"] = per_rank_ms
         # ---- roofline of the dominant kernel of the measured path -----------------------------------------
         if engine_name == "grid":
-            # the pruned search (k_grid_nn1_flat2, plus k_nn1_open for the lanes its cube leaves open from 2M queries on;
-            # both inside the event bracket): every reference point (16 B packed) has to be read at least once, every
-            # query read once (16 B packed + 4 B order) and its result written (8 B)
-            alg = 16.0 * M + 28.0 * N
+            # the pruned search (k_grid_nn1_flat2, plus k_nn1_open_flat for the lanes its cube leaves open from 2M queries on;
+            # both inside the event bracket).  SURVEY.md 8d, k = 1 pruned: every reference and every query read once at 12 B,
+            # 8 B of result per query.  What binds the kernel is not that stream but the instructions it issues; the pair
+            # arithmetic among them is priced against the non-FMA fp32 roof from the profiling build's pair count
+            alg = 12.0 * (M + N) + 8.0 * N
             ach = alg / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else 0.0
             t_main, stale = load_pmc_traffic("k_grid_nn1_flat2", cfg)
             t_open, _ = load_pmc_traffic("k_nn1_open", cfg)
             traffic = None if t_main is None else t_main + (t_open or 0.0)
-            r["roofline"] = {"kernel": "k_grid_nn1_flat2 (+ k_nn1_open)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale,
-                             "kernel_ms": tm[0], "algorithmic_bytes": alg,
-                             "note": "pruned exact search, rows drained with lanes over candidates: latency / VALU-issue bound "
-                                     "(profiles/r03_nn1_counters.json, DESIGN.md 4.2); compulsory HBM bytes are a few % of the roof "
-                                     "by construction, the traffic above them is neighbouring rows re-read through the caches"}
+            pk = pairs.get(cfg if n_per_rank is None or cfg != "c5" else ("c5" if N == C5_TOTAL_QUERIES else "c5_shard"))
+            hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg,
+                   "bytes_per_unit": "12 B per reference + 12 B per query read, 8 B per query written (SURVEY.md 8d)"}
+            r["roofline"] = {"kernel": "k_grid_nn1_flat2 (+ k_nn1_open_flat)", "kernel_ms": tm[0], "traffic": traffic, "traffic_stale": stale,
+                             "hbm": hbm, "counters": load_nn1_counters("c3_flat2" if M >= 5_000_000 else "c2_flat2")}
+            if pk and tm[0] > 0 and pk.get("queries") == N and pk.get("references") == M:
+                pps = pk["pairs_per_call"] / (tm[0] * 1e-3)
+                top = pps * OPS_PER_PAIR / 1e12
+                r["roofline"].update({"bound": "valu", "achieved": top, "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s",
+                                      "frac": top / VALU_NOFMA_PEAK_TOPS, "pairs_per_launch": pk["pairs_per_call"],
+                                      "pairs_per_query": pk["pairs_per_call"] / float(N), "pairs_per_s": pps, "ops_per_pair": OPS_PER_PAIR,
+                                      "valu_fraction": top / VALU_NOFMA_PEAK_TOPS, "hbm_fraction": hbm["frac"]})
+                r["roofline"]["note"] = ("pruned exact search: VALU-issue / latency bound (see counters: the VALUs are busy most of the "
+                                         "time, the pair arithmetic -- 9 operations x pairs_per_launch, counted by libpcc_nn_prof.so -- is "
+                                         "a small share of what they issue; the rest is per-(query, row) set-up, DESIGN.md 4.2).  "
+                                         "The HBM figure on SURVEY 8d's bytes is beside it under `hbm`")
+            else:  # no profiling build at hand: the schema's HBM form
+                r["roofline"].update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                      "note": "pair count unavailable (libpcc_nn_prof.so missing): HBM figure only"})
         else:
             ach = float(M) * N * OPS_PER_PAIR / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else 0.0
             traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
@@ -298,13 +347,13 @@ def main():
             dtb = timed(ix, lambda: ix.nn1(qry, idx_b, d2_b), kb)
             tb = ix.timing()
             ix.enable_timing(0)
-            pairs = float(M) * N
-            ach = pairs * OPS_PER_PAIR / (tb[0] * 1e-3) / 1e12
+            n_pairs = float(M) * N
+            ach = n_pairs * OPS_PER_PAIR / (tb[0] * 1e-3) / 1e12
             same = bool((idx_b == idx).all().item() and (d2_b.view(torch.int32) == d2.view(torch.int32)).all().item())
             traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
             r["exhaustive"] = {
                 "kernel": "k_nn1_brute", "value": N / (dtb / kb), "unit": "queries/s", "ms_per_pass": dtb / kb * 1e3,
-                "pairs_per_sec": pairs / (tb[0] * 1e-3),
+                "pairs_per_sec": n_pairs / (tb[0] * 1e-3),
                 "roofline": {"bound": "valu", "achieved": ach, "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s",
                              "frac": ach / VALU_NOFMA_PEAK_TOPS, "kernel_ms": tb[0], "traffic": traffic,
                              "traffic_stale": stale, "ops_per_pair": OPS_PER_PAIR},
@@ -435,7 +484,17 @@ def main():
         ix.enable_timing(0)
         ix.close()
         passes = iters + 1  # + getFitnessScore
-        return {"workload": f"{desc}: pcc_icp_align(max_iter={iters}, fixed=1) = {iters} x (NN of every source point + "
+        pk = pairs.get("c4") if iters == 50 else None
+        roof = None
+        if pk:  # the NN kernels of all passes against the non-FMA fp32 roof, and the 8d bytes of a pass against the HBM roof
+            nn_s = tm[0] * 1e-3 * passes
+            top = pk["pairs_per_call"] * OPS_PER_PAIR / nn_s / 1e12 if nn_s > 0 else 0.0
+            alg = passes * (12.0 * (M + N) + 8.0 * N + 24.0 * N)  # NN as k = 1 + transform 12 B read + 12 B write per source point
+            roof = {"bound": "valu", "achieved": top, "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s", "frac": top / VALU_NOFMA_PEAK_TOPS,
+                    "pairs_per_call": pk["pairs_per_call"], "pairs_per_pass": pk["pairs_per_call"] / passes,
+                    "hbm": {"algorithmic_bytes": alg, "achieved": alg / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / best / 1e9 / HBM_PEAK_GBS}}
+        return {"roofline": roof,"workload": f"{desc}: pcc_icp_align(max_iter={iters}, fixed=1) = {iters} x (NN of every source point + "
                             "Umeyama sums + transform) + the fitness pass, source resident in HBM",
                 "ms": best * 1e3, "iterations": int(it), "converged": bool(conv), "fitness": fit,
                 "ms_per_pass": best * 1e3 / passes, "nn_queries_per_sec": N * passes / best,
@@ -443,6 +502,13 @@ def main():
                                       "sums_reduce_transform": max(tm[2] - tm[0] - tm[1], 0.0)}}
 
     primary_cfg = "c3" if args.config == "auto" else args.config
+    # pair counts of the workloads this run measures (profiling build, child process, before any timing)
+    want = []
+    if rank == 0 and not args.no_pairs:
+        want = [primary_cfg if primary_cfg != "c5" or n_gpus == 1 else "c5_shard"] if primary_cfg != "c1" else []
+        if args.config == "auto" and not args.no_extra and n_gpus == 1:
+            want += ["c2", "c4", "c5_shard", "c5"]
+    pairs.update(count_pairs([c for c in dict.fromkeys(want) if c in ("c2", "c3", "c4", "c5", "c5_shard")]))
     if primary_cfg == "c4":
         prim = None
         icp = run_icp()

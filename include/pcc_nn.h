@@ -333,11 +333,14 @@ int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t st
 /* ---- instrumentation ------------------------------------------------------------------
  * counters of the last search on this index (host):
  *  stats[0] queries resolved by the GRID engine, [1] queries sent to the BRUTE
- *  fallback, [2] reference points valid, [3] grid cells, [4] pair evaluations
- *  (GRID engine, when counting is compiled in; else 0), [5] queries flagged as tied and [6] indices changed by
+ *  fallback, [2] reference points valid, [3] grid cells, [4] distances evaluated by the pruned kernels (k = 1, k-NN,
+ *  radius, clustering, tie flags) since the previous pcc_index_stats call, process-wide -- counted by the PROFILING build
+ *  only (libpcc_nn_prof.so, `make prof`; pcc_counts_pairs() == 1), 0 in libpcc_nn.so, [5] queries flagged as tied and [6] indices changed by
  *  the FLANN walk (PCC_TIES_FLANN, last search), [7] queries the 3x3x3 cube of the pruned k = 1 kernel left open
  *  (last search that listed them: from 2M queries on, or PCC_OPT_NN1_KERNEL = 2). */
 int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
+/* 1 when this library was built with the pair counter (-DPCC_COUNT_PAIRS: the profiling build), else 0 */
+int pcc_counts_pairs(void);
 /* HIP-event timing of the library's own kernels, recorded on the index's stream
  * (events of another stream would not see them).  After enabling, every
  * set_input / search records events into a 64-call ring without synchronising;

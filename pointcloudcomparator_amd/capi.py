@@ -35,7 +35,7 @@ SYMBOLS = [
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
     "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
-    "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices",
+    "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices", "pcc_counts_pairs",
 ]
 
 

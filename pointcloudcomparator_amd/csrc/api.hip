@@ -14,6 +14,13 @@
 
 namespace pcc {
 
+#ifdef PCC_COUNT_PAIRS
+unsigned long long pairs_take_grid();
+unsigned long long pairs_take_knn();
+unsigned long long pairs_take_cluster();
+unsigned long long pairs_take_flann();
+#endif
+
 static thread_local std::string g_err;
 void set_error(const char* fmt, ...) {
     char buf[512];
@@ -523,11 +530,23 @@ int pcc_index_get_option(pcc_index* ix, int option, double* value) {
     *value = pd ? *pd : (double)*pi;
     return PCC_OK;
 }
+int pcc_counts_pairs(void) {
+#ifdef PCC_COUNT_PAIRS
+    return 1;
+#else
+    return 0;
+#endif
+}
 int pcc_index_stats(const pcc_index* cix, uint64_t stats[8]) {
     if (!cix || !stats) { set_error("null argument"); return PCC_ERR_INVALID; }
     pcc_index* ix = const_cast<pcc_index*>(cix);
     PCC_ENTER(ix);
     PCC_TRY(sync_info(ix));
+#ifdef PCC_COUNT_PAIRS
+    // profiling build: distances evaluated by the pruned kernels (process-wide, every handle) since the previous call
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    ix->stats[4] = pairs_take_grid() + pairs_take_knn() + pairs_take_cluster() + pairs_take_flann();
+#endif
     if (ix->stats_pending) {
         PCC_HIP(hipStreamSynchronize(ix->stream));
         ix->stats_pending = false;

@@ -342,4 +342,6 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
     return PCC_OK;
 }
 
+PCC_PAIRS_TAKE(cluster)
+
 }  // namespace pcc

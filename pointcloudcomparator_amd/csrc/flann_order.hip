@@ -218,4 +218,6 @@ int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys,
     return PCC_OK;
 }
 
+PCC_PAIRS_TAKE(flann)
+
 }  // namespace pcc

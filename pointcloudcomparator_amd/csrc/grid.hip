@@ -632,7 +632,8 @@ __device__ __forceinline__ void flat2_pass(FW& fw, const float4* __restrict__ ce
         for (int b = 0; b < B; ++b) {
             const unsigned int slot = rec[b] & 63u;
             const float4 qv = fw.q[slot];
-            const float d = dist2(qv.x, qv.y, qv.z, r4[b]);
+            const float d = dist2_nc(qv.x, qv.y, qv.z, r4[b]);
+            PCC_PAIR(ok[b]);
             const unsigned int db = __float_as_uint(d);
             const unsigned int cur = LIVE ? reinterpret_cast<const unsigned int*>(&fw.best[slot])[1] : __float_as_uint(qv.w);
             const unsigned int ri = (unsigned int)__float_as_int(r4[b].w);  // (never ~0: keeps the candidate ONE 16-byte load)
@@ -1180,5 +1181,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     ix->last_nq = nq;
     return PCC_OK;
 }
+
+PCC_PAIRS_TAKE(grid)
 
 }  // namespace pcc

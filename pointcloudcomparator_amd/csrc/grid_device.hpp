@@ -33,7 +33,7 @@ __device__ __forceinline__ unsigned int voxel_id(const float4& v, const GridPara
 // (v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per instruction, same rounding as the scalar forms), 6 VALU
 // instructions per candidate instead of 8 -- the pruned kernels are VALU-issue bound.
 typedef float pcc_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& r) {
+__device__ __forceinline__ float dist2_nc(float qx, float qy, float qz, const float4& r) {
     const pcc_f2 q2 = {qx, qy}, r2 = {r.x, r.y};
     const pcc_f2 d2 = q2 - r2;
     const pcc_f2 s2 = d2 * d2;
@@ -41,6 +41,35 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, const float
     float d = s2.x + s2.y;
     d = d + dz * dz;
     return d;
+}
+
+// ---- pair counter of the PROFILING build (make prof: -DPCC_COUNT_PAIRS, libpcc_nn_prof.so) -------------------------
+// Every (query, reference) distance a pruned kernel evaluates is counted, so that pairs/s -- and with 9 VALU operations
+// per pair the fraction of the non-FMA fp32 roof -- can be reported for kernels whose HBM traffic says nothing about
+// them.  One sharded counter array per translation unit (static: no relocatable device code), summed and
+// cleared by pcc_index_stats.  The compiler folds a wave's increments into one atomic.  Not compiled into libpcc_nn.so.
+#ifdef PCC_COUNT_PAIRS
+static __device__ unsigned long long g_pcc_pairs[64 * 16];
+#define PCC_PAIR(pred) do { if (pred) atomicAdd(&g_pcc_pairs[(blockIdx.x & 63u) * 16u], 1ull); } while (0)
+#define PCC_PAIRS_TAKE(NAME)                                                              \
+    unsigned long long pairs_take_##NAME() {                                              \
+        static unsigned long long h[64 * 16];                                             \
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pcc_pairs), sizeof(h)) != hipSuccess) return 0; \
+        unsigned long long sum = 0;                                                       \
+        for (int i = 0; i < 64 * 16; ++i) { sum += h[i]; h[i] = 0; }                      \
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pcc_pairs), h, sizeof(h));                   \
+        return sum;                                                                       \
+    }
+#else
+#define PCC_PAIR(pred) ((void)0)
+#define PCC_PAIRS_TAKE(NAME)
+#endif
+
+// the counted form: every lane that gets here evaluates a candidate (sites that also run clamped tail lanes use
+// dist2_nc and count under their own predicate)
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& r) {
+    PCC_PAIR(true);
+    return dist2_nc(qx, qy, qz, r);
 }
 
 // lower bound (squared, shrunk) of the distance from q to any point outside the cell cube

@@ -46,7 +46,8 @@ __device__ __forceinline__ void knn_scan_span(const float4* __restrict__ cell_re
         const bool two = p + 1 < e;
         const float4 r1 = cell_refs[two ? p + 1 : p];
         const unsigned long long k0 = make_key(dist2(qx, qy, qz, r0), r0);
-        const unsigned long long k1 = make_key(dist2(qx, qy, qz, r1), r1);
+        const unsigned long long k1 = make_key(dist2_nc(qx, qy, qz, r1), r1);
+        PCC_PAIR(two);
         if (k0 < worst) knn_insert(list, K, k0, worst);
         if (two && k1 < worst) knn_insert(list, K, k1, worst);
     }
@@ -659,7 +660,8 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u == 1 && B + 64u >= total) break;
-                    fn(c[u], make_key(dist2(qx, qy, qz, r4[u]), r4[u]), c[u] < total);
+                    PCC_PAIR(c[u] < total);
+                    fn(c[u], make_key(dist2_nc(qx, qy, qz, r4[u]), r4[u]), c[u] < total);
                 }
             }
         };
@@ -1204,7 +1206,8 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         if (u == 1 && B + 64u >= total) break;
-                        const float d = dist2(qx, qy, qz, r4[u]);
+                        const float d = dist2_nc(qx, qy, qz, r4[u]);
+                        PCC_PAIR(c[u] < total);
                         const bool hit = c[u] < total && d < r2;
                         const unsigned long long key = make_key(d, r4[u]);
                         const unsigned long long mask = __ballot(hit);
@@ -1402,5 +1405,7 @@ int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, in
     ev_mark(ix, EV_MAIN1);
     return PCC_OK;
 }
+
+PCC_PAIRS_TAKE(knn)
 
 }  // namespace pcc
