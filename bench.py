@@ -440,7 +440,7 @@ def main():
             for _ in range(reps):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                md, inl, thr, kept = ix.sor(50, 1.5)
+                md, inl, thr, kept = ix.sor(50, 1.5, device=dev)
                 best = min(best, time.perf_counter() - t0)
             r["sor_k51_ms"] = best * 1e3
             r["sor_kept"] = int(kept)

@@ -210,6 +210,10 @@ int pcc_euclidean_clusters(pcc_index *index, double tolerance, uint32_t min_size
  * be NULL); *threshold and *kept are host scalars. */
 int pcc_sor(pcc_index *index, int mean_k, double stddev_mult, int mem,
             float *mean_dist, uint8_t *inlier, double *threshold, size_t *kept);
+/* PCL adds the mean distances up in index order in double (sum, and sq_sum of float squares).  The library takes both sums,
+ * the threshold and the mask on the device whenever no addition of that chain rounds (every order then gives PCL's bits);
+ * otherwise it falls back to the in-order loop on the host.  *on_device = 1 when the last pcc_sor stayed on the device. */
+int pcc_index_sor_on_device(const pcc_index *index, int *on_device);
 
 /* ---- ICP building blocks ----------------------------------------------------------
  * replaces: pcl::IterativeClosestPoint::align / getFitnessScore

@@ -35,7 +35,7 @@ SYMBOLS = [
     "pcc_normals", "pcc_region_growing", "pcc_sac_plane", "pcc_rigid_from_sums",
     "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
-    "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices", "pcc_counts_pairs",
+    "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices", "pcc_counts_pairs", "pcc_index_sor_on_device",
 ]
 
 
@@ -402,14 +402,30 @@ class Index:
         self._after(st)
         return labels, ncl.value, sizes[:min(ncl.value, max_sizes)]
 
-    def sor(self, mean_k: int = 50, stddev_mult: float = 1.5):
-        md = np.empty(self.n_original, dtype=np.float32)
-        inl = np.empty(self.n_original, dtype=np.uint8)
+    def sor(self, mean_k: int = 50, stddev_mult: float = 1.5, device=None):
+        """pcl::StatisticalOutlierRemoval over the indexed cloud: (mean distances, inlier mask, threshold, kept).
+        device: a torch device -> the two arrays stay in HBM (torch tensors), nothing cloud-sized crosses PCIe."""
         thr = C.c_double(0)
         kept = C.c_size_t(0)
+        if device is not None:
+            import torch
+            md = torch.empty(self.n_original, dtype=torch.float32, device=device)
+            inl = torch.empty(self.n_original, dtype=torch.uint8, device=device)
+            st = self._before(md)
+            _check(LIB.pcc_sor(self._h, mean_k, float(stddev_mult), MEM_DEVICE, md.data_ptr(), inl.data_ptr(), C.byref(thr), C.byref(kept)))
+            self._after(st)
+            return md, inl, thr.value, kept.value
+        md = np.empty(self.n_original, dtype=np.float32)
+        inl = np.empty(self.n_original, dtype=np.uint8)
         _check(LIB.pcc_sor(self._h, mean_k, float(stddev_mult), MEM_HOST, md.ctypes.data, inl.ctypes.data,
                            C.byref(thr), C.byref(kept)))
         return md, inl, thr.value, kept.value
+
+    def sor_on_device(self) -> bool:
+        """whether the last sor() took its sums, threshold and mask on the device (else: the in-order host loop)"""
+        f = C.c_int(0)
+        _check(LIB.pcc_index_sor_on_device(self._h, C.byref(f)))
+        return bool(f.value)
 
     def sac_plane(self, points, max_iterations: int = 100, threshold: float = 0.02, probability: float = 0.99,
                   optimize: bool = True):

@@ -757,24 +757,26 @@ int pcc_sac_plane(pcc_index* ix, const void* pts, size_t n, size_t stride, int m
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, pts, n, stride, mem));
     const float4* dp = ix->q_packed.as<float4>();
-    // the sampling and the refit read single points on the host: the caller's array, or a copy of the staged cloud
-    std::vector<float4> hp;
-    const char* host_base = static_cast<const char*>(pts);
-    size_t host_stride = stride;
-    if (mem == PCC_MEM_DEVICE) {
-        hp.resize(n);
+    // the sampling and the refit read single points on the host: from the caller's array when it is a host array; for a
+    // cloud in device memory the few points needed are gathered there (sac.hip) -- round 3 copied the whole cloud back
+    // (16 B x n per call; the -e plane-removal loop calls this a handful of times per cloud)
+    int32_t* di = inliers;
+    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(n * sizeof(int32_t))); di = ix->out_idx.as<int32_t>(); }
+    size_t m = 0;
+    int st = sac_plane(ix, dp, n, mem == PCC_MEM_HOST ? static_cast<const char*>(pts) : nullptr, stride, max_iterations, threshold,
+                       probability, optimize, di, &m, coeff, iterations);
+    if (st == PCC_ERR_RETRY_HOST) {
+        // a degenerate sample (PCL redraws it at once, which the gathered form cannot replay): with a host copy of the cloud
+        std::vector<float4> hp(n);
         PCC_HIP(hipMemcpyAsync(hp.data(), dp, n * sizeof(float4), hipMemcpyDeviceToHost, ix->stream));
         PCC_HIP(hipStreamSynchronize(ix->stream));
         const float qnan = std::nanf("");
         for (size_t i = 0; i < n; ++i)  // the staged copy zeroes non-finite points; PCL would see them as they are
             if (__builtin_bit_cast(int, hp[i].w) < 0) hp[i].x = hp[i].y = hp[i].z = qnan;
-        host_base = reinterpret_cast<const char*>(hp.data());
-        host_stride = sizeof(float4);
+        st = sac_plane(ix, dp, n, reinterpret_cast<const char*>(hp.data()), sizeof(float4), max_iterations, threshold, probability,
+                       optimize, di, &m, coeff, iterations);
     }
-    int32_t* di = inliers;
-    if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(n * sizeof(int32_t))); di = ix->out_idx.as<int32_t>(); }
-    size_t m = 0;
-    PCC_TRY(sac_plane(ix, dp, n, host_base, host_stride, max_iterations, threshold, probability, optimize, di, &m, coeff, iterations));
+    PCC_TRY(st);
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST && m) {
         PCC_TRY(deliver(ix, di, inliers, m, mem));
@@ -956,34 +958,64 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     float* dmean = ix->out_d2.as<float>();
     PCC_HIP(hipMemsetAsync(dmean, 0, no * sizeof(float), ix->stream));
     PCC_TRY(launch_sor_mean(ix->stream, keys, ix->refs.as<float4>(), n, K, dmean, d2_rows));
+    // statistics, threshold and mask on the device (pack.hip: exact whenever no addition of PCL's in-order sums rounds);
+    // the host sees 48 bytes.  Round 3 copied the means back, added them up on one host thread and sent a mask: 0.94 ms
+    // beside a 1.2 ms search at 1M points
+    struct { double sum, sq, thr; unsigned long long kept; unsigned int exact, pad; } hs{};
+    PCC_TRY(ix->scratch_a.reserve((size_t)3 * 1024 * sizeof(double) + 64));
+    PCC_TRY(ix->scratch_b.reserve(no + 64));
+    void* st_dev = ix->small.as<char>() + 256;  // (words 64..75 of the small block: free of the search counters)
+    uint8_t* dmask = mem == PCC_MEM_DEVICE && inlier ? inlier : ix->scratch_b.as<uint8_t>();
+    PCC_TRY(launch_sor_stats(ix->stream, dmean, no, ix->d_grid.as<GridDev>(), K, stddev_mult, ix->scratch_a.as<double>(), st_dev, dmask));
     ev_mark(ix, EV_CALL1);
-    PCC_TRY(ix->host_a.reserve(no * sizeof(float)));
-    PCC_TRY(ix->host_b.reserve(no));
-    float* hm = ix->host_a.as<float>();
-    uint8_t* hin = ix->host_b.as<uint8_t>();
-    PCC_HIP(hipMemcpyAsync(hm, dmean, no * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    PCC_HIP(hipMemcpyAsync(&hs, st_dev, sizeof(hs), hipMemcpyDeviceToHost, ix->stream));
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(ix->host_a.reserve(no * sizeof(float)));
+        PCC_TRY(ix->host_b.reserve(no));
+        if (mean_dist) PCC_HIP(hipMemcpyAsync(ix->host_a.p, dmean, no * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+        if (inlier) PCC_HIP(hipMemcpyAsync(ix->host_b.p, dmask, no, hipMemcpyDeviceToHost, ix->stream));
+    } else if (mean_dist) {
+        PCC_HIP(hipMemcpyAsync(mean_dist, dmean, no * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
+    }
     PCC_HIP(hipStreamSynchronize(ix->stream));
-    // PCL: sum / sq_sum over ALL entries in index order (double), valid = points with a full
-    // neighbourhood.  Invalid points and points without k neighbours contribute 0.
-    PCC_TRY(sync_info(ix));
-    size_t valid = ix->n_valid >= (size_t)K ? ix->n_valid : 0;
-    double sum = 0, sq = 0;
-    for (size_t i = 0; i < no; ++i) { const float f = hm[i]; sum += f; sq += (double)(f * f); }  // PCL squares in float (distances[i] * distances[i]), then widens
-    double mean = sum / (double)valid;
-    double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
-    double thr = mean + stddev_mult * std::sqrt(var);
-    size_t k_in = 0;
-    for (size_t i = 0; i < no; ++i) { hin[i] = !(hm[i] > thr); k_in += hin[i]; }
+    double thr = hs.thr;
+    size_t k_in = (size_t)hs.kept;
+    if (!hs.exact) {
+        // some addition of the in-order sums rounds (terms spread over more than 28 bits below the total): PCL's order
+        // decides the last bits, so the sums are taken in that order -- on the host, as round 3 always did
+        PCC_TRY(ix->host_a.reserve(no * sizeof(float)));
+        PCC_TRY(ix->host_b.reserve(no));
+        float* hm = ix->host_a.as<float>();
+        uint8_t* hin = ix->host_b.as<uint8_t>();
+        PCC_HIP(hipMemcpyAsync(hm, dmean, no * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        PCC_TRY(sync_info(ix));
+        const size_t valid = ix->n_valid >= (size_t)K ? ix->n_valid : 0;
+        double sum = 0, sq = 0;
+        for (size_t i = 0; i < no; ++i) { const float f = hm[i]; sum += f; sq += (double)(f * f); }  // PCL squares in float, then widens
+        const double mean = sum / (double)valid;
+        const double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
+        thr = mean + stddev_mult * std::sqrt(var);
+        k_in = 0;
+        for (size_t i = 0; i < no; ++i) { hin[i] = !(hm[i] > thr); k_in += hin[i]; }
+        if (mem == PCC_MEM_DEVICE && inlier) {
+            PCC_HIP(hipMemcpyAsync(inlier, hin, no, hipMemcpyHostToDevice, ix->stream));
+            PCC_HIP(hipStreamSynchronize(ix->stream));
+        }
+    }
     if (threshold) *threshold = thr;
     if (kept) *kept = k_in;
     if (mem == PCC_MEM_HOST) {
-        if (mean_dist) memcpy(mean_dist, hm, no * sizeof(float));
-        if (inlier) memcpy(inlier, hin, no);
-    } else {
-        if (mean_dist) PCC_HIP(hipMemcpyAsync(mean_dist, dmean, no * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
-        if (inlier) PCC_HIP(hipMemcpyAsync(inlier, hin, no, hipMemcpyHostToDevice, ix->stream));
-        PCC_HIP(hipStreamSynchronize(ix->stream));
+        if (mean_dist) memcpy(mean_dist, ix->host_a.p, no * sizeof(float));
+        if (inlier) memcpy(inlier, ix->host_b.p, no);
     }
+    ix->sor_exact_last = hs.exact != 0;
+    return PCC_OK;
+}
+
+int pcc_index_sor_on_device(const pcc_index* ix, int* on_device) {
+    if (!ix || !on_device) { set_error("null argument"); return PCC_ERR_INVALID; }
+    *on_device = ix->sor_exact_last ? 1 : 0;
     return PCC_OK;
 }
 

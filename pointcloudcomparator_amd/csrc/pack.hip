@@ -428,4 +428,121 @@ int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4*
     return PCC_OK;
 }
 
+// ---- SOR statistics on the device ---------------------------------------------------------------------------------
+// PCL adds the mean distances up one after the other in double (sum += d; sq_sum += d * d with the product rounded to
+// float: pcl/filters/impl/statistical_outlier_removal.hpp).  A sequential chain cannot be parallelised bit for
+// bit in general -- but it can whenever no addition of it ROUNDS: every term is a float (24 bits), every partial sum a
+// multiple of the smallest term's last bit, so as long as total / (last bit of the smallest positive term) stays below 2^52
+// every partial sum of ANY order is exact and all orders give the same double.  The kernels below add in a tree, track the
+// smallest positive term of both sums and say whether that condition held (means of centimetres over a million points:
+// it does, by ten bits); when it does not -- mean distances of micrometres next to metres -- pcc_sor falls back to the
+// in-order host loop.  Threshold and inlier mask follow on the device: no cloud-sized copy, one 48-byte read-back.
+struct SorStats {
+    double sum, sq, thr;
+    unsigned long long kept;
+    unsigned int exact, pad;
+};
+constexpr int SOR_RED_BLOCKS = 1024;
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (unsigned int)__shfl_down((int)v, off, 64));
+    return v;
+}
+// partial rows: {sum, sq, bits(min positive f) | bits(min positive float(f * f)) << 32}
+__global__ void __launch_bounds__(256)
+k_sor_reduce(const float* __restrict__ m, size_t n, double* __restrict__ part) {
+    double sum = 0.0, sq = 0.0;
+    unsigned int fmin = 0x7f800000u, gmin = 0x7f800000u;  // (positive floats order like their bits)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float f = m[i];
+        const float g = f * f;  // PCL: distances[i] * distances[i] in float, then widened
+        sum += (double)f;
+        sq += (double)g;
+        if (f > 0.f) fmin = min(fmin, __float_as_uint(f));
+        if (g > 0.f) gmin = min(gmin, __float_as_uint(g));
+    }
+    __shared__ double rs[4], rq[4];
+    __shared__ unsigned int rf[4], rg[4];
+    sum = wave_sum_f64(sum);
+    sq = wave_sum_f64(sq);
+    fmin = wave_min_u32(fmin);
+    gmin = wave_min_u32(gmin);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = sum; rq[threadIdx.x >> 6] = sq; rf[threadIdx.x >> 6] = fmin; rg[threadIdx.x >> 6] = gmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = ((rs[0] + rs[1]) + rs[2]) + rs[3];
+        part[blockIdx.x * 3 + 1] = ((rq[0] + rq[1]) + rq[2]) + rq[3];
+        const unsigned long long mm = (unsigned long long)min(min(rf[0], rf[1]), min(rf[2], rf[3])) |
+                                      ((unsigned long long)min(min(rg[0], rg[1]), min(rg[2], rg[3])) << 32);
+        part[blockIdx.x * 3 + 2] = __longlong_as_double((long long)mm);
+    }
+}
+// last bit of a positive float given by its bits (denormals: 2^-149), as a double
+__device__ __forceinline__ double float_last_bit(unsigned int bits) {
+    const int e = (int)(bits >> 23);  // biased exponent; 0: denormal
+    return ldexp(1.0, (e > 0 ? e - 127 : -126) - 23);
+}
+__global__ void __launch_bounds__(1024)
+k_sor_finish(const double* __restrict__ part, int nb, const GridDev* __restrict__ gd, int K, double stddev_mult,
+             SorStats* __restrict__ st) {
+    __shared__ double rs[16], rq[16];
+    __shared__ unsigned int rf[16], rg[16];
+    double sum = 0.0, sq = 0.0;
+    unsigned int fmin = 0x7f800000u, gmin = 0x7f800000u;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        sum += part[b * 3 + 0];
+        sq += part[b * 3 + 1];
+        const unsigned long long mm = (unsigned long long)__double_as_longlong(part[b * 3 + 2]);
+        fmin = min(fmin, (unsigned int)mm);
+        gmin = min(gmin, (unsigned int)(mm >> 32));
+    }
+    sum = wave_sum_f64(sum);
+    sq = wave_sum_f64(sq);
+    fmin = wave_min_u32(fmin);
+    gmin = wave_min_u32(gmin);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = sum; rq[threadIdx.x >> 6] = sq; rf[threadIdx.x >> 6] = fmin; rg[threadIdx.x >> 6] = gmin; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    sum = 0.0; sq = 0.0;
+    for (int w = 0; w < 16; ++w) { sum += rs[w]; sq += rq[w]; fmin = min(fmin, rf[w]); gmin = min(gmin, rg[w]); }
+    // no addition rounded if the total, counted in last bits of the smallest positive term, stays below 2^52
+    const bool exact = (fmin == 0x7f800000u || sum < float_last_bit(fmin) * 4503599627370496.0) &&
+                       (gmin == 0x7f800000u || sq < float_last_bit(gmin) * 4503599627370496.0);
+    // PCL: valid = points with a full neighbourhood (all finite points once the cloud holds K of them)
+    const double valid = gd->n_valid >= (unsigned int)K ? (double)gd->n_valid : 0.0;
+    const double mean = sum / valid;
+    const double var = (sq - sum * sum / valid) / (valid - 1.0);
+    st->sum = sum;
+    st->sq = sq;
+    st->thr = mean + stddev_mult * sqrt(var);
+    st->kept = 0ull;
+    st->exact = exact ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_sor_mask(const float* __restrict__ m, size_t n, SorStats* __restrict__ st, uint8_t* __restrict__ inlier) {
+    const double thr = st->thr;
+    unsigned int cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const bool in = !((double)m[i] > thr);  // PCL: outlier iff distances[i] > threshold (float widened to double)
+        if (inlier) inlier[i] = in ? 1 : 0;
+        cnt += in ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st->kept, (unsigned long long)cnt);
+}
+// statistics + threshold + mask of the mean distances m[n] on the stream; stats (device, 48 bytes) and scratch (>= 3 *
+// SOR_RED_BLOCKS doubles) are the caller's
+int launch_sor_stats(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult, double* scratch,
+                     void* stats_dev, uint8_t* inlier_dev) {
+    const int nb = (int)std::min<size_t>((n + 255) / 256, SOR_RED_BLOCKS);
+    hipLaunchKernelGGL(k_sor_reduce, dim3(nb), dim3(256), 0, s, m, n, scratch);
+    hipLaunchKernelGGL(k_sor_finish, dim3(1), dim3(1024), 0, s, scratch, nb, gd, K, stddev_mult, static_cast<SorStats*>(stats_dev));
+    hipLaunchKernelGGL(k_sor_mask, dim3(nb), dim3(256), 0, s, m, n, static_cast<SorStats*>(stats_dev), inlier_dev);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
 }  // namespace pcc

@@ -162,6 +162,7 @@ struct pcc_index {
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
     pcc::DevBuf knn_fb;  // a list of up to n indices + its count, one user at a time: queries the k-NN selection kernel hands back,
                          // rows a fused radius fill leaves to k_sort_rows, region growing's points with a cross edge
+    bool sor_exact_last = true;                   // the last pcc_sor took its sums on the device (no addition of PCL's order rounds)
     bool open_pending = false;                    // the open-lane counters of the last listed k = 1 search are still on the device
     bool ties_pending = false;                    // the tie counters of the last search are still on the device
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
@@ -227,6 +228,10 @@ int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n);
 // the self query; rows with fewer than K neighbours keep 0
 int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4* refs, size_t n, int K,
                     float* mean_dist, const float* d2_rows = nullptr);
+// SOR: sum / sq_sum / threshold / inlier mask of the mean distances on the device (pack.hip); stats_dev receives
+// {double sum, sq, thr; uint64 kept; uint32 exact, pad}: exact == 0 -> the tree sums may differ from PCL's in-order sums
+int launch_sor_stats(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult, double* scratch,
+                     void* stats_dev, uint8_t* inlier_dev);
 int launch_copy_row_prefix(hipStream_t s, const unsigned long long* src, int k_src, unsigned long long* dst, int k_dst, size_t n);
 
 // ---- exhaustive engine (nn1_brute.hip) -------------------------------------------
@@ -271,6 +276,7 @@ bool grid_knn_delivers(int K);
 int grid_radius(pcc_index* ix, const float4* q, size_t nq, float r, float r2, int32_t* counts,
                 const int64_t* offsets, unsigned long long* keys, int sorted, size_t total = 0, int32_t* idx_out = nullptr,
                 float* d2_out = nullptr, bool* delivered = nullptr);
+constexpr int PCC_ERR_RETRY_HOST = -1000;  // sac_plane without a host array met a degenerate sample: repeat with one (internal)
 int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n, const char* host_base, size_t host_stride,
               int max_iterations, double threshold, double probability, int optimize, int32_t* inliers_dev,
               size_t* n_inliers, float coeff[4], int* iterations_out);

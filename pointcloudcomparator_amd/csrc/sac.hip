@@ -78,6 +78,20 @@ k_sac_scatter(const float4* __restrict__ pts, unsigned int n, float4 model, doub
         if (plane_inlier_dev(model, pts[i], threshold)) out[pos[i]] = (int32_t)i;
 }
 
+// out[j] = the three coordinates of point idx[j] as PCL sees them (non-finite points, zeroed and flagged by the staging,
+// come back as NaN): the handful of sampled points of a batch, and the inliers of the refit in list order
+__global__ void __launch_bounds__(256)
+k_sac_gather(const float4* __restrict__ pts, const int32_t* __restrict__ idx, unsigned int m, float* __restrict__ out) {
+    for (unsigned int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        const float4 p = pts[idx[j]];
+        const bool bad = __float_as_int(p.w) < 0;
+        const float qnan = __int_as_float(0x7fc00000);
+        out[3 * (size_t)j + 0] = bad ? qnan : p.x;
+        out[3 * (size_t)j + 1] = bad ? qnan : p.y;
+        out[3 * (size_t)j + 2] = bad ? qnan : p.z;
+    }
+}
+
 // ---- host side: PCL's generator, sampling and plane arithmetic ------------------------------------------
 struct Mt19937 {
     uint32_t mt[624];
@@ -153,13 +167,53 @@ int select_inliers(pcc_index* ix, const float4* pts, unsigned int n, const float
 
 }  // namespace
 
-// pts_dev: the staged cloud (float4, w < 0 = non-finite).  host_xyz(i): pointer to the i-th point's three floats
-// on the host (the caller's own array, or a copy of the staged cloud).
+// PCL's persistent shuffled index array (`shuffled_indices_`, the identity at first), touched in three places per sample:
+// kept as the identity plus the entries that differ -- initialising n integers cost more than everything else the host
+// does for a million points
+struct SparseShuffle {
+    std::vector<std::pair<uint32_t, int32_t>> slots;  // open addressing, key + 1 (0 = empty)
+    size_t used = 0;
+    SparseShuffle() : slots(1024, {0u, 0}) {}
+    int32_t get(uint32_t i) const {
+        for (size_t h = (i * 2654435761u) & (slots.size() - 1);; h = (h + 1) & (slots.size() - 1)) {
+            if (slots[h].first == 0u) return (int32_t)i;
+            if (slots[h].first == i + 1u) return slots[h].second;
+        }
+    }
+    void set(uint32_t i, int32_t v) {
+        if (2 * (used + 1) > slots.size()) {
+            std::vector<std::pair<uint32_t, int32_t>> old(slots.size() * 2, {0u, 0});
+            old.swap(slots);
+            used = 0;
+            for (const auto& e : old)
+                if (e.first) set(e.first - 1u, e.second);
+        }
+        for (size_t h = (i * 2654435761u) & (slots.size() - 1);; h = (h + 1) & (slots.size() - 1)) {
+            if (slots[h].first == 0u) { slots[h] = {i + 1u, v}; ++used; return; }
+            if (slots[h].first == i + 1u) { slots[h].second = v; return; }
+        }
+    }
+    void swap(uint32_t a, uint32_t b) {
+        if (a == b) return;
+        const int32_t va = get(a), vb = get(b);
+        set(a, vb);
+        set(b, va);
+    }
+};
+
+// pts_dev: the staged cloud (float4, w < 0 = non-finite).  host_base / host_stride: the caller's own array when it lives on
+// the host (single points are read from it).  host_base == nullptr (the cloud is in device memory): the points the host
+// needs -- the 96 sampled points of a batch, the inliers of the refit -- are gathered on the device and copied compactly;
+// nothing of the size of the cloud crosses to the host.  The batch's samples are then drawn before their coordinates are
+// known, which is PCL's sequence as long as no sample is degenerate (PCL redraws those at once, exact float equalities:
+// duplicates, collinear lattice points); the first degenerate sample ends the attempt with PCC_ERR_RETRY_HOST and the caller
+// repeats the call with a host copy of the cloud, as round 3 always did.
 int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_base, size_t host_stride,
               int max_iterations, double threshold, double probability, int optimize, int32_t* inliers_dev,
               size_t* n_inliers, float coeff[4], int* iterations_out) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)n_;
+    const bool gathered = host_base == nullptr;
     auto P = [&](int32_t i) { return reinterpret_cast<const float*>(host_base + (size_t)i * host_stride); };
     *n_inliers = 0;
     coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.f;
@@ -172,10 +226,17 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_
     std::vector<unsigned int> part((size_t)count_blocks * SAC_BATCH);
     float4* d_models = ix->scratch_a.as<float4>();
     unsigned int* d_counts = ix->scratch_b.as<unsigned int>();
+    // the sampled points of a batch: indices up, coordinates back (pinned staging in the handle's small block)
+    int32_t* d_smp_idx = nullptr;
+    float* d_smp_xyz = nullptr;
+    if (gathered) {
+        PCC_TRY(ix->scratch_e.reserve(SAC_BATCH * 3 * (sizeof(int32_t) + 3 * sizeof(float)) + 64));
+        d_smp_idx = ix->scratch_e.as<int32_t>();
+        d_smp_xyz = reinterpret_cast<float*>(d_smp_idx + SAC_BATCH * 3);
+    }
 
     Mt19937 gen(12345u);
-    std::vector<int32_t> shuffled(n);
-    for (unsigned int i = 0; i < n; ++i) shuffled[i] = (int32_t)i;
+    SparseShuffle shuffled;
     int iterations = 0, best_count = -INT32_MAX;
     bool have_model = false, stop = false;
     double k = 1.0;
@@ -192,12 +253,33 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_
         int nm = 0;
         bool sampling_failed = false;
         unsigned skipped_batch = skipped;
+        auto draw = [&](int32_t smp[3]) {
+            for (unsigned i = 0; i < 3; ++i) shuffled.swap(i, i + (uint32_t)((size_t)gen.rnd() % (n - i)));
+            smp[0] = shuffled.get(0); smp[1] = shuffled.get(1); smp[2] = shuffled.get(2);
+        };
+        if (gathered) {
+            // one draw per candidate, all candidates of the batch at once; their coordinates in one small round trip
+            int32_t smp[SAC_BATCH][3];
+            float xyz[SAC_BATCH][3][3];
+            int want = 0;
+            while (want < SAC_BATCH && iterations + want <= max_iterations) { draw(smp[want]); ++want; }
+            if (want > 0) {
+                PCC_HIP(hipMemcpyAsync(d_smp_idx, smp, (size_t)want * 3 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_sac_gather, dim3(1), dim3(256), 0, s, pts_dev, d_smp_idx, (unsigned int)want * 3u, d_smp_xyz);
+                PCC_HIP(hipGetLastError());
+                PCC_HIP(hipMemcpyAsync(xyz, d_smp_xyz, (size_t)want * 9 * sizeof(float), hipMemcpyDeviceToHost, s));
+                PCC_HIP(hipStreamSynchronize(s));
+            }
+            for (int c = 0; c < want; ++c) {
+                if (!plane_from_sample(xyz[c][0], xyz[c][1], xyz[c][2], models[nm])) return PCC_ERR_RETRY_HOST;  // PCL would redraw here
+                ++nm;
+            }
+        } else
         while (nm < SAC_BATCH && iterations + nm <= max_iterations && skipped_batch < max_skip) {
             int32_t smp[3];
             bool got = false;
             for (int it = 0; it < 1000 && !got; ++it) {  // max_sample_checks_
-                for (unsigned i = 0; i < 3; ++i) std::swap(shuffled[i], shuffled[i + (size_t)gen.rnd() % (n - i)]);
-                smp[0] = shuffled[0]; smp[1] = shuffled[1]; smp[2] = shuffled[2];
+                draw(smp);
                 got = !sample_degenerate(P(smp[0]), P(smp[1]), P(smp[2]));
             }
             if (!got) { sampling_failed = true; break; }
@@ -245,16 +327,29 @@ int sac_plane(pcc_index* ix, const float4* pts_dev, size_t n_, const char* host_
     PCC_TRY(select_inliers(ix, pts_dev, n, best, threshold, inliers_dev, &m));
     std::memcpy(coeff, best, sizeof(best));
     if (optimize && m >= 4) {
-        // optimizeModelCoefficients: computeMeanAndCovarianceMatrix over the inliers, in index order, in float
-        std::vector<int32_t> hi(m);
-        PCC_HIP(hipMemcpyAsync(hi.data(), inliers_dev, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        PCC_HIP(hipStreamSynchronize(s));
+        // optimizeModelCoefficients: computeMeanAndCovarianceMatrix over the inliers, in index order, in float -- a serial
+        // float chain, PCL's bits only in PCL's order: it stays a host loop.  What it reads: the caller's array, or the
+        // inliers' coordinates gathered on the device in list order (12 bytes per INLIER, not 16 per point of the cloud)
         float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t j = 0; j < m; ++j) {
-            const float* q = P(hi[j]);
+        auto add = [&](const float* q) {
             a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2];
             a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
             a[6] += q[0]; a[7] += q[1]; a[8] += q[2];
+        };
+        if (gathered) {
+            PCC_TRY(ix->scratch_f.reserve(m * 3 * sizeof(float)));
+            PCC_TRY(ix->host_a.reserve(m * 3 * sizeof(float)));
+            hipLaunchKernelGGL(k_sac_gather, dim3(g1(m)), dim3(256), 0, s, pts_dev, inliers_dev, (unsigned int)m, ix->scratch_f.as<float>());
+            PCC_HIP(hipGetLastError());
+            PCC_HIP(hipMemcpyAsync(ix->host_a.p, ix->scratch_f.p, m * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+            PCC_HIP(hipStreamSynchronize(s));
+            const float* hq = ix->host_a.as<float>();
+            for (size_t j = 0; j < m; ++j) add(hq + 3 * j);
+        } else {
+            std::vector<int32_t> hi(m);
+            PCC_HIP(hipMemcpyAsync(hi.data(), inliers_dev, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            PCC_HIP(hipStreamSynchronize(s));
+            for (size_t j = 0; j < m; ++j) add(P(hi[j]));
         }
         float cov[9], nrm[3], curv;
         covariance_from_sums(a, (unsigned int)m, cov);

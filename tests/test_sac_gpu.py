@@ -123,3 +123,40 @@ def test_plane_removal_loop_like_the_reference():
         want = np.ascontiguousarray(np.delete(want, w_inl, 0))
         rounds += 1
     assert rounds == 2 and len(got) < 0.3 * n0
+
+
+def test_sac_plane_in_device_memory_gathers_its_points():
+    """a cloud in HBM: the sampled points of a batch and the inliers of the refit are gathered on the device (no copy of the
+    cloud to the host); a degenerate sample -- PCL redraws it at once -- cannot be replayed that way and sends the call
+    through a host copy.  Both routes: the oracle's samples, counts, inliers and coefficient bits."""
+    import torch
+    ctx = _ctx()
+    # weak support: more than one batch of candidates, refit on
+    pts = _scene(2000, 18000, 7)
+    inl, c, its = ctx.sac_plane(torch.from_numpy(pts).cuda(), 100, 0.02, 0.99, True)
+    w_inl, w_c, w_its = oracle.sac_plane(pts, 100, 0.02, 0.99, True)
+    assert its == w_its and its > 32
+    np.testing.assert_array_equal(inl.cpu().numpy(), w_inl)
+    assert (c.view(np.uint32) == w_c.view(np.uint32)).all()
+    # 32-byte stride in device memory, non-finite points among the samples' candidates
+    wide = np.zeros((len(pts), 8), np.float32)
+    wide[:, :3] = pts
+    wide[::7, 2] = np.nan
+    inl, c, its = ctx.sac_plane(torch.from_numpy(wide).cuda(), 100, 0.02, 0.99, True)
+    w_inl, w_c, w_its = oracle.sac_plane(wide, 100, 0.02, 0.99, True)
+    assert its == w_its
+    np.testing.assert_array_equal(inl.cpu().numpy(), w_inl)
+    assert (c.view(np.uint32) == w_c.view(np.uint32)).all()
+    # duplicates: degenerate samples are drawn (p1 == p0 gives equal ratios 0) -> the retry with a host copy
+    rng = np.random.default_rng(3)
+    base = _scene(300, 100, 5)
+    dup = np.ascontiguousarray(base[rng.integers(0, len(base), 4000)])
+    inl, c, its = ctx.sac_plane(torch.from_numpy(dup).cuda(), 100, 0.02, 0.99, True)
+    w_inl, w_c, w_its = oracle.sac_plane(dup, 100, 0.02, 0.99, True)
+    assert its == w_its
+    np.testing.assert_array_equal(inl.cpu().numpy(), w_inl)
+    assert (c.view(np.uint32) == w_c.view(np.uint32)).all()
+    two = np.tile(np.array([[0, 0, 0], [1, 1, 1]], np.float32), (20, 1))
+    inl, c, its = ctx.sac_plane(torch.from_numpy(two).cuda())
+    w_inl, w_c, w_its = oracle.sac_plane(two)
+    assert len(inl) == len(w_inl) and its == w_its

@@ -174,6 +174,31 @@ def test_sor_matches_oracle(gpu):
     assert (inl == oinl).all() and kept == okept
 
 
+def test_sor_statistics_on_the_device_and_the_in_order_fallback(gpu):
+    """sum, sq_sum, threshold and mask are taken on the device whenever no addition of PCL's in-order double sums can round
+    (then every order gives the same bits); a cloud whose mean distances span micrometres to decimetres makes additions
+    round, and the library must notice and take the sums in PCL's order on the host.  Both ways: the oracle's bits."""
+    import torch
+    pts = _scene(40000)
+    with capi.Index(torch.from_numpy(pts).cuda()) as ix:
+        md, inl, thr, kept = ix.sor(50, 1.5, device="cuda:0")
+        assert ix.sor_on_device()
+        omd, oinl, othr, okept = oracle.sor(pts, 50, 1.5)
+        assert (_bits(md.cpu().numpy()) == _bits(omd)).all() and thr == othr
+        assert (inl.cpu().numpy() == oinl).all() and kept == okept
+    rng = np.random.default_rng(5)
+    wide = _scene(60000)
+    seeds = wide[:300]
+    clumps = (seeds[:, None, :] + rng.normal(0, 2e-7, (300, 70, 3))).reshape(-1, 3).astype(np.float32)  # 70 points within a micrometre
+    wide = np.concatenate([wide[300:], clumps]).astype(np.float32)
+    with capi.Index(wide) as ix:
+        md, inl, thr, kept = ix.sor(50, 1.5)
+        on_dev = ix.sor_on_device()
+    omd, oinl, othr, okept = oracle.sor(wide, 50, 1.5)
+    assert not on_dev, "terms 2^-20 below a sum of 2^11: additions round, the in-order loop is required"
+    assert (_bits(md) == _bits(omd)).all() and thr == othr and (inl == oinl).all() and kept == okept
+
+
 def test_transform_bits(gpu):
     pts = _scene(5000)
     a = np.deg2rad(7.0)

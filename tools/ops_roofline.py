@@ -2,7 +2,8 @@
 algorithmic bytes 8d prescribes, timed call by call (device memory in, device memory out, stream synchronised around the
 call).  Two steps:
     rocprofv3 --kernel-trace --stats -d gpurun_out/ops -- python3 tools/ops_roofline.py run gpurun_out/ops_run.json
-    python3 tools/ops_roofline.py merge gpurun_out/ops_run.json <kernel_stats.csv> profiles/r03_ops_roofline.json
+    PCC_LIB=.../libpcc_nn_prof.so python3 tools/ops_roofline.py run gpurun_out/ops_pairs.json    (pair counts, no times)
+    python3 tools/ops_roofline.py merge gpurun_out/ops_run.json <kernel_stats.csv> profiles/r04_ops_roofline.json [gpurun_out/ops_pairs.json]
 `merge` adds, per operation, the rocprofv3 average of each kernel it launches and prices the dominant one against the
 HBM roof (8 TB/s) on the operation's algorithmic bytes."""
 import csv, json, os, sys, time
@@ -16,7 +17,15 @@ def run(out_path):
     from pointcloudcomparator_amd import capi, synth
     res = []
 
+    counting = capi.LIB.pcc_counts_pairs() == 1  # PCC_LIB=.../libpcc_nn_prof.so: pair counts instead of times
+    cur = {"ix": None}
+
     def timed(fn, reps=3):
+        if counting:
+            cur["ix"].stats()  # clears the counter
+            r = fn(); torch.cuda.synchronize()
+            cur["pairs"] = int(cur["ix"].stats()[4])
+            return 1.0, r
         fn(); torch.cuda.synchronize()
         best = 1e9
         for _ in range(reps):
@@ -28,19 +37,22 @@ def run(out_path):
         res.append({"op": op, "config": config, "call_ms": seconds * 1e3, "algorithmic_bytes": alg_bytes,
                     "achieved_GBps": alg_bytes / seconds / 1e9, "frac_of_hbm": alg_bytes / seconds / 1e9 / HBM,
                     "kernels": kernels, "note": note})
+        if counting:
+            res[-1] = {"op": op, "config": config, "pairs_per_call": cur.get("pairs", 0)}
         print(res[-1], flush=True)
 
     n = 1_000_000
     a = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_A)).cuda()
     ix = capi.Index(a, auto_sync=False)
+    cur["ix"] = ix
     for K in (51, 100):
         t, _ = timed(lambda: (ix.knn(a, K), ix.sync()))
         add(f"k-NN K={K} (self query)", f"{n} x {n} corridor", t, 16.0 * n + 16.0 * n + 8.0 * K * n,
             ["k_grid_knn_sel", "k_grid_knn_wave", "k_knn_fill_invalid"], "refs + queries once (16 B packed), K (index, distance) pairs per query written; the kernel is "
             "VALU-bound (bucket selection, ~625 instructions per query at K = 51), the byte figure is what 8d asks for")
-    t, _ = timed(lambda: ix.sor(50, 1.5))
+    t, _ = timed(lambda: ix.sor(50, 1.5, device="cuda:0"))
     add("SOR mean_k=50 (-n noise pass)", f"{n} points", t, 32.0 * n + 8.0 * 51 * n + 4.0 * n, ["k_grid_knn_sel", "k_grid_knn_wave", "k_knn_fill_invalid", "k_sor_mean_staged"],
-        "includes PCL's in-order host reduction (D2H of the means)")
+        "statistics, threshold and mask on the device (exact-sum condition met); outputs stay in HBM")
     t, _ = timed(lambda: (ix.radius_count(a, 0.05), ix.sync()))
     add("radius count r=0.05", f"{n} x {n} corridor", t, 32.0 * n + 4.0 * n, ["k_grid_radius"])
     nrm = None
@@ -53,6 +65,7 @@ def run(out_path):
     m = 5_000_000
     obj = torch.from_numpy(synth.corridor_cloud(m, synth.SEED_A, layer="objects")).cuda()
     ix = capi.Index(obj, auto_sync=False)
+    cur["ix"] = ix
     cnt = ix.radius_count(obj, 0.05); ix.sync()
     total = int(cnt.to(torch.int64).sum().item())
     offs = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
@@ -78,6 +91,7 @@ def run(out_path):
     tgt = torch.from_numpy(synth.corridor_cloud(mm, synth.SEED_A)).cuda()
     src = torch.from_numpy(synth.rigid_offset(synth.corridor_cloud(mm, synth.SEED_B))).cuda()
     ix = capi.Index(tgt, auto_sync=False)
+    cur["ix"] = ix
     t, _ = timed(lambda: ix.icp_align(src, max_iter=50, fixed=True), reps=2)
     passes = 51
     add("ICP 50 fixed iterations + fitness (-i)", f"{mm} x {mm}", t, passes * (16.0 * mm + 28.0 * mm + 40.0 * mm + 32.0 * mm),
@@ -87,8 +101,12 @@ def run(out_path):
     json.dump(res, open(out_path, "w"), indent=1)
 
 
-def merge(run_json, stats_csv, out_path):
+VALU_PEAK_TOPS = 78.65  # non-FMA fp32 vector peak (157.3 / 2), 9 operations per pair
+
+
+def merge(run_json, stats_csv, out_path, pairs_json=None):
     ops = json.load(open(run_json))
+    pairs = {(o["op"], o["config"]): o["pairs_per_call"] for o in json.load(open(pairs_json))} if pairs_json else {}
     rows = list(csv.DictReader(open(stats_csv)))
     for op in ops:
         ks = {}
@@ -98,13 +116,20 @@ def merge(run_json, stats_csv, out_path):
                 short = name.split("(")[0].replace("void ", "").replace("pcc::", "")
                 ks[short] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
         op["rocprof_kernels"] = ks
-    json.dump({"hbm_peak_GBps": HBM, "operations": ops}, open(out_path, "w"), indent=1)
+        pc = pairs.get((op["op"], op["config"]))
+        if pc is not None:  # the VALU column: pair arithmetic of the call against the non-FMA fp32 roof
+            op["pairs_per_call"] = pc
+            op["pairs_per_s"] = pc / (op["call_ms"] * 1e-3)
+            op["valu_Tops"] = 9.0 * op["pairs_per_s"] / 1e12
+            op["frac_of_valu"] = op["valu_Tops"] / VALU_PEAK_TOPS
+    json.dump({"hbm_peak_GBps": HBM, "valu_peak_Tops": VALU_PEAK_TOPS, "ops_per_pair": 9, "operations": ops}, open(out_path, "w"), indent=1)
     for op in ops:
-        print(f"{op['op']:45s} {op['call_ms']:9.3f} ms  {op['achieved_GBps']:8.1f} GB/s  {op['frac_of_hbm'] * 100:5.1f} % of HBM")
+        print(f"{op['op']:45s} {op['call_ms']:9.3f} ms  {op['achieved_GBps']:8.1f} GB/s  {op['frac_of_hbm'] * 100:5.1f} % of HBM"
+              + (f"  {op['pairs_per_call'] / 1e6:9.1f} M pairs  {op['frac_of_valu'] * 100:5.2f} % of VALU" if "frac_of_valu" in op else ""))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
     else:
-        merge(sys.argv[2], sys.argv[3], sys.argv[4])
+        merge(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)

@@ -20,7 +20,8 @@ a = synth.corridor_cloud(n, synth.SEED_A)
 ta = torch.from_numpy(a).cuda()
 ix = capi.Index(ta)
 timed("knn k=51 1M (device)", lambda: (ix.knn(ta, 51), ix.sync()))
-timed("sor k=50 1M", lambda: ix.sor(50, 1.5))
+timed("sor k=50 1M (device outputs)", lambda: ix.sor(50, 1.5, device="cuda:0"))
+timed("sor k=50 1M (host outputs)", lambda: ix.sor(50, 1.5))
 timed("radius_count r=0.05 1M", lambda: (ix.radius_count(ta, 0.05), ix.sync()))
 nrm = timed("normals k=50 1M (device)", lambda: ix.normals(50, device="cuda:0"))
 timed("region_growing k=100 1M (device normals)", lambda: ix.region_growing(nrm, k=100))
@@ -30,7 +31,7 @@ timed("first_within 100k queries", lambda: (ix.first_within(ta[:100000] + 0.01, 
 ix.close()
 room = torch.from_numpy(synth.room_cloud(synth.ROOM_SIZES[1], synth.SEED_A)).cuda()
 ix = capi.Index(room)
-timed(f"room scan {synth.ROOM_SIZES[1]} points: sor k=50", lambda: ix.sor(50, 1.5))
+timed(f"room scan {synth.ROOM_SIZES[1]} points: sor k=50 (device outputs)", lambda: ix.sor(50, 1.5, device="cuda:0"))
 timed(f"room scan {synth.ROOM_SIZES[1]} points: knn k=51 (device)", lambda: (ix.knn(room, 51), ix.sync()))
 ix.close()
 obj = synth.corridor_cloud(5_000_000, synth.SEED_A, layer="objects")

@@ -31,7 +31,9 @@ python3 tools/exp_ties.py 1e6 2>/dev/null | tail -1 >> $S/${TAG}_ops_wallclock.t
 cat $S/${TAG}_ops_wallclock.txt
 # per-operation rooflines (algorithmic bytes of SURVEY 8d against the HBM roof, rocprofv3 averages per kernel)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/opsr -- python3 tools/ops_roofline.py run $O/ops_run.json > $O/opsr.log 2> $O/opsr.err
-python3 tools/ops_roofline.py merge $O/ops_run.json $(find $O/opsr -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_roofline.json
+# pair counts of the same operations by the profiling build (VALU column of the table)
+PCC_LIB=$GRAFT_REPO_ROOT/pointcloudcomparator_amd/lib/libpcc_nn_prof.so python3 tools/ops_roofline.py run $S/${TAG}_ops_pairs.json > $O/opsp.log 2> $O/opsp.err
+python3 tools/ops_roofline.py merge $O/ops_run.json $(find $O/opsr -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_roofline.json $S/${TAG}_ops_pairs.json
 # counters of the k = 1 kernels (one --pmc pass per group), 10M x 10M and 1M x 1M corridor scene
 rm -rf gpurun_out/pmcf_1_both
 bash tools/pmc_flat.sh 1 1e7 both 1 2 3 4 > $O/pmcf_c3.log 2>&1
