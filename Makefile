@@ -8,7 +8,7 @@ ARCH       ?= gfx950
 HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -Iinclude -Ipointcloudcomparator_amd/csrc
 CSRC       := pointcloudcomparator_amd/csrc
 LIBDIR     := pointcloudcomparator_amd/lib
-HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/normals.hip $(CSRC)/region.hip $(CSRC)/sac.hip $(CSRC)/flann_order.hip $(CSRC)/cellsort_mp.hip)
+HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/normals.hip $(CSRC)/region.hip $(CSRC)/sac.hip $(CSRC)/flann_order.hip $(CSRC)/cellsort_mp.hip $(CSRC)/comm.hip)
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 
 all: lib oracle hosttest cli prof
@@ -22,7 +22,7 @@ build/prof/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $
 	$(HIPCC) $(HIPFLAGS) -DPCC_COUNT_PAIRS $(EXTRA_HIPFLAGS) -c $< -o $@
 $(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(PROF_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(PROF_OBJS) -ldl
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu build/ubench_gather
 hosttest: build/test_host_mirror build/test_lane_ops build/test_report
@@ -34,7 +34,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC
 
 $(LIBDIR)/libpcc_nn.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
 oracle/_build/libpcc_oracle.so: oracle/pcc_oracle.c oracle/pcc_oracle.h
 	@mkdir -p oracle/_build
@@ -56,7 +56,7 @@ build/test_host_mirror: tests/cpp/test_host_mirror.cpp include/pcc/point_types.h
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -pthread -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include $< -o $@ -L$(LIBDIR) -lpcc_nn -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-build/comparator: pointcloudcomparator_amd/host/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp pointcloudcomparator_amd/host/report.hpp include/pcc/multi_device.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+build/comparator: examples/comparator_main.cpp pointcloudcomparator_amd/host/ply_io.hpp pointcloudcomparator_amd/host/report.hpp include/pcc/multi_device.hpp include/pcc/point_types.hpp include/pcc/search.hpp include/pcc/comparator_nn.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 

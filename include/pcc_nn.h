@@ -334,6 +334,52 @@ int pcc_region_growing(pcc_index *index, const float *normals, int mem, int k, f
 int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes,
                      int mem, double radius, int32_t *idx);
 
+/* ---- multi-GPU: RCCL over xGMI ---------------------------------------------
+ * The path shards by independent queries: every GPU holds the whole reference cloud and its own index (one pcc_index per
+ * device), queries are split into contiguous shards and searched with the calls above -- no exchange inside a search.
+ * Exchanged are: the reference cloud, once (broadcast); the 17 sums of every ICP pass when the SOURCE cloud is sharded
+ * (all-reduce on the handle's stream, inside the device-resident loop); SOR's statistics when the cloud's points are
+ * sharded.  Clustering does not shard (global union-find): replicas only.
+ * replaces: the single pcl::KdTreeFLANN / pcl::IterativeClosestPoint / pcl::StatisticalOutlierRemoval object per call site
+ *   (src/comparator.cpp:564-577, 1089-1110, 1523-1541) when a node's GPUs share one cloud pair.
+ * A pcc_comm is one rank of an RCCL communicator: one per (process, GPU).  librccl.so.1 is loaded when the first one is
+ * made (dlopen); libpcc_nn.so does not depend on it otherwise. */
+typedef struct pcc_comm pcc_comm;
+#define PCC_COMM_ID_BYTES 128
+/* one process per GPU: rank 0 makes the id (PCC_COMM_ID_BYTES bytes), hands it to the other ranks over whatever launched
+ * them, every rank then calls pcc_comm_create_rank (collective: it returns when all `world` ranks have called) */
+int pcc_comm_unique_id(void *id, size_t bytes);
+int pcc_comm_create_rank(const void *id, size_t bytes, int world, int rank, int device, pcc_comm **out);
+/* one process driving several GPUs: out[k] is rank k on devices[k] (distinct devices).  Collective calls on these handles
+ * must be issued from one thread per device (every rank blocks until the others have joined) */
+int pcc_comm_create_local(const int *devices, int count, pcc_comm **out);
+int pcc_comm_destroy(pcc_comm *comm);
+int pcc_comm_info(const pcc_comm *comm, int *rank, int *world, int *device);
+/* the reference cloud of rank `root` indexed on EVERY rank: root indexes (points, n, stride, mem) as pcc_index_create does,
+ * the packed cloud (16 B per point) is broadcast once over RCCL, every other rank builds its own index over the copy
+ * (0.5 ms at 10M points: cheaper than shipping the index).  Collective; points / n are read on the root only;
+ * *n_out (nullable): the number of points of the cloud, on every rank. */
+int pcc_index_create_broadcast(pcc_comm *comm, int root, const void *points, size_t n, size_t stride_bytes, int mem,
+                               int engine, pcc_index **out, size_t *n_out);
+/* pcc_icp_align with the SOURCE cloud sharded over the ranks (each rank: its shard, its handle over the same target).  Per
+ * pass the 17 double sums are all-reduced (136 bytes) before the solver runs, so every rank applies the same transform;
+ * fitness is the mean squared distance over ALL shards.  With one rank: pcc_icp_align's result, bit for bit.  Collective. */
+int pcc_icp_align_sharded(pcc_index *index, pcc_comm *comm, const void *source_shard, size_t n, size_t stride_bytes, int mem,
+                          int max_iterations, int fixed_iterations, float T[16], double *fitness, int *iterations,
+                          int *converged);
+/* SOR over a shard [start, start + count) of the indexed cloud: the shard's mean distances (memory space `mem`, nullable)
+ * and its share of PCL's statistics -- sums[0] = sum of the means, [1] = sum of their float squares, [2] / [3] = bit
+ * patterns (as doubles) of the smallest positive term of either sum.  Combine over shards with (+, +, min, min), then
+ * pcc_sor_threshold (host arithmetic, no handle): *exact = 0 means PCL's in-order additions would round, i.e. the combined
+ * sums need not carry PCL's last bits (pcc_sor_sharded and pcc_sor then take the sums in index order). */
+int pcc_sor_partial(pcc_index *index, size_t start, size_t count, int mean_k, int mem, float *mean_dist, double sums[4]);
+int pcc_sor_threshold(const double sums[4], uint64_t n_valid, int mean_k, double stddev_mult, double *threshold, int *exact);
+/* pcc_sor over the ranks of `comm`: this rank filters the points [start, start + count) (the ranks' shards tile the cloud);
+ * the statistics are PCL's over the WHOLE cloud (one all-reduce of the sums, one of the smallest terms, one of the kept
+ * count).  mean_dist / inlier: `count` entries in memory space `mem`; *threshold, *kept_total: same on every rank. */
+int pcc_sor_sharded(pcc_index *index, pcc_comm *comm, size_t start, size_t count, int mean_k, double stddev_mult, int mem,
+                    float *mean_dist, uint8_t *inlier, double *threshold, size_t *kept_total);
+
 /* ---- instrumentation ------------------------------------------------------------------
  * counters of the last search on this index (host):
  *  stats[0] queries resolved by the GRID engine, [1] queries sent to the BRUTE

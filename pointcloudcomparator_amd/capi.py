@@ -36,6 +36,8 @@ SYMBOLS = [
     "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
     "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices", "pcc_counts_pairs", "pcc_index_sor_on_device",
+    "pcc_comm_unique_id", "pcc_comm_create_rank", "pcc_comm_create_local", "pcc_comm_destroy", "pcc_comm_info",
+    "pcc_index_create_broadcast", "pcc_icp_align_sharded", "pcc_sor_partial", "pcc_sor_threshold", "pcc_sor_sharded",
 ]
 
 
@@ -108,6 +110,17 @@ def _load() -> C.CDLL:
     lib.pcc_icp_align.argtypes = [vp, vp, sz, sz, i32, i32, i32, C.POINTER(C.c_float),
                                   C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]
     lib.pcc_match_knn.argtypes = [vp, vp, sz, sz, i32, C.c_float, vp, C.POINTER(C.c_int32)]
+    lib.pcc_comm_unique_id.argtypes = [vp, sz]
+    lib.pcc_comm_create_rank.argtypes = [vp, sz, i32, i32, i32, C.POINTER(vp)]
+    lib.pcc_comm_create_local.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    lib.pcc_comm_destroy.argtypes = [vp]
+    lib.pcc_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.pcc_index_create_broadcast.argtypes = [vp, i32, vp, sz, sz, i32, i32, C.POINTER(vp), C.POINTER(sz)]
+    lib.pcc_icp_align_sharded.argtypes = [vp, vp, vp, sz, sz, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                          C.POINTER(i32), C.POINTER(i32)]
+    lib.pcc_sor_partial.argtypes = [vp, sz, sz, i32, i32, vp, C.POINTER(C.c_double)]
+    lib.pcc_sor_threshold.argtypes = [C.POINTER(C.c_double), C.c_uint64, i32, C.c_double, C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.pcc_sor_sharded.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, C.POINTER(C.c_double), C.POINTER(sz)]
     for name in SYMBOLS:
         fn = getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
         if name != "pcc_last_error":
@@ -175,8 +188,80 @@ def rigid_from_sums(sums, center=None):
     return T.reshape(4, 4)
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """the id rank 0 makes and hands to the other ranks (pcc_comm_unique_id)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(LIB.pcc_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class Comm:
+    """one rank of an RCCL communicator (pcc_comm): one per (process, GPU)"""
+
+    def __init__(self, handle):
+        self._c = handle
+
+    @classmethod
+    def from_id(cls, uid: bytes, world: int, rank: int, device: int):
+        h = C.c_void_p()
+        _check(LIB.pcc_comm_create_rank(uid, len(uid), world, rank, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def local(cls, devices):
+        """communicators for several GPUs driven by this process: [rank 0 on devices[0], ...]"""
+        arr = (C.c_int * len(devices))(*devices)
+        hs = (C.c_void_p * len(devices))()
+        _check(LIB.pcc_comm_create_local(arr, len(devices), hs))
+        return [cls(C.c_void_p(h)) for h in hs]
+
+    def info(self):
+        r, w, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(LIB.pcc_comm_info(self._c, C.byref(r), C.byref(w), C.byref(d)))
+        return r.value, w.value, d.value
+
+    def close(self):
+        if self._c:
+            LIB.pcc_comm_destroy(self._c)
+            self._c = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def sor_threshold(sums, n_valid: int, mean_k: int = 50, stddev_mult: float = 1.5):
+    """PCL's threshold from the combined (+, +, min, min) sums of all shards: (threshold, exact)"""
+    sm = (C.c_double * 4)(*[float(v) for v in sums])
+    thr, ex = C.c_double(0), C.c_int(0)
+    _check(LIB.pcc_sor_threshold(sm, int(n_valid), mean_k, float(stddev_mult), C.byref(thr), C.byref(ex)))
+    return thr.value, bool(ex.value)
+
+
 class Index:
     """Owner of one pcc_index handle (the role pcl::KdTreeFLANN plays in the reference)."""
+
+    @classmethod
+    def broadcast(cls, comm: "Comm", root: int, points=None, engine: int = ENGINE_AUTO, auto_sync: bool = True):
+        """the reference cloud of rank `root` indexed on every rank of `comm` (pcc_index_create_broadcast; collective).
+        points: read on the root only."""
+        ptr, n, stride, mem = _points(points) if points is not None else (None, 0, 12, MEM_HOST)
+        if points is not None and _is_torch(points) and points.is_cuda:
+            import torch
+            torch.cuda.current_stream(points.device).synchronize()
+        h = C.c_void_p()
+        n_all = C.c_size_t(0)
+        _check(LIB.pcc_index_create_broadcast(comm._c, root, ptr, n, stride, mem, engine, C.byref(h), C.byref(n_all)))
+        self = cls.__new__(cls)
+        self._h = h
+        self.auto_sync = auto_sync
+        self.n_original = n_all.value
+        return self
 
     def __init__(self, points, engine: int = ENGINE_AUTO, device: int = 0, auto_sync: bool = True):
         """auto_sync: calls that take torch CUDA tensors are ordered against torch's current stream on both
@@ -426,6 +511,32 @@ class Index:
         f = C.c_int(0)
         _check(LIB.pcc_index_sor_on_device(self._h, C.byref(f)))
         return bool(f.value)
+
+    def sor_partial(self, start: int, count: int, mean_k: int = 50):
+        """mean distances of the points [start, start + count) and the shard's share of the statistics (pcc_sor_partial)"""
+        md = np.empty(count, dtype=np.float32)
+        sums = (C.c_double * 4)()
+        _check(LIB.pcc_sor_partial(self._h, start, count, mean_k, MEM_HOST, md.ctypes.data, sums))
+        return md, np.array(list(sums))
+
+    def sor_sharded(self, comm: "Comm", start: int, count: int, mean_k: int = 50, stddev_mult: float = 1.5):
+        md = np.empty(count, dtype=np.float32)
+        inl = np.empty(count, dtype=np.uint8)
+        thr, kept = C.c_double(0), C.c_size_t(0)
+        _check(LIB.pcc_sor_sharded(self._h, comm._c, start, count, mean_k, float(stddev_mult), MEM_HOST, md.ctypes.data,
+                                   inl.ctypes.data, C.byref(thr), C.byref(kept)))
+        return md, inl, thr.value, kept.value
+
+    def icp_align_sharded(self, comm: "Comm", source_shard, max_iter: int = 20, fixed: bool = False):
+        """pcc_icp_align_sharded: (T 4x4, fitness over all shards, iterations, converged)"""
+        ptr, n, stride, mem = _points(source_shard)
+        T = (C.c_float * 16)()
+        fit, it, conv = C.c_double(0), C.c_int(0), C.c_int(0)
+        st = self._before(source_shard)
+        _check(LIB.pcc_icp_align_sharded(self._h, comm._c, ptr, n, stride, mem, max_iter, int(fixed), T, C.byref(fit),
+                                         C.byref(it), C.byref(conv)))
+        self._after(st)
+        return np.array(list(T), dtype=np.float32).reshape(4, 4), fit.value, it.value, bool(conv.value)
 
     def sac_plane(self, points, max_iterations: int = 100, threshold: float = 0.02, probability: float = 0.99,
                   optimize: bool = True):

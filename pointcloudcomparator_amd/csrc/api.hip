@@ -163,7 +163,7 @@ static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride,
     return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys);
 }
 
-static int check_points(const void* pts, size_t n, size_t stride, int mem) {
+int check_points(const void* pts, size_t n, size_t stride, int mem) {
     if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space %d", mem); return PCC_ERR_INVALID; }
     if (n && !pts) { set_error("null point pointer"); return PCC_ERR_INVALID; }
     if (stride < 12 || stride % 4) { set_error("stride %zu must be a multiple of 4 and >= 12", stride); return PCC_ERR_INVALID; }
@@ -172,7 +172,7 @@ static int check_points(const void* pts, size_t n, size_t stride, int mem) {
 }
 
 // queries -> ix->q_packed (float4, w < 0 marks a non-finite query)
-static int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem) {
+int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem) {
     PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
     PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
     // the pack kernel also zeroes the GRID engine's fallback counter (small + 32) and presets the result key of
@@ -196,7 +196,7 @@ static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) 
 
 
 // k = 1 search of ix->q_packed[0..nq) into ix->out_packed (u64 per query)
-static int nn1_packed(pcc_index* ix, size_t nq) {
+int nn1_packed(pcc_index* ix, size_t nq) {
     PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
     auto* out = ix->out_packed.as<unsigned long long>();
     // GRID: every valid query's key is written by the search kernel itself (no 8 MB memset)
@@ -239,7 +239,7 @@ static int set_input_impl(pcc_index* ix, const void* pts, size_t n, size_t strid
 }
 // on any failure the index is left EMPTY (n_orig = 0: every search then answers PCC_ERR_EMPTY instead of
 // launching over buffers a failed reserve() has freed)
-static int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
+int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) {
     ix->n_valid = 0;
     ix->has_grid = false;
     ix->order_valid = false;
@@ -962,7 +962,7 @@ int pcc_sor(pcc_index* ix, int mean_k, double stddev_mult, int mem, float* mean_
     // the host sees 48 bytes.  Round 3 copied the means back, added them up on one host thread and sent a mask: 0.94 ms
     // beside a 1.2 ms search at 1M points
     struct { double sum, sq, thr; unsigned long long kept; unsigned int exact, pad; } hs{};
-    PCC_TRY(ix->scratch_a.reserve((size_t)3 * 1024 * sizeof(double) + 64));
+    PCC_TRY(ix->scratch_a.reserve((size_t)(3 * 1024 + 4) * sizeof(double) + 64));
     PCC_TRY(ix->scratch_b.reserve(no + 64));
     void* st_dev = ix->small.as<char>() + 256;  // (words 64..75 of the small block: free of the search counters)
     uint8_t* dmask = mem == PCC_MEM_DEVICE && inlier ? inlier : ix->scratch_b.as<uint8_t>();
@@ -1068,7 +1068,7 @@ int pcc_icp_step_about(pcc_index* ix, const void* src, size_t n, size_t stride, 
     PCC_TRY(nn1_packed(ix, n));
     const double* center_dev = nullptr;
     if (center) {  // the sums are taken about it (device copy behind the ICP loop state)
-        PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + 3 * sizeof(double)));
+        PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + (3 + 17) * sizeof(double)));
         double* cd = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
         PCC_HIP(hipMemcpyAsync(cd, center, 3 * sizeof(double), hipMemcpyHostToDevice, ix->stream));
         PCC_HIP(hipStreamSynchronize(ix->stream));  // (center is the caller's memory)
@@ -1121,6 +1121,16 @@ int pcc_transform(pcc_index* ix, const float T[16], const void* src, size_t n, s
 
 int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int mem, int max_iter, int fixed,
                   float T[16], double* fitness, int* iterations, int* converged) {
+    return pcc::icp_align_impl(ix, nullptr, src, n, stride, mem, max_iter, fixed, T, fitness, iterations, converged);
+}
+}  // extern "C"
+
+// pcc_icp_align, and -- with `hooks` -- its sharded form: this handle holds one SHARD of the source cloud, the 17 sums of
+// every pass are added up over the ranks (hooks->allreduce_sum_f64: RCCL on the handle's stream, comm.hip) before the
+// solver sees them, so every rank solves the same transform and moves its shard (reference
+// src/comparator.cpp:1089-1110).  With one rank the all-reduce is the identity and the result is pcc_icp_align's, bit for bit.
+int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* src, size_t n, size_t stride, int mem, int max_iter,
+                        int fixed, float T[16], double* fitness, int* iterations, int* converged) {
     PCC_ENTER(ix);
     PCC_TRY(check_points(src, n, stride, mem));
     if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
@@ -1129,6 +1139,7 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     memcpy(T, I, sizeof(I));
     if (iterations) *iterations = 0;
     if (converged) *converged = 0;
+    if (n == 0 && hooks) { set_error("sharded ICP: every rank needs a non-empty shard"); return PCC_ERR_INVALID; }
     if (n == 0) return PCC_OK;
     // the source stays resident: q_packed is the moving cloud, icp_src keeps the input
     PCC_TRY(stage_queries(ix, src, n, stride, mem));
@@ -1139,11 +1150,13 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     double prev_mse = 1.79769313486231570e308;
     // the sums of every pass are taken about a point of the source cloud (k_icp_center: no cancellation in the
     // covariance for clouds far from the origin); it sits behind the loop state in device memory
-    PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + 3 * sizeof(double)));
+    PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + (3 + 17) * sizeof(double)));
     double* center_dev = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
     PCC_TRY(launch_icp_center(ix->stream, ix->q_packed.as<float4>(), n, center_dev));
+    if (hooks) PCC_TRY(hooks->bcast_f64(hooks->ctx, center_dev, 3, 0, ix->stream));  // every rank about rank 0's point
     const int warm_env = ix->opt.icp_warm;         // 0: every pass from scratch (measurements)
-    const int loop_env = ix->opt.icp_device_loop;  // 0: the host-driven loop (kept for comparison: same bits)
+    const int loop_env = hooks ? 1 : ix->opt.icp_device_loop;  // 0: the host-driven loop (kept for comparison: same bits)
+    double* sums_dev = center_dev + 3;  // (sharded: the 17 sums of a pass, all-reduced in place)
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
         pcc_index* ix;
         explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }
@@ -1180,6 +1193,11 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
                                         ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
                                         ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
                                         static_cast<unsigned int*>(ix->pinned) + 40, center_dev));
+                if (hooks) {  // rows -> 17 sums (workgroup order, as the solver adds them) -> sum over the ranks -> solve
+                    PCC_TRY(launch_icp_rows_to_sums(ix->stream, ix->scratch_a.as<double>(), nb, sums_dev));
+                    PCC_TRY(hooks->allreduce_sum_f64(hooks->ctx, sums_dev, 17, ix->stream));
+                    PCC_TRY(launch_icp_solve(ix->stream, sums_dev, 1, st, max_iter, fixed, center_dev));
+                } else
                 PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed, center_dev));
                 // (the transform also zeroes the counters of the next pass's search)
                 unsigned int* zw = ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr;
@@ -1231,6 +1249,15 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
         ev_mark(ix, EV_CALL0);
         PCC_TRY(nn1_packed(ix, n));
         double sums[17];
+        if (hooks) {  // sum of d2 and count over ALL shards
+            int nb = 0;
+            PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(), ix->refs.as<float4>(),
+                                    ix->scratch_a.as<double>(), &nb, nullptr, nullptr, nullptr));
+            PCC_TRY(launch_icp_rows_to_sums(ix->stream, ix->scratch_a.as<double>(), nb, sums_dev));
+            PCC_TRY(hooks->allreduce_sum_f64(hooks->ctx, sums_dev, 17, ix->stream));
+            PCC_HIP(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, ix->stream));
+            PCC_HIP(hipStreamSynchronize(ix->stream));
+        } else
         PCC_TRY(icp_reduce(ix, n, sums));
         ev_mark(ix, EV_CALL1);
         *fitness = sums[16] > 0 ? sums[15] / sums[16] : 1.79769313486231570e308;
@@ -1239,6 +1266,7 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
     return PCC_OK;
 }
 
+extern "C" {
 int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int mem, float threshold,
                   int32_t* out, int32_t* out_size) {
     PCC_ENTER(ix);
@@ -1270,3 +1298,8 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
 }
 
 }  // extern "C"
+
+namespace pcc {
+int make_handle(int device, int engine, pcc_index** out) { return new_handle(device, engine, out); }
+int need_grid(pcc_index* ix) { return ensure_grid(ix); }
+}  // namespace pcc

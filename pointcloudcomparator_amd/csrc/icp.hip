@@ -115,6 +115,20 @@ k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restr
     for (int k = 0; k < 16; ++k) st->Ti[k] = Ti[k];
 }
 
+__global__ void __launch_bounds__(64)
+k_icp_rows_to_sums(const double* __restrict__ partials, int n_blocks, double* __restrict__ sums) {
+    if (threadIdx.x < 17) {
+        double a = 0;
+        for (int b = 0; b < n_blocks; ++b) a += partials[b * 17 + threadIdx.x];  // workgroup order: k_icp_solve's, the host loop's
+        sums[threadIdx.x] = a;
+    }
+}
+int launch_icp_rows_to_sums(hipStream_t s, const double* partials, int n_blocks, double* sums17) {
+    hipLaunchKernelGGL(k_icp_rows_to_sums, dim3(1), dim3(64), 0, s, partials, n_blocks, sums17);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
 int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed,
                      const double* center_dev) {
     hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1024), (size_t)n_blocks * 17 * sizeof(double), s, partials, n_blocks, state,

@@ -480,14 +480,10 @@ k_sor_reduce(const float* __restrict__ m, size_t n, double* __restrict__ part) {
         part[blockIdx.x * 3 + 2] = __longlong_as_double((long long)mm);
     }
 }
-// last bit of a positive float given by its bits (denormals: 2^-149), as a double
-__device__ __forceinline__ double float_last_bit(unsigned int bits) {
-    const int e = (int)(bits >> 23);  // biased exponent; 0: denormal
-    return ldexp(1.0, (e > 0 ? e - 127 : -126) - 23);
-}
+// rows -> {sum, sq, bits(min positive term of sum), bits(min positive term of sq)} as four doubles (the bit patterns are
+// integers below 2^32: exact as doubles, so a MIN all-reduce over ranks can carry them)
 __global__ void __launch_bounds__(1024)
-k_sor_finish(const double* __restrict__ part, int nb, const GridDev* __restrict__ gd, int K, double stddev_mult,
-             SorStats* __restrict__ st) {
+k_sor_finish(const double* __restrict__ part, int nb, double* __restrict__ out4) {
     __shared__ double rs[16], rq[16];
     __shared__ unsigned int rf[16], rg[16];
     double sum = 0.0, sq = 0.0;
@@ -508,16 +504,36 @@ k_sor_finish(const double* __restrict__ part, int nb, const GridDev* __restrict_
     if (threadIdx.x != 0) return;
     sum = 0.0; sq = 0.0;
     for (int w = 0; w < 16; ++w) { sum += rs[w]; sq += rq[w]; fmin = min(fmin, rf[w]); gmin = min(gmin, rg[w]); }
+    out4[0] = sum;
+    out4[1] = sq;
+    out4[2] = (double)fmin;
+    out4[3] = (double)gmin;
+}
+// PCL's mean / variance / threshold from the (possibly all-reduced) sums, and whether the sums are PCL's in-order ones
+__host__ __device__ inline void sor_threshold(const double in4[4], double n_valid, int K, double stddev_mult, double* thr, bool* exact) {
+    const double sum = in4[0], sq = in4[1];
+    const unsigned int fmin = (unsigned int)in4[2], gmin = (unsigned int)in4[3];
+    auto last_bit = [](unsigned int bits) {  // last bit of a positive float given by its bits (denormals: 2^-149), as a double
+        const int e = (int)(bits >> 23);
+        return ldexp(1.0, (e > 0 ? e - 127 : -126) - 23);
+    };
     // no addition rounded if the total, counted in last bits of the smallest positive term, stays below 2^52
-    const bool exact = (fmin == 0x7f800000u || sum < float_last_bit(fmin) * 4503599627370496.0) &&
-                       (gmin == 0x7f800000u || sq < float_last_bit(gmin) * 4503599627370496.0);
+    *exact = (fmin == 0x7f800000u || sum < last_bit(fmin) * 4503599627370496.0) &&
+             (gmin == 0x7f800000u || sq < last_bit(gmin) * 4503599627370496.0);
     // PCL: valid = points with a full neighbourhood (all finite points once the cloud holds K of them)
-    const double valid = gd->n_valid >= (unsigned int)K ? (double)gd->n_valid : 0.0;
+    const double valid = n_valid >= (double)K ? n_valid : 0.0;
     const double mean = sum / valid;
     const double var = (sq - sum * sum / valid) / (valid - 1.0);
-    st->sum = sum;
-    st->sq = sq;
-    st->thr = mean + stddev_mult * sqrt(var);
+    *thr = mean + stddev_mult * sqrt(var);
+}
+__global__ void k_sor_threshold(const double* __restrict__ in4, const GridDev* __restrict__ gd, int K, double stddev_mult,
+                                SorStats* __restrict__ st) {
+    double thr;
+    bool exact;
+    sor_threshold(in4, (double)gd->n_valid, K, stddev_mult, &thr, &exact);
+    st->sum = in4[0];
+    st->sq = in4[1];
+    st->thr = thr;
     st->kept = 0ull;
     st->exact = exact ? 1u : 0u;
 }
@@ -533,16 +549,35 @@ k_sor_mask(const float* __restrict__ m, size_t n, SorStats* __restrict__ st, uin
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st->kept, (unsigned long long)cnt);
 }
-// statistics + threshold + mask of the mean distances m[n] on the stream; stats (device, 48 bytes) and scratch (>= 3 *
-// SOR_RED_BLOCKS doubles) are the caller's
-int launch_sor_stats(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult, double* scratch,
-                     void* stats_dev, uint8_t* inlier_dev) {
+// sums of the mean distances m[n] -> out4 (device, 4 doubles: see k_sor_finish); scratch: >= 3 * SOR_RED_BLOCKS doubles
+int launch_sor_partial(hipStream_t s, const float* m, size_t n, double* scratch, double* out4_dev) {
     const int nb = (int)std::min<size_t>((n + 255) / 256, SOR_RED_BLOCKS);
-    hipLaunchKernelGGL(k_sor_reduce, dim3(nb), dim3(256), 0, s, m, n, scratch);
-    hipLaunchKernelGGL(k_sor_finish, dim3(1), dim3(1024), 0, s, scratch, nb, gd, K, stddev_mult, static_cast<SorStats*>(stats_dev));
-    hipLaunchKernelGGL(k_sor_mask, dim3(nb), dim3(256), 0, s, m, n, static_cast<SorStats*>(stats_dev), inlier_dev);
+    hipLaunchKernelGGL(k_sor_reduce, dim3(nb < 1 ? 1 : nb), dim3(256), 0, s, m, n, scratch);
+    hipLaunchKernelGGL(k_sor_finish, dim3(1), dim3(1024), 0, s, scratch, nb < 1 ? 1 : nb, out4_dev);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
+}
+// threshold from in4 (the sums of the WHOLE cloud) -> stats_dev; mask + kept count of the n means given
+int launch_sor_threshold_mask(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult,
+                              const double* in4_dev, void* stats_dev, uint8_t* inlier_dev) {
+    const int nb = (int)std::min<size_t>((n + 255) / 256, SOR_RED_BLOCKS);
+    hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(1), 0, s, in4_dev, gd, K, stddev_mult, static_cast<SorStats*>(stats_dev));
+    hipLaunchKernelGGL(k_sor_mask, dim3(nb < 1 ? 1 : nb), dim3(256), 0, s, m, n, static_cast<SorStats*>(stats_dev), inlier_dev);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+// statistics + threshold + mask of the mean distances m[n] of a whole cloud; stats (device, 48 bytes) and scratch (>= 3 *
+// SOR_RED_BLOCKS + 4 doubles) are the caller's
+int launch_sor_stats(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult, double* scratch,
+                     void* stats_dev, uint8_t* inlier_dev) {
+    double* out4 = scratch + 3 * SOR_RED_BLOCKS;
+    PCC_TRY(launch_sor_partial(s, m, n, scratch, out4));
+    return launch_sor_threshold_mask(s, m, n, gd, K, stddev_mult, out4, stats_dev, inlier_dev);
+}
+void sor_threshold_host(const double in4[4], double n_valid, int K, double stddev_mult, double* thr, int* exact) {
+    bool e = false;
+    sor_threshold(in4, n_valid, K, stddev_mult, thr, &e);
+    *exact = e ? 1 : 0;
 }
 
 }  // namespace pcc

@@ -232,6 +232,10 @@ int launch_sor_mean(hipStream_t s, const unsigned long long* keys, const float4*
 // {double sum, sq, thr; uint64 kept; uint32 exact, pad}: exact == 0 -> the tree sums may differ from PCL's in-order sums
 int launch_sor_stats(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult, double* scratch,
                      void* stats_dev, uint8_t* inlier_dev);
+int launch_sor_partial(hipStream_t s, const float* m, size_t n, double* scratch, double* out4_dev);
+int launch_sor_threshold_mask(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult,
+                              const double* in4_dev, void* stats_dev, uint8_t* inlier_dev);
+void sor_threshold_host(const double in4[4], double n_valid, int K, double stddev_mult, double* thr, int* exact);
 int launch_copy_row_prefix(hipStream_t s, const unsigned long long* src, int k_src, unsigned long long* dst, int k_dst, size_t n);
 
 // ---- exhaustive engine (nn1_brute.hip) -------------------------------------------
@@ -311,5 +315,22 @@ struct IcpState {
 int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed,
                      const double* center_dev);
 int launch_icp_center(hipStream_t s, const float4* src, size_t n, double* center_dev);  // first valid point of src
+// the per-workgroup rows added up in workgroup order (what k_icp_solve does before it solves): sums17[k] on the device
+int launch_icp_rows_to_sums(hipStream_t s, const double* partials, int n_blocks, double* sums17);
+// collectives of the sharded ICP loop, supplied by comm.hip (RCCL on the handle's stream); api.hip knows no RCCL type
+struct IcpHooks {
+    void* ctx;
+    int (*allreduce_sum_f64)(void* ctx, double* dev, int count, hipStream_t s);
+    int (*bcast_f64)(void* ctx, double* dev, int count, int root, hipStream_t s);
+};
+int icp_align_impl(pcc_index* ix, const IcpHooks* hooks, const void* src, size_t n, size_t stride, int mem, int max_iter, int fixed,
+                   float T[16], double* fitness, int* iterations, int* converged);
+// ---- api.hip internals comm.hip builds on -------------------------------------------------------------------------
+int check_points(const void* pts, size_t n, size_t stride, int mem);
+int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem);
+int nn1_packed(pcc_index* ix, size_t nq);
+int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem);
+int need_grid(pcc_index* ix);                              // (the GRID engine's index, built on demand)
+int make_handle(int device, int engine, pcc_index** out);  // an empty handle on `device`
 
 }  // namespace pcc

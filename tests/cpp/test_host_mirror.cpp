@@ -209,6 +209,31 @@ int main() {
     for (auto& p : moved->points) { p.x += 0.01f; p.y -= 0.005f; }
     REQUIRE(performICP(moved, cloud));
 
+    // the RCCL form of the sharded tree on the one GPU present (a one-rank communicator: broadcast and all-reduces run for
+    // real): sharded ICP == pcl-shaped IterativeClosestPoint, sharded SOR == pcc_sor, bit for bit
+    {
+        ShardedKdTree<PointXYZRGB> rt(std::vector<int>{0});
+        rt.setUseRccl(true);
+        rt.setInputCloud(cloud);
+        REQUIRE(rt.hasCollectives() && rt.shards() == 1);
+        std::vector<int> i1, i2; std::vector<float> d1, d2b;
+        tree->nearestKSearchBatch(*cloud, i1, d1);
+        rt.nearestKSearchBatch(*cloud, i2, d2b);
+        REQUIRE(i1 == i2 && d1 == d2b);
+        IterativeClosestPoint<PointXYZRGB, PointXYZRGB> icp;
+        icp.setMaximumIterations(20); icp.setInputSource(moved); icp.setInputTarget(cloud);
+        PointCloud<PointXYZRGB> fin;
+        icp.align(fin);
+        std::array<float, 16> Ts; double fit = 0; int its = 0; bool conv = false;
+        rt.icpAlign(*moved, 20, Ts, fit, its, conv);
+        REQUIRE(Ts == icp.getFinalTransformation() && fit == icp.getFitnessScore() && its == icp.getIterations() && conv == icp.hasConverged());
+        std::vector<float> m1(cloud->size()), m2; std::vector<uint8_t> in1(cloud->size()), in2; double t1 = 0, t2 = 0; size_t k1 = 0, k2 = 0;
+        REQUIRE(pcc_sor(rt.handle(0), 50, 1.5, PCC_MEM_HOST, m1.data(), in1.data(), &t1, &k1) == PCC_OK);
+        rt.sor(50, 1.5, m2, in2, t2, k2);
+        REQUIRE(m1 == m2 && in1 == in2 && t1 == t2 && k1 == k2);
+        std::printf("sharded tree over RCCL (1 rank): ICP %d iterations, fitness %.6g; SOR kept %zu of %zu\n", its, fit, k2, cloud->size());
+    }
+
     // matchRIFTFeaturesKnn (src/comparator.cpp:560-588): identical descriptor sets match 1:1
     PointCloud<RIFT32>::Ptr d1(new PointCloud<RIFT32>), dd(new PointCloud<RIFT32>);
     for (int i = 0; i < 300; ++i) { RIFT32 h; for (float& v : h.histogram) v = U(rng); d1->push_back(h); }

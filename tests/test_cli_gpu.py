@@ -1,4 +1,4 @@
-"""The comparator CLI (pointcloudcomparator_amd/host/comparator_main.cpp) end to end on the GPU:
+"""The example CLI (examples/comparator_main.cpp: the reference's call sites over the pcc:: shim) end to end on the GPU:
 flags, banner lines, section strings and the numbers behind them (checked against the oracle)."""
 import subprocess
 from pathlib import Path
