@@ -566,6 +566,36 @@ def main():
         extra["c5"] = c5
         out["extra"] = extra
 
+    # the C-ABI's own RCCL path (pcc_comm_create_rank + pcc_index_create_broadcast: what a C++ host without torch uses),
+    # beside torch.distributed's: the same cloud broadcast through libpcc_nn, one shard searched, bits compared with the
+    # index built from torch's broadcast.  Opt-in (PCC_BENCH_CABI_COMM=1; tests/test_bench_gpu.py runs it with one rank):
+    # a second communicator on an untried node is not worth risking the headline line for
+    if dist is not None and os.environ.get("PCC_BENCH_CABI_COMM", "0") == "1" and backend == "nccl":
+        M, N = 1_000_000, 250_000
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = capi.Comm.from_id(uid[0], n_gpus, rank, dev_index)
+        ref_host = make_cloud(M, synth.SEED_A, 3) if rank == 0 else None
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        bx = capi.Index.broadcast(comm, 0, ref_host)
+        ms = max_over_ranks((time.perf_counter() - t0) * 1e3)
+        ref_t = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        if rank == 0:
+            ref_t.copy_(torch.from_numpy(ref_host))
+        dist.broadcast(ref_t, src=0)
+        q = torch.from_numpy(make_cloud(N, synth.SEED_B, 3, start=rank * N)).to(dev)
+        with capi.Index(ref_t) as tx:
+            i1, d1 = tx.nn1(q)
+            i2, d2_ = bx.nn1(q)
+            same = bool((i1 == i2).all().item() and (d1.view(torch.int32) == d2_.view(torch.int32)).all().item())
+        ok = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        out.setdefault("extra", {})["c_abi_comm"] = {"ranks": comm.info()[1], "references": M, "create_broadcast_ms": ms,
+                                                       "shard_results_equal_torch_broadcast_index": bool(ok.item() == 1.0)}
+        bx.close()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -131,15 +131,14 @@ public:
         k_sqr_distances.clear();
         if (!handle() || !isFinite(p)) return 0;
         int32_t cnt = 0;
-        check(pcc_radius_count(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, &cnt));
+        // (max_nn != 0: FLANN keeps the max_nn nearest within the radius, ascending -- the _max entry points)
+        check(pcc_radius_count_max(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, max_nn, &cnt));
         if (cnt == 0) return 0;
         int64_t offs[2] = {0, cnt};
         k_indices.resize(cnt);
         k_sqr_distances.resize(cnt);
-        // max_nn != 0 truncates the SORTED list (FLANN keeps the max_nn nearest)
-        check(pcc_radius_fill(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, (sorted_ || max_nn) ? 1 : 0, offs,
-                              k_indices.data(), k_sqr_distances.data()));
-        if (max_nn && (unsigned)cnt > max_nn) { k_indices.resize(max_nn); k_sqr_distances.resize(max_nn); cnt = (int32_t)max_nn; }
+        check(pcc_radius_fill_max(index_, &p, 1, sizeof(PointT), PCC_MEM_HOST, radius, sorted_ ? 1 : 0, max_nn, offs,
+                                  k_indices.data(), k_sqr_distances.data()));
         remap(k_indices);
         return cnt;
     }

@@ -186,6 +186,14 @@ int pcc_radius_count(pcc_index *index, const void *queries, size_t nq,
 int pcc_radius_fill(pcc_index *index, const void *queries, size_t nq,
                     size_t stride_bytes, int mem, double radius, int sorted,
                     const int64_t *offsets, int32_t *idx, float *d2);
+/* the same with radiusSearch's max_nn: 0, or anything from the cloud's size on, means "all" and is the
+ * pair above; otherwise the count is min(count, max_nn) and the row holds the max_nn NEAREST neighbours within the radius,
+ * ascending by (d2, idx) whatever `sorted` says (FLANN's KNNRadiusResultSet).  Served by the k-NN kernels with k = max_nn
+ * cut at the radius: the reference's own call sites pass 0 (src/segmentation.cpp:125-131), this is for completeness. */
+int pcc_radius_count_max(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes, int mem, double radius,
+                         unsigned int max_nn, int32_t *counts);
+int pcc_radius_fill_max(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes, int mem, double radius,
+                        int sorted, unsigned int max_nn, const int64_t *offsets, int32_t *idx, float *d2);
 
 /* ---- Euclidean clustering -----------------------------------------------------
  * replaces: pcl::EuclideanClusterExtraction::extract with

@@ -28,7 +28,7 @@ SYMBOLS = [
     "pcc_version", "pcc_last_error", "pcc_device_count",
     "pcc_index_create", "pcc_index_destroy", "pcc_index_size", "pcc_index_set_stream",
     "pcc_index_sync", "pcc_index_engine", "pcc_index_set_engine",
-    "pcc_nn1", "pcc_knn", "pcc_radius_count", "pcc_radius_fill",
+    "pcc_nn1", "pcc_knn", "pcc_radius_count", "pcc_radius_fill", "pcc_radius_count_max", "pcc_radius_fill_max",
     "pcc_euclidean_clusters", "pcc_sor", "pcc_icp_step", "pcc_transform", "pcc_icp_align",
     "pcc_match_knn", "pcc_index_stats", "pcc_index_set_input", "pcc_index_enable_timing",
     "pcc_index_timing", "pcc_first_within", "pcc_voxel_grid",
@@ -102,6 +102,8 @@ def _load() -> C.CDLL:
     lib.pcc_region_growing.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
     lib.pcc_voxel_grid.argtypes = [vp, vp, sz, sz, i32, C.c_float, i32, vp, sz, C.POINTER(sz)]
     lib.pcc_radius_fill.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, vp, vp, vp]
+    lib.pcc_radius_count_max.argtypes = [vp, vp, sz, sz, i32, C.c_double, C.c_uint, vp]
+    lib.pcc_radius_fill_max.argtypes = [vp, vp, sz, sz, i32, C.c_double, i32, C.c_uint, vp, vp, vp]
     lib.pcc_euclidean_clusters.argtypes = [vp, C.c_double, C.c_uint32, C.c_uint32, i32, vp,
                                            C.POINTER(C.c_int32), vp, i32]
     lib.pcc_sor.argtypes = [vp, i32, C.c_double, i32, vp, vp, C.POINTER(C.c_double), C.POINTER(sz)]
@@ -420,11 +422,11 @@ class Index:
         self._after(st)
         return idx, d2
 
-    def radius_count(self, queries, radius: float):
+    def radius_count(self, queries, radius: float, max_nn: int = 0):
         ptr, n, stride, mem = _points(queries)
         cnt, pc = _out(queries, (n,), np.int32)
         st = self._before(queries)
-        _check(LIB.pcc_radius_count(self._h, ptr, n, stride, mem, float(radius), pc))
+        _check(LIB.pcc_radius_count_max(self._h, ptr, n, stride, mem, float(radius), int(max_nn), pc))
         self._after(st)
         return cnt
 
@@ -447,10 +449,10 @@ class Index:
         self._after(st)
         return idx
 
-    def radius_search(self, queries, radius: float, sorted: bool = True):
-        """CSR (offsets, idx, d2) of all neighbours with d2 < float(radius^2)."""
+    def radius_search(self, queries, radius: float, sorted: bool = True, max_nn: int = 0):
+        """CSR (offsets, idx, d2) of all neighbours with d2 < float(radius^2); max_nn > 0: the max_nn nearest of them."""
         ptr, n, stride, mem = _points(queries)
-        cnt = self.radius_count(queries, radius)
+        cnt = self.radius_count(queries, radius, max_nn)
         if _is_torch(cnt):
             import torch
             if not self.auto_sync:
@@ -467,7 +469,7 @@ class Index:
         idx, pi = _out(queries, (max(total, 1),), np.int32)
         d2, pd = _out(queries, (max(total, 1),), np.float32)
         st = self._before(queries, offs)
-        _check(LIB.pcc_radius_fill(self._h, ptr, n, stride, mem, float(radius), int(sorted), po, pi, pd))
+        _check(LIB.pcc_radius_fill_max(self._h, ptr, n, stride, mem, float(radius), int(sorted), int(max_nn), po, pi, pd))
         self._after(st)
         return offs, idx[:total], d2[:total]
 

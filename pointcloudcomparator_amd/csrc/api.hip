@@ -654,6 +654,10 @@ int pcc_knn(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
 static inline float radius2(double radius) { return (float)(radius * radius); }
 
 int pcc_radius_count(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int32_t* counts) {
+    return pcc_radius_count_max(ix, q, nq, stride, mem, radius, 0u, counts);
+}
+int pcc_radius_count_max(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, unsigned int max_nn,
+                         int32_t* counts) {
     PCC_ENTER(ix);
     PCC_TRY(check_points(q, nq, stride, mem));
     if (!counts) { set_error("null counts"); return PCC_ERR_INVALID; }
@@ -667,9 +671,73 @@ int pcc_radius_count(pcc_index* ix, const void* q, size_t nq, size_t stride, int
     if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(nq * sizeof(int32_t))); dcnt = ix->out_idx.as<int32_t>(); }
     PCC_HIP(hipMemsetAsync(dcnt, 0, nq * sizeof(int32_t), ix->stream));
     PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), dcnt, nullptr, nullptr, 0));
+    // KdTreeFLANN::radiusSearch(..., max_nn): 0 or anything from the cloud's size on means "all"; else FLANN keeps the
+    // max_nn nearest within the radius
+    if (max_nn != 0 && (size_t)max_nn < ix->n_orig) PCC_TRY(launch_clamp_counts(ix->stream, dcnt, nq, (int32_t)std::min<unsigned int>(max_nn, 0x7fffffffu)));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, dcnt, counts, nq, mem));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return PCC_OK;
+}
+
+int pcc_radius_fill_max(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int sorted, unsigned int max_nn,
+                        const int64_t* offsets, int32_t* idx, float* d2) {
+    if (!ix) { set_error("null index"); return PCC_ERR_INVALID; }
+    if (max_nn == 0 || (size_t)max_nn >= ix->n_orig) return pcc_radius_fill(ix, q, nq, stride, mem, radius, sorted, offsets, idx, d2);
+    // the max_nn NEAREST within the radius, ascending (FLANN's KNNRadiusResultSet, whatever `sorted` says): the k-NN rows
+    // with k = max_nn, cut at the radius.  Unused by the reference's own call sites (src/segmentation.cpp:125-131 passes 0):
+    // correctness first, no kernel of its own
+    PCC_ENTER(ix);
+    PCC_TRY(check_points(q, nq, stride, mem));
+    if (!offsets) { set_error("null offsets"); return PCC_ERR_INVALID; }
+    if (!(radius >= 0)) { set_error("bad radius"); return PCC_ERR_INVALID; }
+    if (max_nn > (unsigned int)PCC_KNN_MAX_K) { set_error("max_nn=%u beyond %d", max_nn, PCC_KNN_MAX_K); return PCC_ERR_UNSUPPORTED; }
+    if (nq == 0) return PCC_OK;
+    PCC_TRY(ensure_grid(ix));
+    PCC_TRY(stage_queries(ix, q, nq, stride, mem));
+    const int K = (int)max_nn;
+    int64_t total = 0;
+    const int64_t* doff = offsets;
+    if (mem == PCC_MEM_HOST) {
+        total = offsets[nq];
+        PCC_TRY(ix->scratch_d.reserve((nq + 1) * sizeof(int64_t)));
+        PCC_HIP(hipMemcpyAsync(ix->scratch_d.p, offsets, (nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream));
+        doff = ix->scratch_d.as<int64_t>();
+    } else {
+        PCC_HIP(hipMemcpyAsync(&total, offsets + nq, sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
+    if (total < 0) { set_error("negative total"); return PCC_ERR_INVALID; }
+    if (total == 0) return PCC_OK;
+    const bool rows = grid_knn_delivers(K);
+    unsigned long long* keys = nullptr;
+    int32_t* ridx = nullptr;
+    float* rd2 = nullptr;
+    if (rows) {
+        PCC_TRY(ix->scratch_e.reserve(nq * (size_t)K * sizeof(int32_t)));
+        PCC_TRY(ix->scratch_f.reserve(nq * (size_t)K * sizeof(float)));
+        ridx = ix->scratch_e.as<int32_t>();
+        rd2 = ix->scratch_f.as<float>();
+        PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, K, nullptr, ridx, rd2));
+    } else {
+        PCC_TRY(ix->out_packed.reserve(nq * (size_t)K * sizeof(unsigned long long)));
+        keys = ix->out_packed.as<unsigned long long>();
+        PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, K, keys));
+    }
+    int32_t* didx = idx;
+    float* dd2 = d2;
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(ix->out_idx.reserve((size_t)total * sizeof(int32_t)));
+        PCC_TRY(ix->out_d2.reserve((size_t)total * sizeof(float)));
+        didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
+        dd2 = d2 ? ix->out_d2.as<float>() : nullptr;
+    }
+    PCC_TRY(launch_knn_rows_to_csr(ix->stream, keys, ridx, rd2, K, radius2(radius), doff, nq, didx, dd2));
+    if (mem == PCC_MEM_HOST) {
+        PCC_TRY(deliver(ix, didx, idx, (size_t)total, mem));
+        PCC_TRY(deliver(ix, dd2, d2, (size_t)total, mem));
         PCC_HIP(hipStreamSynchronize(ix->stream));
     }
     return PCC_OK;

@@ -580,4 +580,48 @@ void sor_threshold_host(const double in4[4], double n_valid, int K, double stdde
     *exact = e ? 1 : 0;
 }
 
+// ---- radiusSearch(..., max_nn): FLANN keeps the max_nn NEAREST neighbours within the radius (KNNRadiusResultSet) --------
+__global__ void __launch_bounds__(256)
+k_clamp_counts(int32_t* __restrict__ counts, size_t n, int32_t cap) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) counts[i] = min(counts[i], cap);
+}
+int launch_clamp_counts(hipStream_t s, int32_t* counts, size_t n, int32_t cap) {
+    if (n == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(n, 256)), dim3(256), 0, s, counts, n, cap);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+// k-NN rows (K ascending entries per query; keys, or idx / d2 rows) -> CSR rows: entry e of query i is the e-th nearest
+// neighbour if it lies within the radius (d2 < r2, strict), else "nothing found"
+__global__ void __launch_bounds__(256)
+k_knn_rows_to_csr(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ ridx, const float* __restrict__ rd2, int K,
+                  float r2, const int64_t* __restrict__ offsets, size_t nq, int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
+        const int64_t b = offsets[i], len = offsets[i + 1] - b;
+        for (int64_t e = 0; e < len; ++e) {
+            int32_t id = -1;
+            float d = __builtin_inff();
+            if (e < K) {
+                if (keys) {
+                    const unsigned long long key = keys[i * (size_t)K + e];
+                    if (!key_none(key)) { id = (int32_t)(unsigned int)key; d = __uint_as_float((unsigned int)(key >> 32)); }
+                } else {
+                    id = ridx[i * (size_t)K + e];
+                    d = rd2[i * (size_t)K + e];
+                }
+            }
+            const bool in = id >= 0 && d < r2;
+            if (idx_out) idx_out[b + e] = in ? id : -1;
+            if (d2_out) d2_out[b + e] = in ? d : __builtin_inff();
+        }
+    }
+}
+int launch_knn_rows_to_csr(hipStream_t s, const unsigned long long* keys, const int32_t* ridx, const float* rd2, int K, float r2,
+                           const int64_t* offsets, size_t nq, int32_t* idx_out, float* d2_out) {
+    if (nq == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_knn_rows_to_csr, dim3(grid_for(nq, 256)), dim3(256), 0, s, keys, ridx, rd2, K, r2, offsets, nq, idx_out, d2_out);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
 }  // namespace pcc

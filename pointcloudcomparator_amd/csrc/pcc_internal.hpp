@@ -236,6 +236,9 @@ int launch_sor_partial(hipStream_t s, const float* m, size_t n, double* scratch,
 int launch_sor_threshold_mask(hipStream_t s, const float* m, size_t n, const GridDev* gd, int K, double stddev_mult,
                               const double* in4_dev, void* stats_dev, uint8_t* inlier_dev);
 void sor_threshold_host(const double in4[4], double n_valid, int K, double stddev_mult, double* thr, int* exact);
+int launch_clamp_counts(hipStream_t s, int32_t* counts, size_t n, int32_t cap);
+int launch_knn_rows_to_csr(hipStream_t s, const unsigned long long* keys, const int32_t* ridx, const float* rd2, int K, float r2,
+                           const int64_t* offsets, size_t nq, int32_t* idx_out, float* d2_out);
 int launch_copy_row_prefix(hipStream_t s, const unsigned long long* src, int k_src, unsigned long long* dst, int k_dst, size_t n);
 
 // ---- exhaustive engine (nn1_brute.hip) -------------------------------------------

@@ -23,8 +23,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_rank(extra_args, timeout=600):
+def _run_rank(extra_args, timeout=600, more_env=None):
     env = dict(os.environ)
+    env.update(more_env or {})
     env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                 "MASTER_PORT": str(_free_port()), "PCC_BENCH_BACKEND": "nccl", "PCC_BENCH_FORCE_GROUP": "1",
                 "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
@@ -37,7 +38,9 @@ def _run_rank(extra_args, timeout=600):
 
 
 def test_single_rank_rccl_group_runs_the_multi_gpu_path():
-    out = _run_rank(["--config", "c2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-exhaustive"])
+    out = _run_rank(["--config", "c2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-exhaustive"], more_env={"PCC_BENCH_CABI_COMM": "1"})
+    cabi = out["extra"]["c_abi_comm"]               # the library's own RCCL communicator next to torch's
+    assert cabi["ranks"] == 1 and cabi["shard_results_equal_torch_broadcast_index"] and cabi["create_broadcast_ms"] > 0
     assert out["n_gpus"] == 1                      # the size RCCL's process group reported
     assert out["config"]["backend"] == "nccl"
     assert "RCCL" in out["config"]["parallelism"]

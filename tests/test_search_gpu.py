@@ -199,6 +199,33 @@ def test_sor_statistics_on_the_device_and_the_in_order_fallback(gpu):
     assert (_bits(md) == _bits(omd)).all() and thr == othr and (inl == oinl).all() and kept == okept
 
 
+@pytest.mark.parametrize("max_nn", [1, 7, 60, 600])
+def test_radius_search_with_max_nn_keeps_the_nearest(gpu, max_nn):
+    """KdTreeFLANN::radiusSearch(..., max_nn): FLANN's KNNRadiusResultSet keeps the max_nn nearest within the radius,
+    ascending; counts are min(count, max_nn).  Against the oracle's full sorted rows cut at max_nn."""
+    import torch
+    rng = np.random.default_rng(2)
+    a = np.concatenate([rng.normal(0, 0.12, (15000, 3)), rng.random((5000, 3)) * 2 - 1]).astype(np.float32)  # a blob: rows of up to ~1500
+    q = np.concatenate([a[:400] + np.float32(0.003), np.array([[50, 50, 50], [np.nan, 0, 0]], np.float32)])
+    r = 0.12
+    tree = oracle.KdTree(a)
+    with capi.Index(a) as ix:
+        for queries in (q, torch.from_numpy(q).cuda()):
+            offs, idx, d2 = ix.radius_search(queries, r, sorted=False, max_nn=max_nn)
+            if not isinstance(offs, np.ndarray):
+                offs, idx, d2 = offs.cpu().numpy(), idx.cpu().numpy(), d2.cpu().numpy()
+            full = ix.radius_count(q, r)
+            assert (np.diff(offs) == np.minimum(full, max_nn)).all() and (full.max() > max_nn or max_nn >= 600)
+            for j in range(len(q) - 1):
+                oi, od = tree.radius(q[j], r)
+                assert (idx[offs[j]:offs[j + 1]] == oi[:max_nn]).all() and (_bits(d2[offs[j]:offs[j + 1]]) == _bits(od[:max_nn])).all()
+            assert offs[-1] == offs[-2]            # the non-finite query finds nothing
+        # max_nn at or beyond the cloud's size means "all"
+        o1, i1, e1 = ix.radius_search(q[:50], r, sorted=True, max_nn=len(a))
+        o2, i2, e2 = ix.radius_search(q[:50], r, sorted=True)
+        assert (o1 == o2).all() and (i1 == i2).all() and (_bits(e1) == _bits(e2)).all()
+
+
 def test_transform_bits(gpu):
     pts = _scene(5000)
     a = np.deg2rad(7.0)

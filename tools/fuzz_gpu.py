@@ -114,6 +114,7 @@ def main():
     n_cases = 0
     fails = {}
     counts = {}
+    tolerated = {}
 
     def check(op, ok, **dump):
         counts[op] = counts.get(op, 0) + 1
@@ -151,6 +152,7 @@ def main():
                 # the forms of the pruned k = 1 kernel: one lane per query / rows drained flat (open lanes finished in
                 # place or listed for a second kernel)
                 ix.set_option(capi.OPT_NN1_KERNEL, int(rng.integers(0, 4)))
+                ix.set_option(capi.OPT_NN1_OPEN_FLAT, int(rng.random() < 0.7))  # listed open lanes: drained flat / one lane each
                 ix.set_option(capi.OPT_KNN_KERNEL, int(rng.random() < 0.8))
                 ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([1, 1, 2, 0])))
                 if rng.random() < 0.2:
@@ -158,7 +160,7 @@ def main():
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
                 check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
-                op = rng.integers(0, 10)
+                op = rng.integers(0, 11)
                 if args.trace:
                     with open(args.trace, "a") as f:
                         f.write(f"  nn1 done, op {op}\n")
@@ -275,6 +277,23 @@ def main():
                     xi, xd = oracle.nn1_exhaustive(a, q)
                     at_min = bits(td) == bits(xd)
                     check("ties_flann", (bits(fd) == bits(xd)).all() and (fi[at_min] == ti[at_min]).all(), a=a, q=q, engine=engine)
+                elif op == 10 and 20 <= n_valid == m <= 15000 and float(np.abs(a[:, :3]).max()) < 1e6:
+                    # normals on the library's own neighbour rows: bit-identical to the oracle except through the three libm
+                    # calls of the cubic's closed form -- a TOLERATED deviation class, counted in the open:
+                    # points whose bits differ must stay within 1e-6 (direction) / 3e-7 (curvature)
+                    k = int(rng.integers(5, min(m, 51)))
+                    nrm = ix.normals(k)
+                    nbr, _ = ix.knn(a, k)
+                    want = oracle.normals(a, k, neighbours=nbr)
+                    fin_rows = np.isfinite(want).all(1) & np.isfinite(nrm).all(1)
+                    ok = (np.isfinite(want).all(1) == np.isfinite(nrm).all(1)).all()
+                    diff = (bits(nrm) != bits(want)).any(1) & fin_rows
+                    if diff.any():
+                        dots = np.abs((nrm[diff, :3].astype(np.float64) * want[diff, :3]).sum(1))
+                        ok = ok and (dots > 1 - 1e-6).all() and np.allclose(nrm[diff, 3], want[diff, 3], rtol=0, atol=3e-7)
+                    tolerated["normals_points_checked"] = tolerated.get("normals_points_checked", 0) + int(fin_rows.sum())
+                    tolerated["normals_points_within_ulps"] = tolerated.get("normals_points_within_ulps", 0) + int(diff.sum())
+                    check("normals", ok, a=a, k=k)
                 elif op == 5 and n_valid >= 3 and np.isfinite(q[:, :3]).all():
                     i2, dd, sums = ix.icp_step(q)
                     check("icp_step", (i2 == oi).all() and (bits(dd) == bits(od)).all(), a=a, q=q)
@@ -284,6 +303,12 @@ def main():
             check("status", ("empty" in msg) or ("no valid" in msg) or ("non-finite" in msg), a=a, q=q, msg=np.array(msg))
         if n_cases % 50 == 0:
             print(f"{n_cases} cases, {sum(counts.values())} checks, failures {fails}", flush=True)
+    # the two deviation classes the harness tolerates, in the open (neither is a bit-identical result):
+    #   sor_flann_inexact: SOR rows where the oracle's kd-tree walk (FLANN's) misses the float minimum and the library's row
+    #                      was verified against the exhaustive search instead;
+    #   normals_*: points whose normal / curvature bits differ from the oracle's within the stated tolerance (libm)
+    tolerated["sor_flann_inexact"] = counts.get("sor_flann_inexact", 0)
+    print(f"TOLERATED {tolerated}", flush=True)
     print(f"DONE {n_cases} cases; checks {counts}; failures {fails}", flush=True)
     return 1 if fails else 0
 
