@@ -26,7 +26,7 @@ $(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu build/ubench_gather
 hosttest: build/test_host_mirror build/test_lane_ops build/test_report
-cli: build/comparator build/ply_dump
+cli: build/comparator build/ply_dump build/rgb_segments
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
 	@mkdir -p build
@@ -61,6 +61,10 @@ build/comparator: examples/comparator_main.cpp pointcloudcomparator_amd/host/ply
 	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 build/test_report: tests/cpp/test_report.cpp pointcloudcomparator_amd/host/report.hpp include/pcc/comparator_nn.hpp include/pcc/search.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+build/rgb_segments: tests/cpp/rgb_segments.cpp include/pcc/region_growing_rgb.hpp include/pcc/search.hpp include/pcc/point_types.hpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 

@@ -1,0 +1,268 @@
+// region_growing_rgb.hpp -- pcl::RegionGrowingRGB as the reference uses it in color_growing_segmentation
+// (src/segmentation.cpp:161-216: distance threshold 10, point colour threshold 6, region colour threshold 5, minimum
+// cluster size 200; called twice per accepted match, src/comparator.cpp:1466-1500, where only the NUMBER of colour
+// segments enters the report).
+//
+// Where the time goes in PCL: findPointNeighbours() -- one nearestKSearch with 100 neighbours per point.  That is the
+// part this repository accelerates: ONE batched self k-NN on the GPU (pcc_knn, rows ascending by (d2, index)).  What PCL
+// does with the rows is sequential, order-dependent host logic and stays host logic here, statement for statement in
+// PCL's order (restated from PCL 1.7's region_growing.hpp / region_growing_rgb.hpp -- SURVEY.md 9 has no section for
+// it; the same recollection, written independently, is the oracle's orc_region_growing_rgb):
+//   1. growing: seeds in index order, breadth first over the first `neighbour_number_` (30) neighbours of a point, a
+//      neighbour joins when its squared colour distance to the CURRENT point is <= point threshold^2; every joined point
+//      spreads (no normals, no curvature test in this configuration);
+//   2. segment neighbours: per segment the `region_neighbour_number_` (100) nearest other segments, by the smallest
+//      neighbour distance over its points' rows;
+//   3. merging: segments whose MEAN colours (float sums in index order, truncated to integers) differ by less than
+//      region threshold^2 and that lie within distance threshold^2 join a homogeneous region; regions below the minimum
+//      size are folded into their nearest neighbouring region;
+//   4. clusters outside [min, max] size are dropped.
+// PCL orders a region's neighbour list with std::sort, which leaves the order of equal distances unspecified; this mirror
+// (and the oracle) use a stable sort -- one of the orders PCL may produce.
+#pragma once
+#include <algorithm>
+#include <limits>
+#include <queue>
+#include <utility>
+#include <vector>
+#include "pcc/search.hpp"
+
+namespace pcc {
+
+template <class PointT>
+class RegionGrowingRGB {
+public:
+    typedef typename PointCloud<PointT>::ConstPtr CloudConstPtr;
+    typedef typename search::KdTree<PointT>::Ptr KdTreePtr;
+    void setInputCloud(const CloudConstPtr& c) { input_ = c; }
+    void setSearchMethod(const KdTreePtr& t) { search_ = t; }
+    void setDistanceThreshold(float t) { distance_threshold_ = t * t; }
+    void setPointColorThreshold(float t) { color_p2p_threshold_ = t * t; }
+    void setRegionColorThreshold(float t) { color_r2r_threshold_ = t * t; }
+    void setMinClusterSize(int n) { min_pts_per_cluster_ = n; }
+    void setMaxClusterSize(int n) { max_pts_per_cluster_ = n; }
+    void setNumberOfNeighbours(unsigned int k) { neighbour_number_ = k; }
+    void setNumberOfRegionNeighbours(unsigned int k) { region_neighbour_number_ = k; }
+
+    void extract(std::vector<PointIndices>& clusters) {
+        clusters.clear();
+        if (!input_ || input_->empty()) return;
+        if (region_neighbour_number_ == 0 || neighbour_number_ == 0 || color_p2p_threshold_ < 0.f || color_r2r_threshold_ < 0.f ||
+            distance_threshold_ < 0.f)
+            return;
+        if (!search_) search_.reset(new search::KdTree<PointT>);
+        search_->setInputCloud(input_);
+        n_ = input_->size();
+        findPointNeighbours();
+        growSegments();
+        findSegmentNeighbours();
+        mergeRegions();
+        for (const PointIndices& c : clusters_)
+            if ((int)c.indices.size() >= min_pts_per_cluster_ && (int)c.indices.size() <= max_pts_per_cluster_) clusters.push_back(c);
+    }
+
+private:
+    // rows of the self k-NN: row_len_ entries per point, ascending by (d2, index) -- the one GPU call of this class
+    void findPointNeighbours() {
+        row_len_ = (int)std::min<size_t>(region_neighbour_number_, n_);
+        search_->nearestKSearchBatch(*input_, row_len_, nbr_, nbr_d2_);
+        // (rows of non-finite points hold -1: color_growing_segmentation strips NaNs first, PCL would assert on them)
+    }
+    static unsigned int colourDiff(const PointT& a, const PointT& b) {
+        const int dr = (int)a.r - (int)b.r, dg = (int)a.g - (int)b.g, db = (int)a.b - (int)b.b;
+        return (unsigned int)(dr * dr + dg * dg + db * db);
+    }
+    void growSegments() {
+        label_.assign(n_, -1);
+        seg_size_.clear();
+        size_t seed = 0;
+        size_t done = 0;
+        while (done < n_) {
+            while (label_[seed] != -1) ++seed;  // the next unlabelled point in index order
+            const int seg = (int)seg_size_.size();
+            std::queue<int> q;
+            q.push((int)seed);
+            label_[seed] = seg;
+            int count = 1;
+            while (!q.empty()) {
+                const int cur = q.front();
+                q.pop();
+                const int* row = nbr_.data() + (size_t)cur * row_len_;
+                for (unsigned int j = 0; j < neighbour_number_ && j < (unsigned int)row_len_; ++j) {
+                    const int v = row[j];
+                    if (v < 0 || label_[(size_t)v] != -1) continue;
+                    if ((float)colourDiff(input_->points[(size_t)cur], input_->points[(size_t)v]) > color_p2p_threshold_) continue;
+                    label_[(size_t)v] = seg;
+                    ++count;
+                    q.push(v);
+                }
+            }
+            seg_size_.push_back(count);
+            done += (size_t)count;
+        }
+    }
+    void findSegmentNeighbours() {
+        const size_t ns = seg_size_.size();
+        std::vector<std::vector<int> > members(ns);
+        for (size_t s = 0; s < ns; ++s) members[s].reserve((size_t)seg_size_[s]);
+        for (size_t i = 0; i < n_; ++i) members[(size_t)label_[i]].push_back((int)i);
+        seg_nbr_.assign(ns, std::vector<int>());
+        seg_dist_.assign(ns, std::vector<float>());
+        const float fmax = std::numeric_limits<float>::max();
+        std::vector<float> best(ns, fmax);
+        std::vector<int> touched;
+        for (size_t s = 0; s < ns; ++s) {
+            touched.clear();
+            for (int p : members[s]) {
+                const int* row = nbr_.data() + (size_t)p * row_len_;
+                const float* rd = nbr_d2_.data() + (size_t)p * row_len_;
+                for (int j = 0; j < row_len_; ++j) {
+                    if (row[j] < 0) continue;
+                    const int t = label_[(size_t)row[j]];
+                    if (t == (int)s) continue;
+                    if (best[(size_t)t] == fmax) touched.push_back(t);
+                    if (best[(size_t)t] > rd[j]) best[(size_t)t] = rd[j];
+                }
+            }
+            // the region_neighbour_number_ nearest, handed over farthest first (PCL pops a max-heap of (distance, segment))
+            std::sort(touched.begin(), touched.end());
+            std::priority_queue<std::pair<float, int> > heap;
+            for (int t : touched) {
+                heap.push(std::make_pair(best[(size_t)t], t));
+                if (heap.size() > region_neighbour_number_) heap.pop();
+                best[(size_t)t] = fmax;
+            }
+            while (!heap.empty()) {
+                seg_dist_[s].push_back(heap.top().first);
+                seg_nbr_[s].push_back(heap.top().second);
+                heap.pop();
+            }
+        }
+    }
+    static bool lessFirst(const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; }
+    void mergeRegions() {
+        const size_t ns = seg_size_.size();
+        const float fmax = std::numeric_limits<float>::max();
+        // mean colour per segment: float sums in index order, divided by the count, truncated to an unsigned integer
+        std::vector<float> col(ns * 3, 0.f);
+        for (size_t i = 0; i < n_; ++i) {
+            const PointT& p = input_->points[i];
+            float* c = &col[(size_t)label_[i] * 3];
+            c[0] += p.r; c[1] += p.g; c[2] += p.b;
+        }
+        for (size_t s = 0; s < ns; ++s)
+            for (int a = 0; a < 3; ++a) col[s * 3 + a] = (float)(unsigned int)(col[s * 3 + a] / seg_size_[s]);
+        std::vector<int> seg_region(ns, -1);
+        std::vector<unsigned int> reg_pts;
+        std::vector<int> reg_segs;
+        for (size_t s = 0; s < ns; ++s) {
+            int cur;
+            if (seg_region[s] == -1) {
+                cur = (int)reg_pts.size();
+                seg_region[s] = cur;
+                reg_pts.push_back((unsigned int)seg_size_[s]);
+                reg_segs.push_back(1);
+            } else {
+                cur = seg_region[s];
+            }
+            for (size_t j = 0; j < region_neighbour_number_ && j < seg_nbr_[s].size(); ++j) {
+                const int t = seg_nbr_[s][j];
+                if (seg_dist_[s][j] > distance_threshold_) continue;
+                if (seg_region[(size_t)t] != -1) continue;
+                float diff = 0.f;
+                for (int a = 0; a < 3; ++a) {
+                    const float d = col[s * 3 + a] - col[(size_t)t * 3 + a];
+                    diff += d * d;
+                }
+                if (diff < color_r2r_threshold_) {
+                    seg_region[(size_t)t] = cur;
+                    reg_pts[(size_t)cur] += (unsigned int)seg_size_[(size_t)t];
+                    reg_segs[(size_t)cur] += 1;
+                }
+            }
+        }
+        const size_t nr = reg_pts.size();
+        std::vector<std::vector<int> > reg_members(nr);
+        for (size_t s = 0; s < ns; ++s) reg_members[(size_t)seg_region[s]].push_back((int)s);
+        // neighbours of every region: the neighbour entries of its segments that lead out of it, nearest first
+        std::vector<std::vector<std::pair<float, int> > > reg_nbr(nr);
+        for (size_t r = 0; r < nr; ++r) {
+            for (int s : reg_members[r])
+                for (size_t j = 0; j < seg_nbr_[(size_t)s].size(); ++j) {
+                    if (seg_dist_[(size_t)s][j] == fmax) continue;
+                    const int t = seg_nbr_[(size_t)s][j];
+                    if (seg_region[(size_t)t] != (int)r) reg_nbr[r].push_back(std::make_pair(seg_dist_[(size_t)s][j], t));
+                }
+            std::stable_sort(reg_nbr[r].begin(), reg_nbr[r].end(), lessFirst);
+        }
+        // regions below the minimum size fold into the region of their nearest neighbouring segment
+        for (size_t r = 0; r < nr; ++r) {
+            if (reg_pts[r] >= (unsigned int)min_pts_per_cluster_) continue;
+            if (reg_nbr[r].empty() || reg_nbr[r][0].first == fmax) continue;
+            const int into = seg_region[(size_t)reg_nbr[r][0].second];
+            const std::vector<int> moved = reg_members[r];
+            for (int s : moved) {
+                reg_members[(size_t)into].push_back(s);
+                seg_region[(size_t)s] = into;
+            }
+            reg_members[r].clear();
+            reg_pts[(size_t)into] += reg_pts[r];
+            reg_pts[r] = 0;
+            reg_segs[(size_t)into] += reg_segs[r];
+            reg_segs[r] = 0;
+            for (std::pair<float, int>& e : reg_nbr[(size_t)into])
+                if (seg_region[(size_t)e.second] == into) { e.first = fmax; e.second = 0; }
+            for (const std::pair<float, int>& e : reg_nbr[r])
+                if (seg_region[(size_t)e.second] != into) reg_nbr[(size_t)into].push_back(e);
+            reg_nbr[r].clear();
+            std::stable_sort(reg_nbr[(size_t)into].begin(), reg_nbr[(size_t)into].end(), lessFirst);
+        }
+        // the regions as clusters, members in index order; empty regions dropped
+        std::vector<PointIndices> all(nr);
+        for (size_t r = 0; r < nr; ++r) all[r].indices.reserve(reg_pts[r]);
+        for (size_t i = 0; i < n_; ++i) all[(size_t)seg_region[(size_t)label_[i]]].indices.push_back((int)i);
+        clusters_.clear();
+        for (PointIndices& c : all)
+            if (!c.indices.empty()) clusters_.push_back(c);
+    }
+
+    CloudConstPtr input_;
+    KdTreePtr search_;
+    size_t n_ = 0;
+    int row_len_ = 0;
+    float distance_threshold_ = 0.05f * 0.05f, color_p2p_threshold_ = 1225.0f, color_r2r_threshold_ = 10.0f;
+    unsigned int neighbour_number_ = 30, region_neighbour_number_ = 100;
+    int min_pts_per_cluster_ = 10, max_pts_per_cluster_ = std::numeric_limits<int>::max();
+    std::vector<int> nbr_, label_, seg_size_;
+    std::vector<float> nbr_d2_;
+    std::vector<std::vector<int> > seg_nbr_;
+    std::vector<std::vector<float> > seg_dist_;
+    std::vector<PointIndices> clusters_;
+};
+
+// color_growing_segmentation (reference src/segmentation.cpp:161-216) -- the number of colour segments is what the report
+// uses; the segments themselves are returned as the reference returns them
+template <class PointT>
+inline std::vector<typename PointCloud<PointT>::Ptr> color_growing_segmentation(const typename PointCloud<PointT>::Ptr& cloud_in) {
+    std::vector<typename PointCloud<PointT>::Ptr> out;
+    typename PointCloud<PointT>::Ptr cloud(new PointCloud<PointT>);
+    for (const PointT& p : cloud_in->points)  // pcl::removeNaNFromPointCloud
+        if (isFinite(p)) cloud->push_back(p);
+    if (cloud->size() <= 10) return out;
+    RegionGrowingRGB<PointT> reg;
+    reg.setInputCloud(cloud);
+    reg.setDistanceThreshold(10);
+    reg.setPointColorThreshold(6);
+    reg.setRegionColorThreshold(5);
+    reg.setMinClusterSize(200);
+    std::vector<PointIndices> clusters;
+    reg.extract(clusters);
+    for (const PointIndices& c : clusters) {
+        typename PointCloud<PointT>::Ptr seg(new PointCloud<PointT>);
+        for (int i : c.indices) seg->push_back(cloud->points[(size_t)i]);
+        out.push_back(seg);
+    }
+    return out;
+}
+
+}  // namespace pcc

@@ -1274,3 +1274,186 @@ int orc_icp(const void *src, size_t n, size_t sstride, const void *tgt, size_t m
     orc_kdtree_free(tree);
     return it;
 }
+
+/* ======== RegionGrowingRGB (src/segmentation.cpp:161-216: color_growing_segmentation) [PCL 1.7, recalled] =========
+ * TEST INFRASTRUCTURE.  pcl::RegionGrowingRGB::extract as recalled from PCL 1.7's region_growing.hpp and
+ * region_growing_rgb.hpp (SURVEY.md has no section for it; parity unpinned like everything PCL here):
+ *   findPointNeighbours      nearestKSearch(i, region_neighbour_number_ = 100) per point (rows given: nbr / nbr_d2, or
+ *                            taken from this file's kd-tree when nbr == NULL)
+ *   applySmoothRegionGrowing seeds in index order (no normals: residual 0), growRegion walks the first neighbour_number_
+ *                            (30) neighbours, validatePoint = squared colour distance to the CURRENT point <= p2p^2;
+ *                            every joined point is a seed
+ *   findSegmentNeighbours    per segment the 100 nearest other segments by min neighbour distance (max-heap of pairs,
+ *                            handed over farthest first)
+ *   applyRegionMerging       mean colours (float sums in index order / count, truncated to unsigned), homogeneous regions
+ *                            (distance <= dist^2, colour difference < r2r^2), small regions folded into the region of their
+ *                            nearest neighbouring segment; std::sort of equal distances is unspecified in PCL: stable here
+ *   clusters outside [min, max] dropped.  labels[i] = index of the point's cluster in the returned order, or -1. */
+typedef struct { float d; int32_t s; } rgb_pair_t;
+static void rgb_stable_sort(rgb_pair_t *a, size_t n) { /* insertion sort: stable, lists are short */
+    for (size_t i = 1; i < n; ++i) {
+        rgb_pair_t v = a[i];
+        size_t j = i;
+        while (j > 0 && a[j - 1].d > v.d) { a[j] = a[j - 1]; --j; }
+        a[j] = v;
+    }
+}
+static int rgb_pair_greater(rgb_pair_t a, rgb_pair_t b) { return a.d > b.d || (a.d == b.d && a.s > b.s); }
+
+int orc_region_growing_rgb(const void *pts, size_t n, size_t stride, const uint8_t *rgb /* n x 3: r g b */,
+                           const int32_t *nbr_in, const float *nbr_d2_in, int k_rows, float dist_thr, float p2p_thr,
+                           float r2r_thr, int min_size, int max_size, int nn, int region_nn, int32_t *labels) {
+    for (size_t i = 0; i < n; ++i) labels[i] = -1;
+    if (n == 0 || nn <= 0 || region_nn <= 0) return 0;
+    const float dist2 = dist_thr * dist_thr, p2p2 = p2p_thr * p2p_thr, r2r2 = r2r_thr * r2r_thr;
+    /* --- findPointNeighbours */
+    int K = k_rows;
+    int32_t *nbr = NULL;
+    float *nd2 = NULL;
+    if (nbr_in) {
+        nbr = (int32_t *)nbr_in;
+        nd2 = (float *)nbr_d2_in;
+    } else {
+        K = (size_t)region_nn < n ? region_nn : (int)n;
+        nbr = (int32_t *)malloc(sizeof(int32_t) * n * (size_t)K);
+        nd2 = (float *)malloc(sizeof(float) * n * (size_t)K);
+        orc_kdtree *t = orc_kdtree_build(pts, n, stride);
+        for (size_t i = 0; i < n; ++i) {
+            const float *q = (const float *)((const char *)pts + i * stride);
+            for (int j = 0; j < K; ++j) { nbr[i * K + j] = -1; nd2[i * K + j] = 0.f; }
+            if (t) orc_kdtree_knn(t, q, K, nbr + i * (size_t)K, nd2 + i * (size_t)K);
+        }
+        orc_kdtree_free(t);
+    }
+    /* --- applySmoothRegionGrowingAlgorithm / growRegion */
+    int32_t *seg = (int32_t *)malloc(sizeof(int32_t) * n);
+    int32_t *queue = (int32_t *)malloc(sizeof(int32_t) * n);
+    int32_t *seg_pts = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (size_t i = 0; i < n; ++i) seg[i] = -1;
+    int ns = 0;
+    for (size_t s0 = 0; s0 < n; ++s0) {
+        if (seg[s0] != -1) continue;
+        size_t head = 0, tail = 0;
+        queue[tail++] = (int32_t)s0;
+        seg[s0] = ns;
+        int cnt = 1;
+        while (head < tail) {
+            const int32_t cur = queue[head++];
+            for (int j = 0; j < nn && j < K; ++j) {
+                const int32_t v = nbr[(size_t)cur * K + j];
+                if (v < 0 || seg[v] != -1) continue;
+                unsigned int diff = 0;
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned int a = rgb[(size_t)cur * 3 + c], b = rgb[(size_t)v * 3 + c];
+                    diff += (a - b) * (a - b); /* unsigned arithmetic, as PCL's std::vector<unsigned int> colours */
+                }
+                if ((float)diff > p2p2) continue;
+                seg[v] = ns;
+                ++cnt;
+                queue[tail++] = v;
+            }
+        }
+        seg_pts[ns++] = cnt;
+    }
+    /* --- findSegmentNeighbours / findRegionsKNN */
+    int32_t *first = (int32_t *)calloc((size_t)ns + 1, sizeof(int32_t)); /* CSR of the segments' members, index order */
+    for (size_t i = 0; i < n; ++i) first[seg[i] + 1]++;
+    for (int s = 0; s < ns; ++s) first[s + 1] += first[s];
+    int32_t *members = (int32_t *)malloc(sizeof(int32_t) * n);
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
+    for (int s = 0; s < ns; ++s) fill[s] = first[s];
+    for (size_t i = 0; i < n; ++i) members[fill[seg[i]]++] = (int32_t)i;
+    rgb_pair_t **snb = (rgb_pair_t **)calloc((size_t)ns, sizeof(rgb_pair_t *)); /* neighbour lists, farthest first */
+    int *snb_n = (int *)calloc((size_t)ns, sizeof(int));
+    float *dmin = (float *)malloc(sizeof(float) * (size_t)ns);
+    rgb_pair_t *heap = (rgb_pair_t *)malloc(sizeof(rgb_pair_t) * ((size_t)region_nn + 2));
+    for (int s = 0; s < ns; ++s) dmin[s] = FLT_MAX;
+    for (int s = 0; s < ns; ++s) {
+        for (int32_t m = first[s]; m < first[s + 1]; ++m) {
+            const int32_t p = members[m];
+            for (int j = 0; j < K; ++j) {
+                const int32_t v = nbr[(size_t)p * K + j];
+                if (v < 0) continue;
+                const int32_t t = seg[v];
+                if (t != s && dmin[t] > nd2[(size_t)p * K + j]) dmin[t] = nd2[(size_t)p * K + j];
+            }
+        }
+        /* the region_nn smallest (distance, segment) pairs: a bounded max-heap kept as a sorted array (largest first) */
+        int hn = 0;
+        for (int t = 0; t < ns; ++t) {
+            if (!(dmin[t] < FLT_MAX)) continue;
+            rgb_pair_t e = {dmin[t], t};
+            dmin[t] = FLT_MAX;
+            int pos = hn;
+            while (pos > 0 && rgb_pair_greater(e, heap[pos - 1])) { heap[pos] = heap[pos - 1]; --pos; }
+            heap[pos] = e;
+            ++hn;
+            if (hn > region_nn) { memmove(heap, heap + 1, sizeof(rgb_pair_t) * (size_t)(hn - 1)); --hn; } /* pop the largest */
+        }
+        snb[s] = (rgb_pair_t *)malloc(sizeof(rgb_pair_t) * (size_t)(hn > 0 ? hn : 1));
+        memcpy(snb[s], heap, sizeof(rgb_pair_t) * (size_t)hn);
+        snb_n[s] = hn;
+    }
+    /* --- applyRegionMergingAlgorithm */
+    float *col = (float *)calloc((size_t)ns * 3, sizeof(float));
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) col[(size_t)seg[i] * 3 + c] += rgb[i * 3 + c];
+    for (int s = 0; s < ns; ++s)
+        for (int c = 0; c < 3; ++c) col[(size_t)s * 3 + c] = (float)(unsigned int)(col[(size_t)s * 3 + c] / seg_pts[s]);
+    int32_t *sreg = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
+    unsigned int *rpts = (unsigned int *)calloc((size_t)ns, sizeof(unsigned int));
+    for (int s = 0; s < ns; ++s) sreg[s] = -1;
+    int nr = 0;
+    for (int s = 0; s < ns; ++s) {
+        if (sreg[s] == -1) { sreg[s] = nr; rpts[nr] = (unsigned int)seg_pts[s]; ++nr; }
+        const int cur = sreg[s];
+        for (int j = 0; j < region_nn && j < snb_n[s]; ++j) {
+            const int32_t t = snb[s][j].s;
+            if (snb[s][j].d > dist2) continue;
+            if (sreg[t] != -1) continue;
+            float diff = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float d = col[(size_t)s * 3 + c] - col[(size_t)t * 3 + c];
+                diff += d * d;
+            }
+            if (diff < r2r2) { sreg[t] = cur; rpts[cur] += (unsigned int)seg_pts[t]; }
+        }
+    }
+    /* region neighbour lists (findRegionNeighbours): dynamic arrays of pairs */
+    rgb_pair_t **rnb = (rgb_pair_t **)calloc((size_t)nr, sizeof(rgb_pair_t *));
+    size_t *rnb_n = (size_t *)calloc((size_t)nr, sizeof(size_t)), *rnb_cap = (size_t *)calloc((size_t)nr, sizeof(size_t));
+#define RNB_PUSH(r, e) do { if (rnb_n[r] == rnb_cap[r]) { rnb_cap[r] = rnb_cap[r] ? rnb_cap[r] * 2 : 16; rnb[r] = (rgb_pair_t *)realloc(rnb[r], sizeof(rgb_pair_t) * rnb_cap[r]); } rnb[r][rnb_n[r]++] = (e); } while (0)
+    for (int s = 0; s < ns; ++s) /* segments in index order = the order final_segments lists them per region */
+        for (int j = 0; j < snb_n[s]; ++j) {
+            if (snb[s][j].d == FLT_MAX) continue;
+            if (sreg[snb[s][j].s] != sreg[s]) RNB_PUSH(sreg[s], snb[s][j]);
+        }
+    for (int r = 0; r < nr; ++r) rgb_stable_sort(rnb[r], rnb_n[r]);
+    for (int r = 0; r < nr; ++r) {
+        if (rpts[r] >= (unsigned int)min_size) continue;
+        if (rnb_n[r] == 0 || rnb[r][0].d == FLT_MAX) continue;
+        const int into = sreg[rnb[r][0].s];
+        for (int s = 0; s < ns; ++s)
+            if (sreg[s] == r) sreg[s] = into; /* (order inside a region's segment list does not matter below) */
+        rpts[into] += rpts[r];
+        rpts[r] = 0;
+        for (size_t j = 0; j < rnb_n[into]; ++j)
+            if (sreg[rnb[into][j].s] == into) { rnb[into][j].d = FLT_MAX; rnb[into][j].s = 0; }
+        for (size_t j = 0; j < rnb_n[r]; ++j)
+            if (sreg[rnb[r][j].s] != into) RNB_PUSH(into, rnb[r][j]);
+        rnb_n[r] = 0;
+        rgb_stable_sort(rnb[into], rnb_n[into]);
+    }
+#undef RNB_PUSH
+    /* clusters: regions in index order, empty ones dropped, sizes outside [min, max] dropped */
+    int32_t *rid = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nr > 0 ? nr : 1));
+    int ncl = 0;
+    for (int r = 0; r < nr; ++r) rid[r] = (rpts[r] > 0 && (int)rpts[r] >= min_size && (int)rpts[r] <= max_size) ? ncl++ : -1;
+    for (size_t i = 0; i < n; ++i) labels[i] = rid[sreg[seg[i]]];
+    for (int s = 0; s < ns; ++s) free(snb[s]);
+    for (int r = 0; r < nr; ++r) free(rnb[r]);
+    free(rid); free(rnb); free(rnb_n); free(rnb_cap); free(rpts); free(sreg); free(col); free(heap); free(dmin);
+    free(snb_n); free(snb); free(fill); free(members); free(first); free(seg_pts); free(queue); free(seg);
+    if (!nbr_in) { free(nbr); free(nd2); }
+    return ncl;
+}

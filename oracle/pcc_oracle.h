@@ -176,3 +176,11 @@ void orc_transform(const float T[16], const void *src, size_t n, size_t sstride,
 }
 #endif
 #endif
+
+/* pcl::RegionGrowingRGB::extract as color_growing_segmentation configures it (src/segmentation.cpp:161-216; recalled from
+ * PCL 1.7, see pcc_oracle.c).  rgb: n x 3 bytes (r, g, b).  nbr / nbr_d2: rows of k_rows neighbours per point (ascending,
+ * -1 padded) or NULL to search them with this file's kd-tree.  labels[i] = cluster of point i in PCL's cluster order, -1
+ * when its cluster was dropped.  Returns the number of clusters. */
+int orc_region_growing_rgb(const void *pts, size_t n, size_t stride, const uint8_t *rgb, const int32_t *nbr, const float *nbr_d2,
+                           int k_rows, float dist_thr, float p2p_thr, float r2r_thr, int min_size, int max_size, int nn,
+                           int region_nn, int32_t *labels);

@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         L.orc_kdtree_nn1_batch.restype = None
         L.orc_kdtree_nn1_batch_mt.argtypes = [vp, vp, sz, sz, vp, vp, i32]
         L.orc_kdtree_nn1_batch_mt.restype = None
+        L.orc_region_growing_rgb.argtypes = [vp, sz, sz, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, vp]
+        L.orc_region_growing_rgb.restype = i32
         L.orc_normals.argtypes = [vp, sz, sz, i32, vp, vp]
         L.orc_normals.restype = None
         L.orc_normals_radius.argtypes = [vp, sz, sz, C.c_double, vp, vp]
@@ -231,6 +233,24 @@ def region_growing(normals4, neighbours, smoothness, curvature_threshold, min_si
     labels = np.empty(len(nm), np.int32)
     ncl = lib().orc_region_growing(len(nm), nm.ctypes.data, nb.ctypes.data, nb.shape[1], np.float32(smoothness),
                                    np.float32(curvature_threshold), min_size, max_size, labels.ctypes.data)
+    return labels, ncl
+
+
+def region_growing_rgb(pts, rgb, neighbours=None, neighbour_d2=None, distance=10.0, point_colour=6.0, region_colour=5.0,
+                       min_size=200, max_size=2**31 - 1, nn=30, region_nn=100):
+    """(labels, number of clusters) of pcl::RegionGrowingRGB::extract as color_growing_segmentation sets it up; rows of
+    neighbours (ascending, -1 padded) may be given, else they come from the oracle's kd-tree"""
+    a, ap, n, s1 = _f32(pts)
+    col = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    labels = np.full(n, -1, np.int32)
+    if neighbours is not None:
+        nb = np.ascontiguousarray(neighbours, dtype=np.int32)
+        nd = np.ascontiguousarray(neighbour_d2, dtype=np.float32)
+        ncl = lib().orc_region_growing_rgb(ap, n, s1, col.ctypes.data, nb.ctypes.data, nd.ctypes.data, nb.shape[1], distance,
+                                           point_colour, region_colour, min_size, max_size, nn, region_nn, labels.ctypes.data)
+    else:
+        ncl = lib().orc_region_growing_rgb(ap, n, s1, col.ctypes.data, None, None, 0, distance, point_colour, region_colour,
+                                           min_size, max_size, nn, region_nn, labels.ctypes.data)
     return labels, ncl
 
 

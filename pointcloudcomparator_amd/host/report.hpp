@@ -8,9 +8,9 @@
 // matchRIFTFeaturesKnn() (one pcc_match_knn per candidate pair) for the correspondences.  The descriptors
 // themselves (SIFT keypoints + RIFT histograms) are NOT computed here -- SURVEY.md section 2 keeps that pipeline
 // out of scope -- they are read from files a caller provides (descriptors_io below); without them every
-// cluster has 0 descriptors, nothing can match and no verdict is given.  The colour-based element count
-// (color_growing_segmentation, :1466-1500) is not part of this build either: its three lines are not written
-// and its score stays 0 on both sides.
+// cluster has 0 descriptors, nothing can match and no verdict is given.  The colour-based element count of a match
+// (color_growing_segmentation on both clusters, :1466-1500) runs pcl::RegionGrowingRGB's 100-neighbour search on the GPU
+// (include/pcc/region_growing_rgb.hpp) and writes the reference's three lines.
 #pragma once
 #include <cmath>
 #include <fstream>
@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include "pcc/comparator_nn.hpp"
+#include "pcc/region_growing_rgb.hpp"
 
 namespace pcc {
 namespace report {
@@ -110,6 +111,12 @@ public:
         else if (a < b) f_ << "\t\tSegment of PCL 2 has more " << what_plural << ": " << b << " over: " << a << "\n";
         else f_ << "\t\tBoth segments have the same number of " << what_plural << ": " << a << "\n";
     }
+    // the colour lines of a match (reference :1472-1500): PCL 1's count comes first in all three, "over" without a colon
+    void compareColour(size_t a, size_t b) {
+        if (a > b) f_ << "\t\tSegment of PCL 1 has more elements based on color differences: " << a << " over " << b << "\n";
+        else if (a < b) f_ << "\t\tSegment of PCL 2 has more elements based on color differences: " << a << " over " << b << "\n";
+        else f_ << "\t\tSegment of PCL 1 and segment of PCL 2 have the same number of elements based on color differences: " << a << "\n";
+    }
     void matchRule() { f_ << "      " << std::string(58, '+') << "\t\n"; }
     void close() { f_.close(); }
 
@@ -182,6 +189,11 @@ inline Scores clusterSections(Writer& w, const std::vector<CloudPtr>& clusters1,
             s.points1 += p1; s.points2 += p2;
             w.compare("descriptors", d1, d2);
             s.des1 += d1; s.des2 += d2;
+            // colour based segmentation of both clusters: which one has more elements of different colours
+            const size_t c1 = color_growing_segmentation<PointXYZRGB>(clusters1[i]).size();
+            const size_t c2 = color_growing_segmentation<PointXYZRGB>(clusters2[j]).size();
+            w.compareColour(c1, c2);
+            s.colour1 += c1; s.colour2 += c2;
         } else {
             std::cout << "No match" << std::endl;
             f << "\t\tCluster " << i << " of PCL 1 has no match in PCL 2\n";

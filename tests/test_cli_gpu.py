@@ -212,19 +212,21 @@ def test_cli_cluster_sections_matches_scores_verdict(gpu, tmp_path):
     assert want in txt
     # matches: clusters 0 and 3
     plus = "      " + "+" * 58 + "\t\n"
+    # (color_growing_segmentation of a matched pair: one-coloured clusters of 216 points are one colour segment each)
+    colour = "\t\tSegment of PCL 1 and segment of PCL 2 have the same number of elements based on color differences: 1\n"
     m = rule + "Information of matches of clusters of PCL 1 and PCL 2:\n" + "-" * 36 + "\n"
     m += (f"\tMatched cluster 0 of PCL 1 with cluster {twin[0]} of PCL 2:\n\t\tBoth segments have the same number of points: 216\n"
-          "\t\tBoth segments have the same number of descriptors: 10\n" + plus)
+          "\t\tBoth segments have the same number of descriptors: 10\n" + colour + plus)
     m += "\t\tCluster 1 of PCL 1 has no match in PCL 2\n" + plus
     m += "\t\tCluster 2 of PCL 1 has no match in PCL 2\n" + plus
     m += (f"\tMatched cluster 3 of PCL 1 with cluster {twin[3]} of PCL 2:\n\t\tBoth segments have the same number of points: 216\n"
-          "\t\tSegment of PCL 2 has more descriptors: 9 over: 8\n" + plus)
+          "\t\tSegment of PCL 2 has more descriptors: 9 over: 8\n" + colour + plus)
     m += "Total number of matches found: 2\n\n"
     assert m in txt
     # scores, ratios, verdict: points tie (432 / 432), descriptors 18 vs 19 -> the second cloud wins
     s = ("\n" + "-" * 28 + "\n\npoints score pcl1: 432\npoints score pcl2: 432\n\ndescriptors score pcl1: 18\n"
-         "descriptors score pcl2: 19\n\ncolor elements score pcl1: 0\ncolor elements score pcl2: 0\n\n" + "-" * 28 + "\n\n")
-    ratio = (432 / 432 + 18 / 19 + 0) / 3
+         "descriptors score pcl2: 19\n\ncolor elements score pcl1: 2\ncolor elements score pcl2: 2\n\n" + "-" * 28 + "\n\n")
+    ratio = (432 / 432 + 18 / 19 + 2 / 2) / 3
     s += f"Ratio of similarity over the 2 matches: {_g(ratio)}\nRatio of general similarity of pcl 1 over pcl 2: {_g(ratio * (2 / 4))}\n"
     assert txt.endswith(s)
     assert f"Percentage of RIFT correspondences of clusters 0 and {twin[0]} is: 100" in out

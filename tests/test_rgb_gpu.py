@@ -1,0 +1,74 @@
+"""color_growing_segmentation on the GPU rows: include/pcc/region_growing_rgb.hpp (pcl::RegionGrowingRGB's host logic over ONE
+batched self k-NN, K = 100, from libpcc_nn) through build/rgb_segments, against the oracle's restatement fed with the same
+rows and with its own kd-tree rows -- reference src/segmentation.cpp:161-216, src/comparator.cpp:1466-1500."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from pointcloudcomparator_amd import capi, synth
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+from ply_util import write_ply  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _tool(tmp_path, pts, rgb, *args):
+    tool = ROOT / "build" / "rgb_segments"
+    assert tool.exists(), "make cli"
+    ply = tmp_path / "c.ply"
+    write_ply(ply, pts, rgb)
+    out = subprocess.run([str(tool), str(ply)] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.split("\n")
+    ncl, n = [int(v) for v in lines[0].split()]
+    labels = np.array([int(v) for v in lines[1:1 + n]], np.int32)
+    nseg = int(lines[1 + n].split()[1])
+    return ncl, labels, nseg
+
+
+def _scenes():
+    rng = np.random.default_rng(8)
+    out = []
+    # a painted room: surfaces in a few colours with per-point noise of +-2 levels, furniture in others
+    room = synth.room_cloud(30000, synth.SEED_A)
+    base = np.array([[180, 170, 150], [90, 60, 40], [40, 90, 160], [200, 40, 40], [60, 160, 80]], np.int32)
+    which = (np.floor(room[:, 0] * 1.3).astype(int) + np.floor(room[:, 1] * 0.9).astype(int) * 2) % len(base)
+    rgb = np.clip(base[which] + rng.integers(-2, 3, (len(room), 3)), 0, 255).astype(np.uint8)
+    out.append(("room", room, rgb, (10, 6, 5, 200)))
+    # colour noise: most segments are single points, everything is folded
+    pts = rng.random((4000, 3)).astype(np.float32)
+    out.append(("noise", pts, rng.integers(0, 256, (4000, 3)).astype(np.uint8), (10, 6, 5, 200)))
+    # a few colours, 20 levels apart, random placement: segments of all sizes; small minimum so that many clusters survive
+    out.append(("patches", pts, (rng.integers(0, 3, (4000, 3)) * 20).astype(np.uint8), (10, 6, 5, 15)))
+    # fewer points than a row is long, and fewer than the reference's gate of 10
+    out.append(("tiny", pts[:60], (rng.integers(0, 2, (60, 3)) * 50).astype(np.uint8), (10, 6, 5, 5)))
+    # a tight distance threshold: merging limited to touching segments
+    out.append(("near", pts, (rng.integers(0, 3, (4000, 3)) * 4).astype(np.uint8), (0.05, 6, 5, 30)))
+    return out
+
+
+@pytest.mark.parametrize("scene", range(5))
+def test_colour_segments_match_the_oracle(gpu, tmp_path, scene):
+    name, pts, rgb, (dist, p2p, r2r, mn) = _scenes()[scene]
+    ncl, labels, nseg = _tool(tmp_path, pts, rgb, dist, p2p, r2r, mn)
+    K = min(100, len(pts))
+    with capi.Index(pts) as ix:
+        ki, kd = ix.knn(pts, K)
+    want, want_n = oracle.region_growing_rgb(pts, rgb, neighbours=ki, neighbour_d2=kd, distance=dist, point_colour=p2p,
+                                             region_colour=r2r, min_size=mn)
+    assert ncl == want_n, (name, ncl, want_n)
+    assert (labels == want).all(), (name, np.nonzero(labels != want)[0][:10])
+    # the oracle searching its own rows (FLANN's kd-tree restatement): the same segmentation on tie-free clouds
+    own, own_n = oracle.region_growing_rgb(pts, rgb, distance=dist, point_colour=p2p, region_colour=r2r, min_size=mn)
+    assert own_n == want_n and (own == want).all(), name
+    # color_growing_segmentation itself (the reference's defaults, clouds of <= 10 points give nothing)
+    dflt, dflt_n = oracle.region_growing_rgb(pts, rgb)
+    assert nseg == (dflt_n if len(pts) > 10 else 0)
+    if name == "room":
+        assert 3 <= ncl <= 100           # painted patches of the surfaces, not one blob and not confetti
