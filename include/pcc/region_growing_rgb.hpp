@@ -7,7 +7,7 @@
 // part this repository accelerates: ONE batched self k-NN on the GPU (pcc_knn, rows ascending by (d2, index)).  What PCL
 // does with the rows is sequential, order-dependent host logic and stays host logic here, statement for statement in
 // PCL's order (restated from PCL 1.7's region_growing.hpp / region_growing_rgb.hpp -- SURVEY.md 9 has no section for
-// it; the same recollection, written independently, is the oracle's orc_region_growing_rgb):
+// it; the same recollection, written independently in C, is the test oracle's restatement):
 //   1. growing: seeds in index order, breadth first over the first `neighbour_number_` (30) neighbours of a point, a
 //      neighbour joins when its squared colour distance to the CURRENT point is <= point threshold^2; every joined point
 //      spreads (no normals, no curvature test in this configuration);
