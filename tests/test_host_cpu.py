@@ -26,6 +26,13 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    # more ranks than GPUs (none here) is refused with a message, before anything is launched ...
+    monkeypatch.delenv("PCC_BENCH_SHARE_DEVICES", raising=False)
+    with pytest.raises(SystemExit) as refused:
+        bench.main()
+    assert "one rank per GPU" in str(refused.value.code) and not calls
+    # ... unless the shared-device rehearsal is asked for
+    monkeypatch.setenv("PCC_BENCH_SHARE_DEVICES", "1")
     # main() must hand over to the child ranks before importing torch / the library
     imported_before = "pointcloudcomparator_amd.capi" in sys.modules
     try:
