@@ -307,7 +307,9 @@ def main():
             alg = 12.0 * (M + N) + 8.0 * N
             ach = alg / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else 0.0
             t_main, stale = load_pmc_traffic("k_grid_nn1_flat2", cfg)
-            t_open, _ = load_pmc_traffic("k_nn1_open", cfg)
+            t_open, _ = load_pmc_traffic("k_nn1_open_flat", cfg)
+            if t_open is None:
+                t_open, _ = load_pmc_traffic("k_nn1_open", cfg)
             traffic = None if t_main is None else t_main + (t_open or 0.0)
             pk = pairs.get(cfg if n_per_rank is None or cfg != "c5" else ("c5" if N == C5_TOTAL_QUERIES else "c5_shard"))
             hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg,
