@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-c4trace}
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --config c4 --no-cpu > $O/bench.json 2> $O/err.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --config c4 --no-cpu --no-pairs > $O/bench.json 2> $O/err.log
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python3 - "$O" <<'PY'
 import csv, sys, glob, collections
