@@ -554,7 +554,10 @@ def main():
                     extra["ops_roofline"] = {"source": "profiles/" + ops_files[-1].name,
                                              "operations": [{"op": o["op"], "config": o["config"], "call_ms": round(o["call_ms"], 3),
                                                              "achieved_GBps": round(o["achieved_GBps"], 1),
-                                                             "frac_of_hbm": round(o["frac_of_hbm"], 4)} for o in ops]}
+                                                             "frac_of_hbm": round(o["frac_of_hbm"], 4),
+                                                             "pairs_per_call": o.get("pairs_per_call"),
+                                                             "frac_of_valu": round(o["frac_of_valu"], 4) if "frac_of_valu" in o else None}
+                                                            for o in ops]}
                 except Exception:
                     pass
             # what ONE of eight GPUs does in BASELINE configs[4] (a 4M-query shard vs the 8M references)
