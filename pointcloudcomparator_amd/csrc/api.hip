@@ -44,7 +44,6 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_KNN_CACHE_K: return value >= 0 && value <= 512;
         case PCC_OPT_NN1_DENSE_MIN: return value >= 1 && value <= 1000000;
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
-        case PCC_OPT_KNN_KERNEL: return value >= 0 && value <= 2;
         default: return value == 0 || value == 1;
     }
 }

@@ -781,354 +781,6 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     }
 }
 
-// ---- k-NN by selection, TWO queries per wave (K <= 64; round 4) --------------------------------------------------------
-// k_grid_knn_sel spends ~625 wave instructions on a query with K = 51, about 450 of them on steps whose cost does not depend
-// on the ~250 candidates at all: sizing the cube, laying out the span table, the scans, ballots and read-lanes around the
-// histogram, the bucket sort's bookkeeping -- each a handful of instructions that keep 64 lanes busy for the sake of one
-// query.  Here the two halves of a wave work on two different queries: every one of those steps serves both (scans and
-// ballots split at lane 32: the DPP row steps never cross it, a ballot's two 32-bit words are the halves' masks), and the
-// candidate walk takes 32 candidates of each query per window instead of 64 of one.  Same algorithm, same candidate sets,
-// same filter, same bucket + rank sort as k_grid_knn_sel -- so the same rows, bit for bit; a query that does not fit (or whose
-// final buckets are crowded: lattices) is handed to k_grid_knn_wave as before.  Control flow stays wave-uniform: loops run to
-// the larger of the two halves' bounds with the shorter half predicated off.
-namespace h2 {
-__device__ __forceinline__ unsigned int scan_add(unsigned int x) {  // inclusive, within each half of the wave
-#define PCC_H2_STEP(CTRL, ROWMASK) x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xf, false)
-    PCC_H2_STEP(0x111, 0xf);  // row_shr:1
-    PCC_H2_STEP(0x112, 0xf);  // row_shr:2
-    PCC_H2_STEP(0x114, 0xf);  // row_shr:4
-    PCC_H2_STEP(0x118, 0xf);  // row_shr:8
-    PCC_H2_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3: the halves' second rows (no row_bcast:31: the halves stay apart)
-#undef PCC_H2_STEP
-    return x;
-}
-__device__ __forceinline__ unsigned int last(unsigned int x, unsigned int half) {  // lane 31 of the own half
-    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)x, 31), b = (unsigned int)__builtin_amdgcn_readlane((int)x, 63);
-    return half ? b : a;
-}
-__device__ __forceinline__ unsigned int ballot(bool p, unsigned int half) {  // the own half's 32 lanes
-    const unsigned long long m = __ballot(p);
-    return half ? (unsigned int)(m >> 32) : (unsigned int)m;
-}
-__device__ __forceinline__ unsigned int both_max(unsigned int x) {  // wave-uniform: the larger of the halves' (half-uniform) values
-    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)x, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)x, 32);
-    return a > b ? a : b;
-}
-}  // namespace h2
-
-__global__ void __launch_bounds__(256)
-k_grid_knn_sel2(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
-                const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
-                const unsigned int* __restrict__ n_sorted_ptr, int K, KnnOut out,
-                unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
-    constexpr unsigned int SCAP = 256, CAP = 512;  // survivors the final sort takes; candidates of the cube (kept in LDS)
-    constexpr int KSEL = 5, ROWCAP = (2 * KSEL + 1) * (2 * KSEL + 1), SPANCAP = 2 * ROWCAP;
-    constexpr int RL = (ROWCAP + 31) / 32;  // rows of the cube a lane looks after
-    constexpr unsigned int FLAT_CAP2 = 2048;  // candidates of one pass: two planes of span-end bits, 1024 positions each
-    struct alignas(8) HalfLds {
-        unsigned long long cand[CAP];
-        unsigned int bk[BUCKET_N + 2], tab_s[SPANCAP], endb[2][32];
-        unsigned short tab_o[SPANCAP];
-    };
-    __shared__ HalfLds lds_all[8];
-    const unsigned int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-    HalfLds& L = lds_all[(threadIdx.x >> 6) * 2 + half];
-    const GridParams g = gd->g;
-    const float slack = gd->slack;
-    const unsigned int n_valid = gd->n_valid;
-    const unsigned int ns = *n_sorted_ptr;
-    if (n_valid == 0) return;
-    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned int want = (unsigned int)K < n_valid ? (unsigned int)K : n_valid;
-    const unsigned int lt_mask = (1u << hl) - 1u;
-    for (unsigned int t0 = 2u * wave; t0 < ns; t0 += 2u * nwaves) {  // wave-uniform
-        const unsigned int t = t0 + half;
-        bool ok = t < ns;  // this half has a query and is still on the fast path
-        const unsigned int qi = ok ? order[t] : 0u;
-        const float4 qv = ok ? q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float qx = qv.x, qy = qv.y, qz = qv.z;
-        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
-        auto give_up = [&]() {  // (called by the lanes of ONE half, or both: no wave-level operation inside)
-            if (ok && hl == 0) fb_list[atomicAdd(fb_count, 1u)] = qi;
-            ok = false;
-        };
-        // ---- the smallest cube that holds at least 2 x want points; a lane looks after rows hl, hl + 32, ... of it
-        int k = 1;
-        unsigned int cnt = 0, rs0[RL], rc[RL];
-#pragma unroll
-        for (int i = 0; i < RL; ++i) { rs0[i] = 0; rc[i] = 0; }
-        bool sizing = ok;
-        for (;;) {
-            unsigned int mine = 0;
-            if (sizing) {
-                const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
-                const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
-                const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
-                const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-                const float inv_ny = 1.0f / (float)ny;
-#pragma unroll
-                for (int i = 0; i < RL; ++i) {
-                    const int r = (int)hl + 32 * i;
-                    rs0[i] = 0;
-                    rc[i] = 0;
-                    if (r < nrow) {
-                        const int zi = (int)(((float)r + 0.5f) * inv_ny);  // r / ny (exact: r < 128, ny <= 11)
-                        const unsigned int row = ((unsigned int)(z0 + zi) * g.dim[1] + (y0 + (r - zi * ny))) * g.dim[0];
-                        rs0[i] = cell_start[row + x0];
-                        rc[i] = cell_start[row + x1 + 1] - rs0[i];
-                    }
-                    mine += rc[i];
-                }
-            }
-            const unsigned int c_new = h2::last(h2::scan_add(mine), half);
-            if (sizing) {
-                cnt = c_new;
-                if (cnt >= 2u * want || k >= KSEL) sizing = false;
-                else ++k;
-            }
-            if (__ballot(sizing) == 0ull) break;
-        }
-        if (ok && (cnt < want || cnt > CAP)) give_up();
-        if (!ok) {
-#pragma unroll
-            for (int i = 0; i < RL; ++i) rc[i] = 0;
-        }
-        int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
-        int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
-        int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
-        // ---- span table of the half: (start in cell_refs, flat offset) per non-empty span, one bit per span END over the flat
-        // positions, transposed for windows of 32: word (p mod 32) of plane (p / 1024) holds position p at bit (p / 32) mod 32
-        unsigned int nspans = 0, total = 0;  // half-uniform
-        auto table_reset = [&]() {
-            nspans = 0;
-            total = 0;
-            wave_lds_sync();
-            L.endb[0][hl] = 0u;
-            L.endb[1][hl] = 0u;
-            wave_lds_sync();
-        };
-        auto table_add = [&](unsigned int s0, unsigned int c) {
-            const unsigned int incl = h2::scan_add(c);
-            const unsigned int occ = h2::ballot(c != 0, half);
-            if (c) {
-                const unsigned int slot = nspans + (unsigned int)__popc(occ & lt_mask);
-                const unsigned int off = total + incl - c;
-                L.tab_s[slot] = s0;
-                const unsigned int e = off + c - 1;
-                if (e < FLAT_CAP2) {
-                    L.tab_o[slot] = (unsigned short)off;
-                    atomicOr(&L.endb[e >> 10][e & 31], 1u << ((e >> 5) & 31));
-                }
-            }
-            nspans += (unsigned int)__popc(occ);
-            total += h2::last(incl, half);
-        };
-        // the table's candidates, 32 of each half at a time, two windows per turn: fn(flat position, key, in range)
-        auto walk = [&](auto&& fn) {
-            const unsigned int mt = h2::both_max(total);
-            unsigned int before = 0, word = 0;
-            for (unsigned int B = 0; B < mt; B += 64) {
-                unsigned int my[2], c[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const unsigned int w = (B >> 5) + (unsigned int)u;
-                    if ((w & 31u) == 0u) word = L.endb[(w >> 5) & 1u][hl];
-                    const unsigned int m = h2::ballot(((word >> (w & 31u)) & 1u) != 0u, half);
-                    my[u] = before + (unsigned int)__popc(m & lt_mask);
-                    before += (unsigned int)__popc(m);
-                    c[u] = B + 32u * (unsigned int)u + hl;
-                }
-                float4 r4[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    r4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c[u] < total) {
-                        const unsigned int mm = min(my[u], nspans - 1u);
-                        r4[u] = cell_refs[L.tab_s[mm] + (c[u] - (unsigned int)L.tab_o[mm])];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && B + 32u >= mt) break;
-                    PCC_PAIR(c[u] < total);
-                    fn(c[u], make_key(dist2_nc(qx, qy, qz, r4[u]), r4[u]), c[u] < total);
-                }
-            }
-        };
-        // ---- pass 1: every candidate of the cube kept, d2 counted into buckets over the cube's d2 range
-        const float reach = (float)(k + 1) * g.h;
-        const float scale1 = (float)BUCKET_N / (3.03f * reach * reach);
-        table_reset();
-#pragma unroll
-        for (int i = 0; i < RL; ++i) table_add(rs0[i], rc[i]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) L.bk[1 + 4 * hl + j] = 0u;
-        if (hl == 0) { L.bk[0] = 0u; L.bk[BUCKET_N + 1] = 0u; }
-        wave_lds_sync();
-        walk([&](unsigned int c, unsigned long long key, bool in) {
-            if (in) {
-                L.cand[c] = key;
-                atomicAdd(&L.bk[1 + bucket_of(key, scale1)], 1u);
-            }
-        });
-        wave_lds_sync();
-        // the bucket that holds the want-th: a lane holds four buckets; first lane whose running count reaches it, then the
-        // bucket inside that lane
-        unsigned int bstar = 0, s1 = 0;
-        {
-            unsigned int cb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cb[j] = L.bk[1 + 4 * hl + j];
-            const unsigned int sum4 = (cb[0] + cb[1]) + (cb[2] + cb[3]);
-            const unsigned int incl = h2::scan_add(sum4);
-            const unsigned int reached = h2::ballot(incl >= want, half);
-            const unsigned int fl = reached ? (unsigned int)__builtin_ctz(reached) : 0u;
-            // (every lane works out the answer as if it were that lane; the half then reads lane fl's)
-            unsigned int run = incl - sum4, bj = 4u * hl, sj = 0;
-            bool found = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                run += cb[j];
-                if (!found && run >= want) { found = true; bj = 4u * hl + (unsigned int)j; sj = run; }
-            }
-            bstar = (unsigned int)__shfl((int)bj, (int)(fl + 32u * half), 64);
-            s1 = (unsigned int)__shfl((int)sj, (int)(fl + 32u * half), 64);
-            if (ok && (reached == 0u || bstar >= BUCKET_N - 1 || s1 > SCAP)) give_up();
-        }
-        const float bound = (float)(bstar + 1) / scale1 * 1.00001f;  // every d2 >= bound has a bucket > b*
-        // ---- the kept keys with bucket <= b*, compacted to the front of the buffer (a window is read whole before its
-        // survivors are written, and they land at or before their own position)
-        unsigned int scnt = 0;  // half-uniform
-        {
-            const unsigned int mt = h2::both_max(ok ? total : 0u);
-            for (unsigned int B = 0; B < mt; B += 32) {
-                const unsigned int c = B + hl;
-                const bool in = ok && c < total;
-                const unsigned long long key = in ? L.cand[c] : ~0ull;
-                const bool pass = in && bucket_of(key, scale1) <= bstar;
-                const unsigned int m = h2::ballot(pass, half);
-                wave_lds_sync();
-                if (pass) L.cand[scnt + (unsigned int)__popc(m & lt_mask)] = key;
-                scnt += (unsigned int)__popc(m);
-                wave_lds_sync();
-            }
-        }
-        // ---- pass 2: what the ball of the bound holds outside the cube
-        {
-            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
-            bool need = ok && !(bound < lb2);
-            int ix0 = 1, ix1 = 0, iy0 = 1, iy1 = 0, iz0 = 1, iz1 = 0;
-            if (need) {
-                const float rb = sqrtf(bound) * 1.00001f + slack;
-                int a0, a1, b0, b1, e0, e1;
-                cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
-                cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
-                cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], e0, e1);
-                ix0 = x0; ix1 = x1; iy0 = y0; iy1 = y1; iz0 = z0; iz1 = z1;
-                x0 = min(x0, a0); x1 = max(x1, a1); y0 = min(y0, b0); y1 = max(y1, b1); z0 = min(z0, e0); z1 = max(z1, e1);
-                if ((y1 - y0 + 1) * (z1 - z0 + 1) > ROWCAP) { give_up(); need = false; }
-            }
-            if (__ballot(need) != 0ull) {
-                // the box minus the box already scanned: a row crossing it gives its left and its right part
-                const int ny = y1 - y0 + 1, nrow = need ? ny * (z1 - z0 + 1) : 0;
-                const float inv_ny = 1.0f / (float)ny;
-                const unsigned int max_rows = h2::both_max((unsigned int)nrow);
-                table_reset();
-                for (unsigned int base = 0; base < max_rows; base += 32) {
-                    const int r = (int)(base + hl);
-                    unsigned int s0 = 0, c0 = 0, s1b = 0, c1 = 0;
-                    if (r < nrow) {
-                        const int zi = (int)(((float)r + 0.5f) * inv_ny);
-                        const int z = z0 + zi, y = y0 + (r - zi * ny);
-                        const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
-                        if (y >= iy0 && y <= iy1 && z >= iz0 && z <= iz1) {
-                            if (x0 < ix0) { s0 = cell_start[row + x0]; c0 = cell_start[row + ix0] - s0; }
-                            if (ix1 < x1) { s1b = cell_start[row + ix1 + 1]; c1 = cell_start[row + x1 + 1] - s1b; }
-                        } else {
-                            s0 = cell_start[row + x0];
-                            c0 = cell_start[row + x1 + 1] - s0;
-                        }
-                    }
-                    table_add(s0, c0);
-                    if (__ballot(c1 != 0) != 0ull) table_add(s1b, c1);
-                }
-                wave_lds_sync();
-                if (need && total > FLAT_CAP2) { give_up(); need = false; }
-                if (!need) total = 0;  // (a half that fell out here must not walk a table beyond the end bits)
-                walk([&](unsigned int, unsigned long long key, bool in) {
-                    const bool pass = in && need && bucket_of(key, scale1) <= bstar;
-                    const unsigned int m = h2::ballot(pass, half);
-                    const unsigned int slot = scnt + (unsigned int)__popc(m & lt_mask);
-                    if (pass && slot < SCAP) L.cand[slot] = key;
-                    scnt += (unsigned int)__popc(m);
-                });
-                wave_lds_sync();
-                if (ok && scnt > SCAP) give_up();
-            }
-        }
-        if (!ok) scnt = 0;
-        // ---- the survivors in order: 128 finer buckets over [0, bound], count -> scan -> scatter -> rank inside the bucket
-        // (the bucket is a monotone function of d2 alone, so bucket-then-key order is key order); a crowded bucket -- many
-        // equal distances -- hands the query to the merge kernel
-        {
-            const float scale2 = (float)BUCKET_N / bound;
-            unsigned long long* tmp = L.cand + SCAP;
-            const unsigned int rmax = (h2::both_max(scnt) + 31u) >> 5;  // wave-uniform trip count
-            wave_lds_sync();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) L.bk[1 + 4 * hl + j] = 0u;
-            wave_lds_sync();
-            for (unsigned int r = 0; r < rmax; ++r) {
-                const unsigned int e = r * 32u + hl;
-                if (e < scnt) atomicAdd(&L.bk[1 + bucket_of(L.cand[e], scale2)], 1u);
-            }
-            wave_lds_sync();
-            unsigned int cb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cb[j] = L.bk[1 + 4 * hl + j];
-            const unsigned int crowded = h2::ballot(max(max(cb[0], cb[1]), max(cb[2], cb[3])) > BUCKET_FULL, half);
-            if (ok && crowded != 0u && scnt >= 2u) give_up();
-            if (!ok) scnt = 0;
-            const unsigned int sum4 = (cb[0] + cb[1]) + (cb[2] + cb[3]);
-            unsigned int ex = h2::scan_add(sum4) - sum4;
-            wave_lds_sync();
-            if (hl == 0) L.bk[0] = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { L.bk[1 + 4 * hl + j] = ex; ex += cb[j]; }  // fill pointer of bucket b, then its END
-            wave_lds_sync();
-            for (unsigned int r = 0; r < rmax; ++r) {
-                const unsigned int e = r * 32u + hl;
-                if (e < scnt) {
-                    const unsigned long long kk = L.cand[e];
-                    tmp[atomicAdd(&L.bk[1 + bucket_of(kk, scale2)], 1u)] = kk;
-                }
-            }
-            wave_lds_sync();
-            for (unsigned int r = 0; r < rmax; ++r) {
-                const unsigned int e = r * 32u + hl;
-                if (e < scnt) {
-                    const unsigned long long kk = tmp[e];
-                    const unsigned int bb = bucket_of(kk, scale2);
-                    const unsigned int lo = L.bk[bb], hi = L.bk[bb + 1];
-                    unsigned int pos = lo;
-                    for (unsigned int j = lo; j < hi; ++j) pos += tmp[j] < kk ? 1u : 0u;
-                    L.cand[pos] = kk;
-                }
-            }
-            wave_lds_sync();
-        }
-        // (entries past `want` -- K beyond the number of valid references -- are "nothing found")
-        if (ok) {
-            const size_t row0 = (size_t)qi * K;
-            for (unsigned int e = hl; e < (unsigned int)K; e += 32) knn_emit(out, row0 + e, e < want ? L.cand[e] : ~0ull);
-        }
-        wave_lds_sync();
-    }
-}
-
 // keys: the rows as search keys; or keys == nullptr and idx_out / d2_out (either may be null): the rows delivered as
 // indices and squared distances (K <= 512 only -- check with grid_knn_delivers)
 bool grid_knn_delivers(int K) { return K <= 512; }
@@ -1162,12 +814,7 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
 #define PCC_LAUNCH_SEL(SCAP_, STORE_)                                                                                     \
     hipLaunchKernelGGL((k_grid_knn_sel<SCAP_, STORE_>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),            \
                        ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq)
-            if (K <= 64 && ix->opt.knn_kernel == 2) {
-                unsigned int g2 = (n + 7) / 8;  // two queries per wave, four waves per workgroup, waves loop
-                if (g2 > 8192) g2 = 8192;
-                hipLaunchKernelGGL(k_grid_knn_sel2, dim3(g2), dim3(256), 0, s, ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(),
-                                   ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq);
-            } else if (K <= 64) PCC_LAUNCH_SEL(256, true);
+            if (K <= 64) PCC_LAUNCH_SEL(256, true);
             else if (K <= 128) PCC_LAUNCH_SEL(256, false);
             else if (K <= 256) PCC_LAUNCH_SEL(384, false);
             else PCC_LAUNCH_SEL(768, false);
