@@ -94,3 +94,27 @@ def test_sor_shards_combine_to_the_whole_clouds_statistics(gpu, parts):
             tot[2:] = np.minimum(tot[2:], sums[2:])
         _, exact = capi.sor_threshold(tot, ix.stats()[2], 50, 1.5)
         assert not exact
+
+
+def test_one_rank_communicator_on_a_small_cloud_and_edge_shards(gpu):
+    """a cloud below the GRID engine's threshold (exhaustive engine; SOR builds the grid on demand), an empty SOR shard,
+    a shard outside the cloud, an index on another handle's communicator arguments"""
+    tgt = synth.corridor_cloud(900, synth.SEED_A)
+    src = synth.rigid_offset(synth.corridor_cloud(400, synth.SEED_B), rot_deg=0.3, t=(0.005, 0.0, 0.0))
+    with capi.Comm.from_id(capi.comm_unique_id(), 1, 0, 0) as comm:
+        with capi.Index.broadcast(comm, 0, tgt) as bx, capi.Index(tgt) as ix:
+            T1, f1, it1, c1 = ix.icp_align(src, max_iter=8)
+            T2, f2, it2, c2 = bx.icp_align_sharded(comm, src, max_iter=8)
+            assert (T1.view(np.uint32) == T2.view(np.uint32)).all() and f1 == f2 and it1 == it2 and c1 == c2
+            md, inl, thr, kept = ix.sor(20, 1.0)
+            smd, sinl, sthr, skept = bx.sor_sharded(comm, 0, len(tgt), 20, 1.0)
+            assert (_bits(md) == _bits(smd)).all() and (inl == sinl).all() and thr == sthr and kept == skept
+            # an empty shard still takes part in the collectives and learns the whole cloud's threshold
+            emd, einl, ethr, ekept = bx.sor_sharded(comm, len(tgt), 0, 20, 1.0)
+            assert len(emd) == 0 and len(einl) == 0 and ekept == 0   # (one rank: the sums of "all shards" are this empty one's)
+            with pytest.raises(capi.PccError):
+                bx.sor_sharded(comm, 10, len(tgt), 20, 1.0)                          # runs past the end of the cloud
+            with pytest.raises(capi.PccError):
+                bx.icp_align_sharded(comm, src[:0], max_iter=3)                       # every rank needs a non-empty shard
+        with pytest.raises(capi.PccError):
+            capi.Index.broadcast(comm, 3, tgt)                                        # root outside the communicator
