@@ -95,3 +95,35 @@ def icp_align_sharded(step, transform, solve, src_shard, max_iter: int, dist=Non
             break
         prev = mse
     return T, it, mse
+
+
+def sor_sharded(partial, threshold, n_total: int, rank: int, world: int, mean_k: int = 50, stddev_mult: float = 1.5, dist=None):
+    """StatisticalOutlierRemoval with the cloud's POINTS sharded over the ranks ("SOR adds an all-reduce of
+    (sum, sum of squares, count)"): each rank takes the mean distances of its contiguous shard, the four statistics are
+    combined over the ranks -- (+, +) for the sums, (min, min) for the smallest positive terms that decide whether the sums
+    carry PCL's in-order bits -- and every rank derives the same threshold.
+
+    partial(start, count) -> (mean_dist[count] float32, sums[4])   capi.Index.sor_partial
+    threshold(sums[4]) -> (thr, exact)                             capi.sor_threshold bound to n_valid / mean_k / stddev_mult
+    Returns (start, mean_dist of the shard, inlier mask of the shard, threshold, kept over ALL shards, exact)."""
+    import numpy as np
+    import torch
+    start, count = shard_range(n_total, rank, world)
+    md, sums = partial(start, count)
+    sums = np.asarray(sums, dtype=np.float64)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        add, low = torch.from_numpy(sums[:2].copy()), torch.from_numpy(sums[2:].copy())
+        if on_gpu:
+            add, low = add.cuda(), low.cuda()
+        dist.all_reduce(add, op=dist.ReduceOp.SUM)
+        dist.all_reduce(low, op=dist.ReduceOp.MIN)
+        sums = np.concatenate([add.cpu().numpy(), low.cpu().numpy()])
+    thr, exact = threshold(sums)
+    inl = ~(np.asarray(md, dtype=np.float32).astype(np.float64) > thr)
+    kept = torch.tensor([int(inl.sum())], dtype=torch.int64)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            kept = kept.cuda()
+        dist.all_reduce(kept, op=dist.ReduceOp.SUM)
+    return start, md, inl, thr, int(kept.item()), exact

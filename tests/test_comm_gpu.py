@@ -118,3 +118,17 @@ def test_one_rank_communicator_on_a_small_cloud_and_edge_shards(gpu):
                 bx.icp_align_sharded(comm, src[:0], max_iter=3)                       # every rank needs a non-empty shard
         with pytest.raises(capi.PccError):
             capi.Index.broadcast(comm, 3, tgt)                                        # root outside the communicator
+
+
+def test_python_sharding_helper_over_the_real_partial_sums(gpu):
+    """sharding.sor_sharded (what a torch.distributed job calls per rank) on top of pcc_sor_partial / pcc_sor_threshold:
+    with one rank it reproduces pcc_sor; tests/test_sharding_cpu.py runs the same helper over two gloo ranks"""
+    pts = synth.corridor_cloud(30000, synth.SEED_B)
+    with capi.Index(pts) as ix:
+        md, inl, thr, kept = ix.sor(50, 1.5)
+        n_valid = ix.stats()[2]
+        start, smd, sinl, sthr, skept, exact = sharding.sor_sharded(lambda s, c: ix.sor_partial(s, c, 50),
+                                                                    lambda sums: capi.sor_threshold(sums, n_valid, 50, 1.5),
+                                                                    len(pts), 0, 1)
+    assert start == 0 and exact and sthr == thr and skept == kept
+    assert (_bits(smd) == _bits(md)).all() and (sinl == inl.astype(bool)).all()

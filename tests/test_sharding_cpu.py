@@ -106,3 +106,52 @@ def test_two_rank_gloo_sharded_icp_matches_unsharded():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert it == it1 == 5 and dT < 1e-6 and dm < 1e-9
+
+
+def _float_bits_min_positive(x):
+    pos = x[x > 0]
+    return float(pos.view(np.uint32).min()) if len(pos) else float(0x7f800000)
+
+
+def _sor_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import oracle
+    from pointcloudcomparator_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pts = synth.corridor_cloud(6001, synth.SEED_A)
+    omd, oinl, othr, okept = oracle.sor(pts, 50, 1.5)          # the whole cloud on one "device"
+
+    def partial(start, count):                                  # what pcc_sor_partial returns for a shard (the oracle's means)
+        m = omd[start:start + count]
+        g = (m * m).astype(np.float32)                          # PCL squares in float
+        return m, [float(m.astype(np.float64).sum()), float(g.astype(np.float64).sum()),
+                   _float_bits_min_positive(m), _float_bits_min_positive(g)]
+
+    thr_fn = lambda sums: capi.sor_threshold(sums, len(pts), 50, 1.5)   # libpcc_nn's host arithmetic, no GPU
+    start, md, inl, thr, kept, exact = sharding.sor_sharded(partial, thr_fn, len(pts), rank, world, dist=dist)
+    q.put((rank, thr == othr, kept == okept, bool((inl == oinl[start:start + len(md)]).all()), exact))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_sor_reaches_the_whole_clouds_threshold():
+    """the cloud's points split over two ranks, (sum, sq) all-reduced with SUM and the smallest terms with MIN: both ranks
+    derive PCL's threshold over the whole cloud (bit-equal to the oracle's: no addition of these sums rounds) and the
+    kept count over all shards"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, True, True, True), (1, True, True, True, True)]
