@@ -351,7 +351,11 @@ int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t st
  * replaces: the single pcl::KdTreeFLANN / pcl::IterativeClosestPoint / pcl::StatisticalOutlierRemoval object per call site
  *   (src/comparator.cpp:564-577, 1089-1110, 1523-1541) when a node's GPUs share one cloud pair.
  * A pcc_comm is one rank of an RCCL communicator: one per (process, GPU).  librccl.so.1 is loaded when the first one is
- * made (dlopen); libpcc_nn.so does not depend on it otherwise. */
+ * made (dlopen); libpcc_nn.so does not depend on it otherwise.
+ * The calls marked "collective" must be made by EVERY rank of the communicator with arguments that are valid on every
+ * rank: a rank that returns an error before its first collective (a shard outside the cloud, an allocation failure) leaves
+ * the others waiting in theirs, as with any RCCL program.  pcc_index_create_broadcast tells the other ranks when the ROOT
+ * could not index its cloud (they return PCC_ERR_EMPTY instead of waiting). */
 typedef struct pcc_comm pcc_comm;
 #define PCC_COMM_ID_BYTES 128
 /* one process per GPU: rank 0 makes the id (PCC_COMM_ID_BYTES bytes), hands it to the other ranks over whatever launched
