@@ -87,6 +87,16 @@ static int exercise_oracle(const std::vector<float>& a, const std::vector<float>
     orc_set_split_rule(0);
     std::vector<int32_t> labels(m), sizes(64);
     orc_euclidean_clusters(a.data(), m, 12, 0.05f, 2, 100000, labels.data(), sizes.data(), 64);
+    {   // RegionGrowingRGB's restatement: few colours (many small segments, folds), rows from the oracle's own tree
+        bool finite = true;
+        for (float v : a) finite = finite && std::isfinite(v);
+        if (finite && m <= 1000) {
+            std::vector<uint8_t> rgb(m * 3);
+            for (size_t i = 0; i < m * 3; ++i) rgb[i] = (uint8_t)(((i * 2654435761u) >> 28) * 16);
+            std::vector<int32_t> cl(m);
+            for (int mn : {1, 7, 200}) orc_region_growing_rgb(a.data(), m, 12, rgb.data(), nullptr, nullptr, 0, 10.f, 6.f, 5.f, mn, 1 << 30, 30, 100, cl.data());
+        }
+    }
     std::vector<float> md(m);
     std::vector<uint8_t> inl(m);
     double thr = 0;
