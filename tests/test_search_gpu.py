@@ -226,6 +226,24 @@ def test_radius_search_with_max_nn_keeps_the_nearest(gpu, max_nn):
         assert (o1 == o2).all() and (i1 == i2).all() and (_bits(e1) == _bits(e2)).all()
 
 
+def test_sor_threshold_nan_when_the_variance_rounds_below_zero(gpu):
+    """tests/golden/sor_negative_variance.npz (a scene tools/fuzz_gpu.py drew: two tight clumps 7 km apart at coordinates of
+    1e5, mean_k beyond a clump's size): every mean distance is ~2824 and (sq_sum - sum^2 / n) / (n - 1) rounds to a small
+    NEGATIVE number -- PCL's threshold is the sqrt of it, NaN, and `distance > NaN` is false for every point: all are kept.
+    The library says the same on both output routes (the fuzz checker had compared the two NaNs with ==)."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "sor_negative_variance.npz")
+    a, mk = g["cloud"], int(g["mean_k"])
+    omd, oinl, othr, okept = oracle.sor(a, mk, 1.5)
+    assert np.isnan(othr) and okept == len(a) == int(g["kept"]) and (_bits(omd) == g["mean_dist_bits"]).all()
+    with capi.Index(a) as ix:
+        for dev in (None, "cuda:0"):
+            md, inl, thr, kept = ix.sor(mk, 1.5, device=dev)
+            md = md if dev is None else md.cpu().numpy()
+            inl = inl if dev is None else inl.cpu().numpy()
+            assert np.isnan(thr) and kept == okept and (inl == oinl).all() and (_bits(md) == _bits(omd)).all()
+
+
 def test_transform_bits(gpu):
     pts = _scene(5000)
     a = np.deg2rad(7.0)

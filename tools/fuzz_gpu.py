@@ -206,7 +206,7 @@ def main():
                     mk = int(rng.integers(2, 51))
                     md, inl, thr, kept = ix.sor(mean_k=mk, stddev_mult=1.5)
                     omd, oinl, othr, okept = oracle.sor(a, mk, 1.5)
-                    ok = (bits(md) == bits(omd)).all() and (np.asarray(inl) == oinl).all() and thr == othr and kept == okept
+                    ok = (bits(md) == bits(omd)).all() and (np.asarray(inl) == oinl).all() and (thr == othr or (np.isnan(thr) and np.isnan(othr))) and kept == okept  # (a variance that rounds below zero: PCL's threshold is NaN, everything is kept)
                     if not ok:
                         # the oracle's SOR searches through its kd-tree as FLANN does, and FLANN's walk is not exact where
                         # squared distances are huge against their ulp (a stray point 1e5 away: the rounded branch bound prunes a
