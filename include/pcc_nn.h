@@ -153,8 +153,10 @@ enum pcc_option {
                                     that needs no more than the kept rows hold takes their prefix instead of searching again (the
                                     reference's default segmentation: normals with 50, then region growing with 100 neighbours of the
                                     same cloud -- one search instead of two).  Costs n x K x 8 bytes of device memory */
-    PCC_OPT_NN1_OPEN_FLAT = 14   /* flat k = 1 kernel, listed open lanes: 1 = their rows drained with lanes over candidates (default),
+    PCC_OPT_NN1_OPEN_FLAT = 14,  /* flat k = 1 kernel, listed open lanes: 1 = their rows drained with lanes over candidates (default),
                                     0 = one lane per listed query (round 3) */
+    PCC_OPT_SORT_STAGE1 = 15     /* three-level cell sort, level 1: 1 = reference points leave in bucket-sorted LDS tiles, whole runs
+                                    stored (default); 0 = one store per point; 2 = tiles for the queries' 8-byte pairs too */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -44,6 +44,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_KNN_CACHE_K: return value >= 0 && value <= 512;
         case PCC_OPT_NN1_DENSE_MIN: return value >= 1 && value <= 1000000;
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
+        case PCC_OPT_SORT_STAGE1: return value >= 0 && value <= 2;
         default: return value == 0 || value == 1;
     }
 }
@@ -64,6 +65,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_KNN_KERNEL: *as_int = &o.knn_kernel; return nullptr;
         case PCC_OPT_KNN_CACHE_K: *as_int = &o.knn_cache_k; return nullptr;
         case PCC_OPT_NN1_OPEN_FLAT: *as_int = &o.nn1_open_flat; return nullptr;
+        case PCC_OPT_SORT_STAGE1: *as_int = &o.sort_stage1; return nullptr;
         default: return nullptr;
     }
 }
@@ -76,7 +78,7 @@ void Options::from_env() {
         {"PCC_ICP_WARM", PCC_OPT_ICP_WARM}, {"PCC_ICP_DEVICE_LOOP", PCC_OPT_ICP_DEVICE_LOOP}, {"PCC_EC_CELLS", PCC_OPT_EC_CELLS},
         {"PCC_SORT_MP_MIN", PCC_OPT_SORT_MP_MIN}, {"PCC_SORT_MP_MIN_Q", PCC_OPT_SORT_MP_MIN_Q}, {"PCC_NN1_KERNEL", PCC_OPT_NN1_KERNEL},
         {"PCC_FLANN_SPLIT", PCC_OPT_FLANN_SPLIT}, {"PCC_NN1_DENSE_MIN", PCC_OPT_NN1_DENSE_MIN}, {"PCC_KNN_KERNEL", PCC_OPT_KNN_KERNEL},
-        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}};
+        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;

@@ -111,6 +111,72 @@ k_mp_scatter1(const float4* __restrict__ pts, unsigned int n, const GridDev* __r
     }
 }
 
+// The same scatter with the slice taken in TILES that are sorted by bucket in LDS first: a wave's store then covers a few
+// whole 128-byte runs instead of 64 pieces of 16 (or 8) bytes going to 64 different buckets -- the pass moved exactly its
+// algorithmic bytes already (PMC) but at 49 % of the HBM roof: it is the L2's write transactions that it was short of.
+// Measured at 10M points: index build 0.447 -> 0.434 ms with the 16-byte points; used for them only.
+constexpr unsigned int MP_TILE1 = 2048;  // points of a tile: 32 KB of LDS for points, 16 KB for (cell, position) pairs
+template <class E>
+__global__ void __launch_bounds__(MP_T)
+k_mp_scatter1_staged(const float4* __restrict__ pts, unsigned int n, const GridDev* __restrict__ gd, unsigned int F1, unsigned int B1,
+                     unsigned int slice, const unsigned int* __restrict__ H, E* __restrict__ out) {
+    constexpr int PER = MP_TILE1 / MP_T;  // points a thread takes per tile
+    __shared__ unsigned int cur[MP_MAX_B1], tcnt[MP_MAX_B1], tstart[MP_MAX_B1];
+    __shared__ unsigned short sb[MP_TILE1];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[MP_TILE1 * sizeof(E)];
+    E* stage = reinterpret_cast<E*>(stage_raw);
+    const GridParams g = gd->g;
+    const bool voxel = gd->voxel != 0;
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) cur[b] = H[(size_t)b * gridDim.x + blockIdx.x];
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int t0 = beg; t0 < end; t0 += MP_TILE1) {  // (workgroup-uniform)
+        for (unsigned int b = threadIdx.x; b < MP_MAX_B1; b += MP_T) tcnt[b] = 0;
+        __syncthreads();
+        float4 v[PER];
+        unsigned int bk[PER], rk[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const unsigned int i = t0 + threadIdx.x + u * MP_T;
+            v[u] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (i < end) v[u] = pts[i];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            bk[u] = 0xffffffffu;
+            rk[u] = 0;
+            if (__float_as_int(v[u].w) >= 0) {
+                bk[u] = mp_cell(v[u], g, voxel);
+                rk[u] = atomicAdd(&tcnt[bk[u] / F1], 1u);  // rank inside the tile's run for that bucket
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // exclusive scan of the <= 256 tile counts: four per lane of the first wave
+            unsigned int c[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = tcnt[4 * threadIdx.x + j]; sum += c[j]; }
+            unsigned int ex = wave_incl_scan_add(sum) - sum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tstart[4 * threadIdx.x + j] = ex; ex += c[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (bk[u] != 0xffffffffu) {
+                const unsigned int b = bk[u] / F1, slot = tstart[b] + rk[u];
+                stage[slot] = mp_make<E>(v[u], bk[u]);
+                sb[slot] = (unsigned short)b;
+            }
+        __syncthreads();
+        const unsigned int tile_n = tstart[MP_MAX_B1 - 1] + tcnt[MP_MAX_B1 - 1];  // valid points of the tile
+        for (unsigned int j = threadIdx.x; j < tile_n; j += MP_T) {
+            const unsigned int b = sb[j];
+            out[cur[b] + (j - tstart[b])] = stage[j];
+        }
+        __syncthreads();
+        for (unsigned int b = threadIdx.x; b < MP_MAX_B1; b += MP_T) cur[b] += tcnt[b];
+    }
+}
+
 // ---- level 2 ---------------------------------------------------------------------------------------------------
 // pair id of a cell: (level-1 bucket) * B2 + (level-2 bucket inside it)
 __device__ __forceinline__ unsigned int mp_pair(unsigned int c, unsigned int F1, unsigned int F2) {
@@ -284,7 +350,10 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
         float4* t1 = ix->mp_a.as<float4>();
         float4* t2 = ix->mp_b.as<float4>();
         const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(float4) - 1) / (MP_STAGE_BYTES / sizeof(float4));
-        hipLaunchKernelGGL((k_mp_scatter1<float4>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+        if (ix->opt.sort_stage1)
+            hipLaunchKernelGGL((k_mp_scatter1_staged<float4>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+        else
+            hipLaunchKernelGGL((k_mp_scatter1<float4>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         hipLaunchKernelGGL((k_mp_level2<false, float4>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
         PCC_TRY(launch_exclusive_scan(s, C, np, ix->scratch_a));
         hipLaunchKernelGGL((k_mp_level2<true, float4>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
@@ -296,7 +365,12 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
         uint2* t1 = ix->mp_a.as<uint2>();
         uint2* t2 = ix->mp_b.as<uint2>();
         const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(uint2) - 1) / (MP_STAGE_BYTES / sizeof(uint2));
-        hipLaunchKernelGGL((k_mp_scatter1<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+        // (the 8-byte pairs lose with the staged form: 10M queries 0.218 vs 0.209 ms for the whole sort -- their pieces are half
+        // as long and the tile's LDS round trip costs what the stores save; option value 2 forces it for measurements)
+        if (ix->opt.sort_stage1 == 2)
+            hipLaunchKernelGGL((k_mp_scatter1_staged<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
+        else
+            hipLaunchKernelGGL((k_mp_scatter1<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         hipLaunchKernelGGL((k_mp_level2<false, uint2>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
         PCC_TRY(launch_exclusive_scan(s, C, np, ix->scratch_a));
         hipLaunchKernelGGL((k_mp_level2<true, uint2>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);

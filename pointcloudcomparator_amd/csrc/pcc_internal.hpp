@@ -100,6 +100,7 @@ struct Options {
     int knn_cache_k = 0;            // PCC_OPT_KNN_CACHE_K: self k-NN rows searched with at least this K and kept (0: off)
     int knn_kernel = 1;             // PCC_OPT_KNN_KERNEL: 1 selection kernel for k <= 128, 0 merge network only
     int nn1_dense_min = 4;          // PCC_OPT_NN1_DENSE_MIN: references per own cell from which a wave starts with the own cell alone
+    int sort_stage1 = 1;            // PCC_OPT_SORT_STAGE1: level 1 of the three-level sort writes bucket-sorted LDS tiles (1: reference points; 2: query pairs too; 0: one store per point)
     int nn1_open_flat = 1;          // PCC_OPT_NN1_OPEN_FLAT: the listed open lanes drained flat (k_nn1_open_flat); 0 = one lane per query
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     void from_env();

@@ -81,6 +81,34 @@ def test_nn1_kernel_forms_agree_at_a_million(gpu):
         assert (idx[:20000] == bi).all() and (_bits(d2[:20000]) == _bits(bd)).all()
 
 
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_three_level_sort_forms_build_the_same_index(gpu, stage):
+    """PCC_OPT_SORT_STAGE1: level 1 of the sort for clouds beyond the L2s with and without bucket-sorted LDS tiles (references /
+    queries): 2M x 2M through the three-level sort on both sides (thresholds lowered), results = the default's, bit for bit"""
+    torch = pytest.importorskip("torch")
+    n = 2_000_000
+    a = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_A)).cuda()
+    b = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_B)).cuda()
+    with capi.Index(a, engine=capi.ENGINE_GRID) as ix:
+        i0, d0 = ix.nn1(b)
+        ix.set_option(capi.OPT_SORT_STAGE1, stage)
+        ix.set_option(capi.OPT_SORT_MP_MIN, 1000)       # the three-level sort for both clouds
+        ix.set_option(capi.OPT_SORT_MP_MIN_Q, 1000)
+        ix.set_input(a)
+        i1, d1 = ix.nn1(b)
+        assert (i0 == i1).all().item() and (d0.view(torch.int32) == d1.view(torch.int32)).all().item()
+        assert ix.stats()[1] == 0
+    with capi.Index(a[:50000], engine=capi.ENGINE_BRUTE) as bx:      # and against the exhaustive kernel on a slice
+        bi, bd = bx.nn1(b[:3000])
+    with capi.Index(a[:50000], engine=capi.ENGINE_GRID) as gx:
+        gx.set_option(capi.OPT_SORT_STAGE1, stage)
+        gx.set_option(capi.OPT_SORT_MP_MIN, 1000)
+        gx.set_option(capi.OPT_SORT_MP_MIN_Q, 1000)
+        gx.set_input(a[:50000])
+        gi, gdd = gx.nn1(b[:3000])
+    assert (bi == gi).all().item() and (bd.view(torch.int32) == gdd.view(torch.int32)).all().item()
+
+
 def test_options_are_per_handle_and_validated(gpu):
     a = synth.corridor_cloud(5000, synth.SEED_A)
     with capi.Index(a) as ix, capi.Index(a) as iy:
