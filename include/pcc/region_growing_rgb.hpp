@@ -143,15 +143,19 @@ private:
     void mergeRegions() {
         const size_t ns = seg_size_.size();
         const float fmax = std::numeric_limits<float>::max();
-        // mean colour per segment: float sums in index order, divided by the count, truncated to an unsigned integer
-        std::vector<float> col(ns * 3, 0.f);
+        // mean colour per segment as PCL's applyRegionMergingAlgorithm takes it: the channel sums in std::vector<unsigned int>
+        // (EXACT -- a float sum rounds from 2^24 on, i.e. from ~66k bright points per segment, and the truncated mean can
+        // then be off by one and flip a merge), then float(sum) / float(count) truncated to an unsigned integer
+        std::vector<unsigned int> sum(ns * 3, 0u);
         for (size_t i = 0; i < n_; ++i) {
             const PointT& p = input_->points[i];
-            float* c = &col[(size_t)label_[i] * 3];
+            unsigned int* c = &sum[(size_t)label_[i] * 3];
             c[0] += p.r; c[1] += p.g; c[2] += p.b;
         }
+        std::vector<float> col(ns * 3, 0.f);
         for (size_t s = 0; s < ns; ++s)
-            for (int a = 0; a < 3; ++a) col[s * 3 + a] = (float)(unsigned int)(col[s * 3 + a] / seg_size_[s]);
+            for (int a = 0; a < 3; ++a)
+                col[s * 3 + a] = (float)static_cast<unsigned int>(static_cast<float>(sum[s * 3 + a]) / static_cast<float>(seg_size_[s]));
         std::vector<int> seg_region(ns, -1);
         std::vector<unsigned int> reg_pts;
         std::vector<int> reg_segs;

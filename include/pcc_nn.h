@@ -188,8 +188,9 @@ int pcc_radius_count(pcc_index *index, const void *queries, size_t nq,
 int pcc_radius_fill(pcc_index *index, const void *queries, size_t nq,
                     size_t stride_bytes, int mem, double radius, int sorted,
                     const int64_t *offsets, int32_t *idx, float *d2);
-/* the same with radiusSearch's max_nn: 0, or anything from the cloud's size on, means "all" and is the
- * pair above; otherwise the count is min(count, max_nn) and the row holds the max_nn NEAREST neighbours within the radius,
+/* the same with radiusSearch's max_nn: 0, or anything from the number of FINITE indexed points on (PCL's
+ * total_nr_points_), means "all" and is the pair above; a max_nn below that but beyond PCC_KNN_MAX_K is refused by both calls
+ * (PCC_ERR_UNSUPPORTED); otherwise the count is min(count, max_nn) and the row holds the max_nn NEAREST neighbours within the radius,
  * ascending by (d2, idx) whatever `sorted` says (FLANN's KNNRadiusResultSet).  Served by the k-NN kernels with k = max_nn
  * cut at the radius: the reference's own call sites pass 0 (src/segmentation.cpp:125-131), this is for completeness. */
 int pcc_radius_count_max(pcc_index *index, const void *queries, size_t nq, size_t stride_bytes, int mem, double radius,
@@ -354,10 +355,11 @@ int pcc_first_within(pcc_index *index, const void *queries, size_t nq, size_t st
  *   (src/comparator.cpp:564-577, 1089-1110, 1523-1541) when a node's GPUs share one cloud pair.
  * A pcc_comm is one rank of an RCCL communicator: one per (process, GPU).  librccl.so.1 is loaded when the first one is
  * made (dlopen); libpcc_nn.so does not depend on it otherwise.
- * The calls marked "collective" must be made by EVERY rank of the communicator with arguments that are valid on every
- * rank: a rank that returns an error before its first collective (a shard outside the cloud, an allocation failure) leaves
- * the others waiting in theirs, as with any RCCL program.  pcc_index_create_broadcast tells the other ranks when the ROOT
- * could not index its cloud (they return PCC_ERR_EMPTY instead of waiting). */
+ * The calls marked "collective" must be made by EVERY rank of the communicator.  A failure on ONE rank -- a shard outside
+ * the cloud, an empty shard, an allocation that is refused, a cloud the root cannot index -- does not leave the others
+ * waiting: before every data collective the ranks agree on one status word (all-reduce MIN), and every rank returns the
+ * failing rank's code (pcc_last_error on the others: "another rank of the communicator failed").  Only a rank that never
+ * makes the call (or passes no communicator) can still stall its peers, as in any RCCL program. */
 typedef struct pcc_comm pcc_comm;
 #define PCC_COMM_ID_BYTES 128
 /* one process per GPU: rank 0 makes the id (PCC_COMM_ID_BYTES bytes), hands it to the other ranks over whatever launched
@@ -405,6 +407,11 @@ int pcc_sor_sharded(pcc_index *index, pcc_comm *comm, size_t start, size_t count
 int pcc_index_stats(const pcc_index *index, uint64_t stats[8]);
 /* 1 when this library was built with the pair counter (-DPCC_COUNT_PAIRS: the profiling build), else 0 */
 int pcc_counts_pairs(void);
+/* test hook: the nth device allocation the library makes from now on (process-wide, nth >= 1) fails as an exhausted
+ * hipMalloc does -- PCC_ERR_NOMEM from whichever call needed it; 0 disarms.  The reference maps every failure to a return
+ * code (src/comparator.cpp:1123,1134,1179); this is how the tests reach the library's allocation-failure paths, the
+ * collective ones above all (a rank that cannot allocate must take its peers out of the call, not leave them waiting). */
+int pcc_debug_fail_alloc(int nth);
 /* HIP-event timing of the library's own kernels, recorded on the index's stream
  * (events of another stream would not see them).  After enabling, every
  * set_input / search records events into a 64-call ring without synchronising;

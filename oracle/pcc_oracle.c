@@ -1395,11 +1395,15 @@ int orc_region_growing_rgb(const void *pts, size_t n, size_t stride, const uint8
         snb_n[s] = hn;
     }
     /* --- applyRegionMergingAlgorithm */
+    /* segment colours: PCL sums the channels in std::vector<unsigned int> (exact), then
+     * static_cast<unsigned int>(static_cast<float>(sum) / static_cast<float>(num_pts_in_segment_)) */
     float *col = (float *)calloc((size_t)ns * 3, sizeof(float));
+    unsigned int *csum = (unsigned int *)calloc((size_t)ns * 3, sizeof(unsigned int));
     for (size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 3; ++c) col[(size_t)seg[i] * 3 + c] += rgb[i * 3 + c];
+        for (int c = 0; c < 3; ++c) csum[(size_t)seg[i] * 3 + c] += rgb[i * 3 + c];
     for (int s = 0; s < ns; ++s)
-        for (int c = 0; c < 3; ++c) col[(size_t)s * 3 + c] = (float)(unsigned int)(col[(size_t)s * 3 + c] / seg_pts[s]);
+        for (int c = 0; c < 3; ++c) col[(size_t)s * 3 + c] = (float)(unsigned int)((float)csum[(size_t)s * 3 + c] / (float)seg_pts[s]);
+    free(csum);
     int32_t *sreg = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
     unsigned int *rpts = (unsigned int *)calloc((size_t)ns, sizeof(unsigned int));
     for (int s = 0; s < ns; ++s) sreg[s] = -1;

@@ -36,6 +36,7 @@ SYMBOLS = [
     "pcc_rigid_from_sums_about", "pcc_icp_step_about",
     "pcc_normals_radius", "pcc_index_wait_stream", "pcc_stream_wait_index", "pcc_index_clone_to_device", "pcc_index_set_tie_order",
     "pcc_index_set_option", "pcc_index_get_option", "pcc_index_clone_to_devices", "pcc_counts_pairs", "pcc_index_sor_on_device",
+    "pcc_debug_fail_alloc",
     "pcc_comm_unique_id", "pcc_comm_create_rank", "pcc_comm_create_local", "pcc_comm_destroy", "pcc_comm_info",
     "pcc_index_create_broadcast", "pcc_icp_align_sharded", "pcc_sor_partial", "pcc_sor_threshold", "pcc_sor_sharded",
 ]
@@ -472,6 +473,18 @@ class Index:
         _check(LIB.pcc_radius_fill_max(self._h, ptr, n, stride, mem, float(radius), int(sorted), int(max_nn), po, pi, pd))
         self._after(st)
         return offs, idx[:total], d2[:total]
+
+    def radius_fill(self, queries, radius: float, offsets, sorted: bool = True, max_nn: int = 0):
+        """the fill pass alone, for CSR offsets the caller already holds (host queries, numpy int64 offsets[nq + 1])"""
+        ptr, n, stride, mem = _points(queries)
+        assert mem == MEM_HOST and len(offsets) == n + 1
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        total = int(offs[-1])
+        idx = np.empty(max(total, 1), np.int32)
+        d2 = np.empty(max(total, 1), np.float32)
+        _check(LIB.pcc_radius_fill_max(self._h, ptr, n, stride, mem, float(radius), int(sorted), int(max_nn), offs.ctypes.data,
+                                       idx.ctypes.data, d2.ctypes.data))
+        return idx[:total], d2[:total]
 
     def euclidean_clusters(self, tolerance: float, min_size: int, max_size: int, device_out=None,
                            max_sizes: int = 65536):

@@ -3,6 +3,7 @@
 // no CPU compute fallback: without a HIP device every entry point fails with
 // PCC_ERR_DEVICE.
 #include "pcc_internal.hpp"
+#include <atomic>
 #include "rigid_solve.hpp"
 #include <cstdarg>
 #include <cstdio>
@@ -91,8 +92,15 @@ void Options::from_env() {
     }
 }
 
+// test hook (pcc_debug_fail_alloc): the n-th device allocation from now on fails as an exhausted hipMalloc would
+static std::atomic<int> g_fail_alloc{0};
+
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap && p) return PCC_OK;
+    if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1) == 1) {
+        set_error("hipMalloc(%zu) failed: injected by pcc_debug_fail_alloc", bytes);
+        return PCC_ERR_NOMEM;  // (the buffer keeps what it had: exactly what a refused growth leaves behind)
+    }
     if (bytes == 0) bytes = 256;
     size_t want = bytes + bytes / 8;  // slack so slowly growing batches do not realloc each call
     want = (want + 255) & ~(size_t)255;
@@ -278,7 +286,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c, &ix->rows_idx, &ix->rows_d2};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)
@@ -532,6 +540,10 @@ int pcc_index_get_option(pcc_index* ix, int option, double* value) {
     *value = pd ? *pd : (double)*pi;
     return PCC_OK;
 }
+int pcc_debug_fail_alloc(int nth) {
+    g_fail_alloc.store(nth > 0 ? nth : 0);
+    return PCC_OK;
+}
 int pcc_counts_pairs(void) {
 #ifdef PCC_COUNT_PAIRS
     return 1;
@@ -658,6 +670,17 @@ static inline float radius2(double radius) { return (float)(radius * radius); }
 int pcc_radius_count(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int32_t* counts) {
     return pcc_radius_count_max(ix, q, nq, stride, mem, radius, 0u, counts);
 }
+// radiusSearch's max_nn, decided under the handle's lock for count and fill alike: "all" when it is 0 or reaches the number of
+// FINITE indexed points (PCL's total_nr_points_); beyond PCC_KNN_MAX_K both calls refuse (the rows come from the k-NN kernels)
+static int radius_max_mode(pcc_index* ix, unsigned int max_nn, bool* all) {
+    PCC_TRY(sync_info(ix));
+    *all = max_nn == 0 || (size_t)max_nn >= ix->n_valid;
+    if (!*all && max_nn > (unsigned int)PCC_KNN_MAX_K) { set_error("max_nn=%u beyond %d", max_nn, PCC_KNN_MAX_K); return PCC_ERR_UNSUPPORTED; }
+    return PCC_OK;
+}
+static int radius_fill_impl(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int sorted,
+                            const int64_t* offsets, int32_t* idx, float* d2);
+
 int pcc_radius_count_max(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, unsigned int max_nn,
                          int32_t* counts) {
     PCC_ENTER(ix);
@@ -666,6 +689,8 @@ int pcc_radius_count_max(pcc_index* ix, const void* q, size_t nq, size_t stride,
     if (!(radius >= 0)) { set_error("bad radius"); return PCC_ERR_INVALID; }
     if (nq == 0) return PCC_OK;
     PCC_TRY(ensure_grid(ix));
+    bool max_nn_is_all = true;
+    PCC_TRY(radius_max_mode(ix, max_nn, &max_nn_is_all));  // (the same decision, and the same refusal, as the fill's)
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
     PCC_TRY(stage_queries(ix, q, nq, stride, mem));
@@ -673,9 +698,9 @@ int pcc_radius_count_max(pcc_index* ix, const void* q, size_t nq, size_t stride,
     if (mem == PCC_MEM_HOST) { PCC_TRY(ix->out_idx.reserve(nq * sizeof(int32_t))); dcnt = ix->out_idx.as<int32_t>(); }
     PCC_HIP(hipMemsetAsync(dcnt, 0, nq * sizeof(int32_t), ix->stream));
     PCC_TRY(grid_radius(ix, ix->q_packed.as<float4>(), nq, (float)radius, radius2(radius), dcnt, nullptr, nullptr, 0));
-    // KdTreeFLANN::radiusSearch(..., max_nn): 0 or anything from the cloud's size on means "all"; else FLANN keeps the
-    // max_nn nearest within the radius
-    if (max_nn != 0 && (size_t)max_nn < ix->n_orig) PCC_TRY(launch_clamp_counts(ix->stream, dcnt, nq, (int32_t)std::min<unsigned int>(max_nn, 0x7fffffffu)));
+    // KdTreeFLANN::radiusSearch(..., max_nn): 0 or anything from the cloud's size on means "all" -- the size PCL compares
+    // with is total_nr_points_, the FINITE points --; else FLANN keeps the max_nn nearest within the radius
+    if (!max_nn_is_all) PCC_TRY(launch_clamp_counts(ix->stream, dcnt, nq, (int32_t)max_nn));
     ev_mark(ix, EV_CALL1);
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, dcnt, counts, nq, mem));
@@ -686,8 +711,6 @@ int pcc_radius_count_max(pcc_index* ix, const void* q, size_t nq, size_t stride,
 
 int pcc_radius_fill_max(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int sorted, unsigned int max_nn,
                         const int64_t* offsets, int32_t* idx, float* d2) {
-    if (!ix) { set_error("null index"); return PCC_ERR_INVALID; }
-    if (max_nn == 0 || (size_t)max_nn >= ix->n_orig) return pcc_radius_fill(ix, q, nq, stride, mem, radius, sorted, offsets, idx, d2);
     // the max_nn NEAREST within the radius, ascending (FLANN's KNNRadiusResultSet, whatever `sorted` says): the k-NN rows
     // with k = max_nn, cut at the radius.  Unused by the reference's own call sites (src/segmentation.cpp:125-131 passes 0):
     // correctness first, no kernel of its own
@@ -695,9 +718,11 @@ int pcc_radius_fill_max(pcc_index* ix, const void* q, size_t nq, size_t stride, 
     PCC_TRY(check_points(q, nq, stride, mem));
     if (!offsets) { set_error("null offsets"); return PCC_ERR_INVALID; }
     if (!(radius >= 0)) { set_error("bad radius"); return PCC_ERR_INVALID; }
-    if (max_nn > (unsigned int)PCC_KNN_MAX_K) { set_error("max_nn=%u beyond %d", max_nn, PCC_KNN_MAX_K); return PCC_ERR_UNSUPPORTED; }
     if (nq == 0) return PCC_OK;
     PCC_TRY(ensure_grid(ix));
+    bool max_nn_is_all = true;
+    PCC_TRY(radius_max_mode(ix, max_nn, &max_nn_is_all));
+    if (max_nn_is_all) return radius_fill_impl(ix, q, nq, stride, mem, radius, sorted, offsets, idx, d2);
     PCC_TRY(stage_queries(ix, q, nq, stride, mem));
     const int K = (int)max_nn;
     int64_t total = 0;
@@ -718,10 +743,13 @@ int pcc_radius_fill_max(pcc_index* ix, const void* q, size_t nq, size_t stride, 
     int32_t* ridx = nullptr;
     float* rd2 = nullptr;
     if (rows) {
-        PCC_TRY(ix->scratch_e.reserve(nq * (size_t)K * sizeof(int32_t)));
-        PCC_TRY(ix->scratch_f.reserve(nq * (size_t)K * sizeof(float)));
-        ridx = ix->scratch_e.as<int32_t>();
-        rd2 = ix->scratch_f.as<float>();
+        // (buffers of their own: the query sort inside grid_knn re-reserves scratch_e as its pair buffer, and a reserve
+        // that grows FREES the old block -- with the rows in scratch_e a fresh handle, nq = 1 or max_nn = 1 left the k-NN
+        // kernels writing into freed memory)
+        PCC_TRY(ix->rows_idx.reserve(nq * (size_t)K * sizeof(int32_t)));
+        PCC_TRY(ix->rows_d2.reserve(nq * (size_t)K * sizeof(float)));
+        ridx = ix->rows_idx.as<int32_t>();
+        rd2 = ix->rows_d2.as<float>();
         PCC_TRY(grid_knn(ix, ix->q_packed.as<float4>(), nq, K, nullptr, ridx, rd2));
     } else {
         PCC_TRY(ix->out_packed.reserve(nq * (size_t)K * sizeof(unsigned long long)));
@@ -748,6 +776,11 @@ int pcc_radius_fill_max(pcc_index* ix, const void* q, size_t nq, size_t stride, 
 int pcc_radius_fill(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int sorted,
                     const int64_t* offsets, int32_t* idx, float* d2) {
     PCC_ENTER(ix);
+    return radius_fill_impl(ix, q, nq, stride, mem, radius, sorted, offsets, idx, d2);
+}
+// (the caller holds the handle's lock)
+static int radius_fill_impl(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, double radius, int sorted,
+                            const int64_t* offsets, int32_t* idx, float* d2) {
     PCC_TRY(check_points(q, nq, stride, mem));
     if (!offsets) { set_error("null offsets"); return PCC_ERR_INVALID; }
     if (nq == 0) return PCC_OK;
@@ -1202,27 +1235,39 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
 int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* src, size_t n, size_t stride, int mem, int max_iter,
                         int fixed, float T[16], double* fitness, int* iterations, int* converged) {
     PCC_ENTER(ix);
-    PCC_TRY(check_points(src, n, stride, mem));
-    if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
-    if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    memcpy(T, I, sizeof(I));
-    if (iterations) *iterations = 0;
-    if (converged) *converged = 0;
-    if (n == 0 && hooks) { set_error("sharded ICP: every rank needs a non-empty shard"); return PCC_ERR_INVALID; }
-    if (n == 0) return PCC_OK;
-    // the source stays resident: q_packed is the moving cloud, icp_src keeps the input
-    PCC_TRY(stage_queries(ix, src, n, stride, mem));
-    PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
-    PCC_HIP(hipMemcpyAsync(ix->icp_src.p, ix->q_packed.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ix->stream));
     int it = 0;
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
-    // the sums of every pass are taken about a point of the source cloud (k_icp_center: no cancellation in the
-    // covariance for clouds far from the origin); it sits behind the loop state in device memory
-    PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + (3 + 17) * sizeof(double)));
-    double* center_dev = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
-    PCC_TRY(launch_icp_center(ix->stream, ix->q_packed.as<float4>(), n, center_dev));
+    double* center_dev = nullptr;
+    // Everything that can fail on ONE rank alone -- argument checks, staging, allocations -- comes before the first
+    // collective and ends in a status the ranks agree on (hooks->agree: all-reduce MIN of one word), so a rank that
+    // cannot go on takes the others out with it instead of leaving them in the broadcast below (comm.hip).
+    auto prepare = [&]() -> int {
+        PCC_TRY(check_points(src, n, stride, mem));
+        if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
+        if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
+        memcpy(T, I, sizeof(I));
+        if (iterations) *iterations = 0;
+        if (converged) *converged = 0;
+        if (n == 0 && hooks) { set_error("sharded ICP: every rank needs a non-empty shard"); return PCC_ERR_INVALID; }
+        if (n == 0) return PCC_OK;
+        // the source stays resident: q_packed is the moving cloud, icp_src keeps the input
+        PCC_TRY(stage_queries(ix, src, n, stride, mem));
+        PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
+        PCC_HIP(hipMemcpyAsync(ix->icp_src.p, ix->q_packed.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ix->stream));
+        // the sums of every pass are taken about a point of the source cloud (k_icp_center: no cancellation in the
+        // covariance for clouds far from the origin); it sits behind the loop state in device memory
+        PCC_TRY(ix->icp_state.reserve(sizeof(IcpState) + (3 + 17) * sizeof(double)));
+        PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
+        center_dev = reinterpret_cast<double*>(ix->icp_state.as<char>() + sizeof(IcpState));
+        PCC_TRY(launch_icp_center(ix->stream, ix->q_packed.as<float4>(), n, center_dev));
+        return PCC_OK;
+    };
+    int st_prep = prepare();
+    if (hooks) st_prep = hooks->agree(hooks->ctx, st_prep);
+    if (st_prep != PCC_OK) return st_prep;
+    if (n == 0) return PCC_OK;
     if (hooks) PCC_TRY(hooks->bcast_f64(hooks->ctx, center_dev, 3, 0, ix->stream));  // every rank about rank 0's point
     const int warm_env = ix->opt.icp_warm;         // 0: every pass from scratch (measurements)
     const int loop_env = hooks ? 1 : ix->opt.icp_device_loop;  // 0: the host-driven loop (kept for comparison: same bits)
@@ -1239,7 +1284,6 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
         // read-back and a launch gap per pass, ~65 us of 0.44 ms); after each chunk the host looks whether the loop
         // has stopped.  Passes enqueued past the stop are no-ops on the state (identity transform), so a chunk costs at
         // most its own length in wasted searches -- none with a fixed count, where the whole loop is one chunk.
-        PCC_TRY(ix->scratch_a.reserve((size_t)ICP_MAX_BLOCKS * 17 * sizeof(double)));
         IcpState h0{};
         memcpy(h0.Ti, I, sizeof(I));
         memcpy(h0.T, I, sizeof(I));

@@ -101,6 +101,21 @@ static int check_comm(const pcc_comm* c) {
     return PCC_OK;
 }
 
+// One status word agreed over the ranks before a data collective: the MINIMUM of the local statuses (PCC_OK = 0, every
+// error is negative), so all ranks return the same code and none is left waiting in a collective its peer never joins
+// -- the reference maps every failure to a return code (src/comparator.cpp:1123,1134,1179), it never hangs.  Costs one
+// 4-byte all-reduce; called at the same point of the call on every rank, with a failed rank passing its error.
+static int agree_status(pcc_comm* c, int local) {
+    int* w = c->word.as<int>() + 16;
+    int agreed = local;
+    if (hipMemcpy(w, &local, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { set_error("status exchange: hipMemcpy failed"); return PCC_ERR_DEVICE; }
+    PCC_NCCL(rccl()->AllReduce(w, w, 1, ncclInt32, ncclMin, c->nccl, nullptr));
+    if (hipMemcpy(&agreed, w, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { set_error("status exchange: hipMemcpy failed"); return PCC_ERR_DEVICE; }
+    if (agreed != PCC_OK && local == PCC_OK) set_error("another rank of the communicator failed (status %d)", agreed);
+    return agreed;
+}
+static int agree_hook(void* ctx, int local) { return agree_status(static_cast<pcc_comm*>(ctx), local); }
+
 }  // namespace pcc
 
 using namespace pcc;
@@ -158,9 +173,15 @@ int pcc_comm_create_local(const int* devices, int count, pcc_comm** out) {
         c->rank = k;
         c->world = count;
         c->device = devices[k];
-        SetDevice g(devices[k]);
-        (void)c->word.reserve(256);
         out[k] = c;
+    }
+    for (int k = 0; k < count; ++k) {  // the scalar-exchange words of every rank, or no communicator at all
+        SetDevice g(devices[k]);
+        if (!g.ok || out[k]->word.reserve(256) != PCC_OK) {
+            if (!g.ok) set_error("hipSetDevice(%d) failed", devices[k]);
+            for (int j = 0; j < count; ++j) { pcc_comm_destroy(out[j]); out[j] = nullptr; }
+            return g.ok ? PCC_ERR_NOMEM : PCC_ERR_DEVICE;
+        }
     }
     return PCC_OK;
 }
@@ -195,36 +216,45 @@ int pcc_index_create_broadcast(pcc_comm* c, int root, const void* pts, size_t n,
     if (!g.ok) { set_error("hipSetDevice(%d) failed", c->device); return PCC_ERR_DEVICE; }
     pcc_index* ix = nullptr;
     unsigned long long n64 = 0;
-    int st_root = PCC_OK;
-    if (c->rank == root) {
-        st_root = pcc_index_create(pts, n, stride, 3, mem, c->device, engine, &ix);
-        n64 = st_root == PCC_OK ? (unsigned long long)n : 0ull;  // (0: the other ranks learn that the root failed)
-    }
-    // the size first (a device word; the default stream orders the three steps)
+    auto fail = [&](int st) { if (ix) pcc_index_destroy(ix); ix = nullptr; return st; };
+    // step 1: the root indexes its cloud, every other rank makes its empty handle; one agreed status
+    int st = c->rank == root ? pcc_index_create(pts, n, stride, 3, mem, c->device, engine, &ix) : make_handle(c->device, engine, &ix);
+    if (st != PCC_OK) ix = nullptr;
+    if ((st = agree_status(c, st)) != PCC_OK) return fail(st);
+    // step 2: the size (a device word; the default stream orders the three steps)
+    n64 = c->rank == root ? (unsigned long long)n : 0ull;
     unsigned long long* w = c->word.as<unsigned long long>();
     PCC_HIP(hipMemcpy(w, &n64, sizeof(n64), hipMemcpyHostToDevice));
-    PCC_NCCL(rccl()->Broadcast(w, w, 1, ncclUint64, root, c->nccl, nullptr));
-    PCC_HIP(hipMemcpy(&n64, w, sizeof(n64), hipMemcpyDeviceToHost));
-    if (c->rank == root && st_root != PCC_OK) return st_root;
-    if (n64 == 0) { set_error("rank %d could not index the reference cloud", root); return PCC_ERR_EMPTY; }
+    {
+        ncclResult_t r = rccl()->Broadcast(w, w, 1, ncclUint64, root, c->nccl, nullptr);
+        if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); return fail(PCC_ERR_DEVICE); }
+    }
+    if (hipMemcpy(&n64, w, sizeof(n64), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return fail(PCC_ERR_DEVICE); }
+    // step 3: room for the copy on the other ranks; one agreed status BEFORE the data collective
+    st = PCC_OK;
+    if (c->rank != root) {
+        std::lock_guard<std::mutex> lock(ix->mu);
+        st = n64 ? ix->icp_src.reserve((size_t)n64 * sizeof(float4)) : PCC_ERR_EMPTY;
+    }
+    if ((st = agree_status(c, st)) != PCC_OK) return fail(st);
+    // step 4: the packed cloud, 16 B per point, in one broadcast on the handle's stream; every other rank builds over its copy
     if (c->rank == root) {
         std::lock_guard<std::mutex> lock(ix->mu);
-        PCC_NCCL(rccl()->Broadcast(ix->refs.p, ix->refs.p, (size_t)n64 * 4, ncclFloat, root, c->nccl, ix->stream));
-        PCC_HIP(hipStreamSynchronize(ix->stream));
+        ncclResult_t r = rccl()->Broadcast(ix->refs.p, ix->refs.p, (size_t)n64 * 4, ncclFloat, root, c->nccl, ix->stream);
+        if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); st = PCC_ERR_DEVICE; }
+        else if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("broadcast failed: %s", hipGetErrorString(hipGetLastError())); st = PCC_ERR_DEVICE; }
     } else {
-        PCC_TRY(make_handle(c->device, engine, &ix));
-        auto fail = [&](int s) { pcc_index_destroy(ix); return s; };
         std::lock_guard<std::mutex> lock(ix->mu);
-        int st = ix->icp_src.reserve((size_t)n64 * sizeof(float4));
-        if (st != PCC_OK) return fail(st);
         ncclResult_t r = rccl()->Broadcast(ix->icp_src.p, ix->icp_src.p, (size_t)n64 * 4, ncclFloat, root, c->nccl, ix->stream);
-        if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); return fail(PCC_ERR_DEVICE); }
+        if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); st = PCC_ERR_DEVICE; }
         // (non-finite points get their NaN back so that the build sees what the root's upload saw; then the usual build)
-        if ((st = launch_nanify(ix->stream, ix->icp_src.as<float4>(), (size_t)n64)) != PCC_OK) return fail(st);
-        if ((st = set_input(ix, ix->icp_src.p, (size_t)n64, sizeof(float4), PCC_MEM_DEVICE)) != PCC_OK) return fail(st);
-        if ((st = sync_info(ix)) != PCC_OK) return fail(st);
-        if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); return fail(PCC_ERR_DEVICE); }
+        if (st == PCC_OK) st = launch_nanify(ix->stream, ix->icp_src.as<float4>(), (size_t)n64);
+        if (st == PCC_OK) st = set_input(ix, ix->icp_src.p, (size_t)n64, sizeof(float4), PCC_MEM_DEVICE);
+        if (st == PCC_OK) st = sync_info(ix);
+        if (st == PCC_OK && hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("index build failed: %s", hipGetErrorString(hipGetLastError())); st = PCC_ERR_DEVICE; }
     }
+    // step 5: every rank holds an index, or none does
+    if ((st = agree_status(c, st)) != PCC_OK) return fail(st);
     *out = ix;
     if (n_out) *n_out = (size_t)n64;
     return PCC_OK;
@@ -235,9 +265,10 @@ int pcc_index_create_broadcast(pcc_comm* c, int root, const void* pts, size_t n,
 int pcc_icp_align_sharded(pcc_index* ix, pcc_comm* c, const void* src_shard, size_t n, size_t stride, int mem, int max_iter, int fixed,
                           float T[16], double* fitness, int* iterations, int* converged) {
     PCC_TRY(check_comm(c));
-    if (!ix) { set_error("null index"); return PCC_ERR_INVALID; }
-    if (ix->device != c->device) { set_error("index on device %d, communicator on device %d", ix->device, c->device); return PCC_ERR_INVALID; }
-    const IcpHooks hooks{c, allreduce_sum_f64, bcast_f64};
+    // (a rank that fails here joins the one status exchange icp_align_impl makes before its first collective)
+    if (!ix) { set_error("null index"); return agree_status(c, PCC_ERR_INVALID); }
+    if (ix->device != c->device) { set_error("index on device %d, communicator on device %d", ix->device, c->device); return agree_status(c, PCC_ERR_INVALID); }
+    const IcpHooks hooks{c, allreduce_sum_f64, bcast_f64, agree_hook};
     return icp_align_impl(ix, &hooks, src_shard, n, stride, mem, max_iter, fixed, T, fitness, iterations, converged);
 }
 
@@ -300,24 +331,35 @@ int pcc_sor_threshold(const double sums[4], uint64_t n_valid, int mean_k, double
 int pcc_sor_sharded(pcc_index* ix, pcc_comm* c, size_t start, size_t count, int mean_k, double stddev_mult, int mem,
                     float* mean_dist, uint8_t* inlier, double* threshold, size_t* kept_total) {
     PCC_TRY(check_comm(c));
-    if (!ix) { set_error("null index"); return PCC_ERR_INVALID; }
-    if (ix->device != c->device) { set_error("index on device %d, communicator on device %d", ix->device, c->device); return PCC_ERR_INVALID; }
-    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
+    // (every failure of one rank alone ends in the status exchange below, never in a peer waiting for its all-reduce)
+    if (!ix) { set_error("null index"); return agree_status(c, PCC_ERR_INVALID); }
+    if (ix->device != c->device) { set_error("index on device %d, communicator on device %d", ix->device, c->device); return agree_status(c, PCC_ERR_INVALID); }
+    if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return agree_status(c, PCC_ERR_INVALID); }
     std::lock_guard<std::mutex> lock(ix->mu);
     SetDevice g(ix->device);
     hipStream_t s = ix->stream;
     const int K = mean_k + 1;
     float* dmean = nullptr;
-    PCC_TRY(sor_shard_means(ix, start, count, mean_k, &dmean));
-    PCC_TRY(ix->scratch_a.reserve((size_t)(3 * 1024 + 4) * sizeof(double) + 64));
-    double* out4 = ix->scratch_a.as<double>() + 3 * 1024;
-    PCC_TRY(launch_sor_partial(s, dmean, count, ix->scratch_a.as<double>(), out4));
+    double* out4 = nullptr;
+    uint8_t* dmask = nullptr;
+    auto prepare = [&]() -> int {  // shard search + every allocation of the exact path
+        if (!g.ok) { set_error("hipSetDevice(%d) failed", ix->device); return PCC_ERR_DEVICE; }
+        PCC_TRY(sor_shard_means(ix, start, count, mean_k, &dmean));
+        PCC_TRY(ix->scratch_a.reserve((size_t)(3 * 1024 + 4) * sizeof(double) + 64));
+        out4 = ix->scratch_a.as<double>() + 3 * 1024;
+        PCC_TRY(ix->scratch_b.reserve(count + 64));
+        dmask = mem == PCC_MEM_DEVICE && inlier ? inlier : ix->scratch_b.as<uint8_t>();
+        PCC_TRY(launch_sor_partial(s, dmean, count, ix->scratch_a.as<double>(), out4));
+        return PCC_OK;
+    };
+    {
+        const int st = agree_status(c, prepare());
+        if (st != PCC_OK) return st;
+    }
     PCC_NCCL(rccl()->AllReduce(out4, out4, 2, ncclDouble, ncclSum, c->nccl, s));
     PCC_NCCL(rccl()->AllReduce(out4 + 2, out4 + 2, 2, ncclDouble, ncclMin, c->nccl, s));
     struct { double sum, sq, thr; unsigned long long kept; unsigned int exact, pad; } hs{};
     void* st_dev = ix->small.as<char>() + 256;
-    PCC_TRY(ix->scratch_b.reserve(count + 64));
-    uint8_t* dmask = mem == PCC_MEM_DEVICE && inlier ? inlier : ix->scratch_b.as<uint8_t>();
     PCC_TRY(launch_sor_threshold_mask(s, dmean, count, ix->d_grid.as<GridDev>(), K, stddev_mult, out4, st_dev, dmask));
     unsigned long long* kept_dev = reinterpret_cast<unsigned long long*>(static_cast<char*>(st_dev) + 24);
     PCC_NCCL(rccl()->AllReduce(kept_dev, kept_dev, 1, ncclUint64, ncclSum, c->nccl, s));
@@ -329,12 +371,16 @@ int pcc_sor_sharded(pcc_index* ix, pcc_comm* c, size_t start, size_t count, int 
         // (the same verdict on every rank) PCL's order decides the last bits: every rank gets ALL mean distances -- its own
         // shard in a zeroed array of the cloud's size, summed over the ranks (adding zeros is exact) -- and walks them in order
         const size_t no = ix->n_orig;
-        PCC_TRY(ix->scratch_c.reserve(no * sizeof(float) + 64));
+        {  // (hs.exact is the same on every rank, so every rank is here: agree on the allocations before the big all-reduce)
+            int st = ix->scratch_c.reserve(no * sizeof(float) + 64);
+            if (st == PCC_OK) st = ix->host_a.reserve(no * sizeof(float));
+            if (st == PCC_OK) st = ix->host_b.reserve(count + 64);
+            if ((st = agree_status(c, st)) != PCC_OK) return st;
+        }
         float* all = ix->scratch_c.as<float>();
         PCC_HIP(hipMemsetAsync(all, 0, no * sizeof(float), s));
         if (count) PCC_HIP(hipMemcpyAsync(all + start, dmean, count * sizeof(float), hipMemcpyDeviceToDevice, s));
         PCC_NCCL(rccl()->AllReduce(all, all, no, ncclFloat, ncclSum, c->nccl, s));
-        PCC_TRY(ix->host_a.reserve(no * sizeof(float)));
         float* hm = ix->host_a.as<float>();
         PCC_HIP(hipMemcpyAsync(hm, all, no * sizeof(float), hipMemcpyDeviceToHost, s));
         PCC_HIP(hipStreamSynchronize(s));
@@ -347,7 +393,6 @@ int pcc_sor_sharded(pcc_index* ix, pcc_comm* c, size_t start, size_t count, int 
         thr = mean + stddev_mult * std::sqrt(var);
         kept = 0;
         for (size_t i = 0; i < no; ++i) kept += !(hm[i] > thr);
-        PCC_TRY(ix->host_b.reserve(count + 64));
         uint8_t* hin = ix->host_b.as<uint8_t>();
         for (size_t i = 0; i < count; ++i) hin[i] = !(hm[start + i] > thr);
         if (count) PCC_HIP(hipMemcpyAsync(dmask, hin, count, hipMemcpyHostToDevice, s));

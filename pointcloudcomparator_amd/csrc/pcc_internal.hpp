@@ -150,7 +150,8 @@ struct pcc_index {
     // scratch (grow-only, reused across calls on the index's stream)
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
         scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, icp_state, vox_a, vox_b, vox_c,
-        mp_a, mp_b, mp_c;  // cellsort_mp.hip: two intermediate point buffers, bucket counters
+        mp_a, mp_b, mp_c,  // cellsort_mp.hip: two intermediate point buffers, bucket counters
+        rows_idx, rows_d2;  // pcc_radius_fill_max: the k-NN rows it cuts at the radius (no scratch the query sort touches)
     // PCC_TIES_FLANN (flann_tree.hpp): kd-tree of FLANN's shape, built on the host at the first search after every
     // set_input, walked on the device (flann_order.hip)
     int tie_mode = PCC_TIES_LOWEST_INDEX;
@@ -326,6 +327,7 @@ struct IcpHooks {
     void* ctx;
     int (*allreduce_sum_f64)(void* ctx, double* dev, int count, hipStream_t s);
     int (*bcast_f64)(void* ctx, double* dev, int count, int root, hipStream_t s);
+    int (*agree)(void* ctx, int local_status);  // the worst status over the ranks (one all-reduce): same return everywhere
 };
 int icp_align_impl(pcc_index* ix, const IcpHooks* hooks, const void* src, size_t n, size_t stride, int mem, int max_iter, int fixed,
                    float T[16], double* fitness, int* iterations, int* converged);

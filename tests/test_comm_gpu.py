@@ -132,3 +132,45 @@ def test_python_sharding_helper_over_the_real_partial_sums(gpu):
                                                                     len(pts), 0, 1)
     assert start == 0 and exact and sthr == thr and skept == kept
     assert (_bits(smd) == _bits(md)).all() and (sinl == inl.astype(bool)).all()
+
+
+def test_a_rank_that_cannot_allocate_returns_nomem_and_the_communicator_stays_usable(gpu):
+    """Collectives that cannot hang: every failure of one rank alone (here an injected allocation failure, hook
+    pcc_debug_fail_alloc) ends in the status word the ranks agree on before the data collective, so the call returns the
+    failing rank's code -- PCC_ERR_NOMEM on the spot -- and the SAME communicator and handles run the next call.  The
+    reference maps every failure to a return code (src/comparator.cpp:1123,1134,1179)."""
+    tgt = synth.corridor_cloud(40000, synth.SEED_A)
+    src = synth.rigid_offset(synth.corridor_cloud(15000, synth.SEED_B), rot_deg=0.4, t=(0.01, 0.0, -0.005))
+    L = capi.LIB
+    with capi.Comm.from_id(capi.comm_unique_id(), 1, 0, 0) as comm:
+        # pcc_index_create_broadcast: the root's first allocation is refused
+        L.pcc_debug_fail_alloc(1)
+        with pytest.raises(capi.PccError) as e:
+            capi.Index.broadcast(comm, 0, tgt)
+        L.pcc_debug_fail_alloc(0)
+        assert e.value.status == -4 and "injected" in str(e.value)
+        with capi.Index.broadcast(comm, 0, tgt) as bx, capi.Index(tgt) as ix:
+            # pcc_sor_sharded on a fresh handle: the k-NN rows cannot be allocated
+            L.pcc_debug_fail_alloc(1)
+            with pytest.raises(capi.PccError) as e:
+                bx.sor_sharded(comm, 0, len(tgt), 50, 1.5)
+            L.pcc_debug_fail_alloc(0)
+            assert e.value.status == -4
+            md, inl, thr, kept = ix.sor(50, 1.5)
+            smd, sinl, sthr, skept = bx.sor_sharded(comm, 0, len(tgt), 50, 1.5)
+            assert (_bits(md) == _bits(smd)).all() and (inl == sinl).all() and thr == sthr and kept == skept
+            # pcc_icp_align_sharded: the staging buffer of the source shard is refused
+            L.pcc_debug_fail_alloc(1)
+            with pytest.raises(capi.PccError) as e:
+                bx.icp_align_sharded(comm, src, max_iter=5, fixed=True)
+            L.pcc_debug_fail_alloc(0)
+            assert e.value.status == -4
+            T1, f1, it1, c1 = ix.icp_align(src, max_iter=5, fixed=True)
+            T2, f2, it2, c2 = bx.icp_align_sharded(comm, src, max_iter=5, fixed=True)
+            assert (T1.view(np.uint32) == T2.view(np.uint32)).all() and f1 == f2 and it1 == it2 == 5 and c1 == c2
+    # pcc_comm_create_local: the scalar-exchange word of a rank is refused -> no communicator, an error, nothing leaked
+    L.pcc_debug_fail_alloc(1)
+    with pytest.raises(capi.PccError) as e:
+        capi.Comm.local([0])
+    L.pcc_debug_fail_alloc(0)
+    assert e.value.status == -4

@@ -71,3 +71,27 @@ def test_rows_given_equal_rows_searched_and_labels_partition_the_cloud():
     l2, n2 = oracle.region_growing_rgb(pts, rgb, neighbours=ki, neighbour_d2=kd, min_size=20)
     assert n1 == n2 and (l1 == l2).all()
     assert set(np.unique(l1)) <= set(range(-1, n1)) and all((l1 == c).sum() >= 20 for c in range(n1))
+
+
+def big_segment_scene():
+    """80 points of colour 250 (first in index order: segment 0) 0.4 from a tight blob of 72 001 points of colour 253.  The
+    channel sums of the blob are 18.2M > 2^24: a float accumulation rounds (mean 252), PCL's unsigned sums do not (253).
+    Against the small segment's 250 that is a colour difference of 3 * 2^2 = 12 < 25 (merge) or 3 * 3^2 = 27 (no merge)."""
+    rng = np.random.default_rng(4)
+    small = _blob(rng, (0.4, 0, 0), 80, 0.004)
+    big = _blob(rng, (0, 0, 0), 72001, 0.03)
+    pts = np.concatenate([small, big])
+    rgb = np.concatenate([np.full((80, 3), 250), np.full((72001, 3), 253)]).astype(np.uint8)
+    return pts, rgb
+
+
+def test_segment_colours_are_summed_exactly_like_pcls_unsigned_vectors():
+    pts, rgb = big_segment_scene()
+    acc = np.cumsum(np.full(72001, 253, np.float32), dtype=np.float32)[-1]
+    assert int(np.float32(acc) / np.float32(72001)) == 252, "the scene must be one a float sum gets wrong"
+    labels, ncl = oracle.region_growing_rgb(pts, rgb, min_size=50)
+    assert ncl == 2 and (labels[:80] == labels[0]).all() and (labels[80:] == labels[80]).all() and labels[0] != labels[80]
+    # one grey level closer the exact means differ by 3 * 2^2 = 12 < 25 and the two do merge
+    rgb[:80] = 251
+    labels, ncl = oracle.region_growing_rgb(pts, rgb, min_size=50)
+    assert ncl == 1 and (labels == 0).all()

@@ -72,3 +72,16 @@ def test_colour_segments_match_the_oracle(gpu, tmp_path, scene):
     assert nseg == (dflt_n if len(pts) > 10 else 0)
     if name == "room":
         assert 3 <= ncl <= 100           # painted patches of the surfaces, not one blob and not confetti
+
+
+def test_a_segment_beyond_two_to_the_24_in_its_colour_sums(gpu, tmp_path):
+    """pcc::RegionGrowingRGB sums a segment's colours in unsigned integers like PCL (a float sum rounds from ~66k bright
+    points on and flipped this scene's merge): tests/test_rgb_cpu.py::big_segment_scene through the shim, against the oracle"""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_rgb_cpu import big_segment_scene
+    pts, rgb = big_segment_scene()
+    ncl, labels, nseg = _tool(tmp_path, pts, rgb, 10, 6, 5, 50)
+    with capi.Index(pts) as ix:
+        ki, kd = ix.knn(pts, 100)
+    want, want_n = oracle.region_growing_rgb(pts, rgb, neighbours=ki, neighbour_d2=kd, min_size=50)
+    assert ncl == want_n == 2 and (labels == want).all()

@@ -226,6 +226,35 @@ def test_radius_search_with_max_nn_keeps_the_nearest(gpu, max_nn):
         assert (o1 == o2).all() and (i1 == i2).all() and (_bits(e1) == _bits(e2)).all()
 
 
+@pytest.mark.parametrize("nq,max_nn", [(1, 5), (300, 1), (1, 1), (2000, 3)])
+def test_radius_fill_max_with_offsets_computed_elsewhere_on_a_fresh_handle(gpu, nq, max_nn):
+    """pcc_radius_fill_max WITHOUT the count call before it (offsets from the oracle), on a handle that has never sorted a
+    query cloud: the k-NN rows must sit in buffers the query sort inside the search does not re-reserve (they were in the
+    sort's pair scratch -- freed by its growing reserve with nq = 1, max_nn = 1 or a fresh handle).  Also the count / fill
+    pair agrees on what "all" means: max_nn against the FINITE points, as PCL's total_nr_points_."""
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.normal(0, 0.1, (6000, 3)), rng.random((3000, 3)) - 0.5]).astype(np.float32)
+    q = (a[rng.integers(0, len(a), nq)] + np.float32(0.002)).astype(np.float32)
+    r = 0.08
+    tree = oracle.KdTree(a)
+    rows = [tree.radius(qq, r) for qq in q]
+    cnt = np.array([min(len(ri), max_nn) for ri, _ in rows], np.int64)
+    offs = np.zeros(nq + 1, np.int64)
+    np.cumsum(cnt, out=offs[1:])
+    with capi.Index(a) as ix:                                   # fresh handle: the fill is its first search
+        idx, d2 = ix.radius_fill(q, r, offs, sorted=True, max_nn=max_nn)
+    for j, (oi, od) in enumerate(rows):
+        assert (idx[offs[j]:offs[j + 1]] == oi[:max_nn]).all() and (_bits(d2[offs[j]:offs[j + 1]]) == _bits(od[:max_nn])).all()
+    # "all" is decided against the finite points: 40 points of which 10 are NaN, max_nn = 30 -> the plain radius rows
+    b = a[:40].copy()
+    b[::4] = np.nan
+    with capi.Index(b, engine=capi.ENGINE_GRID) as ix:
+        assert ix.stats()[2] == 30
+        o1, i1, e1 = ix.radius_search(b[1:9], 0.5, sorted=True, max_nn=30)
+        o2, i2, e2 = ix.radius_search(b[1:9], 0.5, sorted=True)
+        assert (o1 == o2).all() and (i1 == i2).all() and (_bits(e1) == _bits(e2)).all()
+
+
 def test_sor_threshold_nan_when_the_variance_rounds_below_zero(gpu):
     """tests/golden/sor_negative_variance.npz (a scene tools/fuzz_gpu.py drew: two tight clumps 7 km apart at coordinates of
     1e5, mean_k beyond a clump's size): every mean distance is ~2824 and (sq_sum - sum^2 / n) / (n - 1) rounds to a small
