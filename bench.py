@@ -9,17 +9,23 @@ when the timed region starts; outputs (idx int32, d2 float32) stay in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
 
 Workload (BASELINE.json configs):
-  default       C3, 10M x 10M XYZRGB (north_star's target size) at every N: each rank searches its own
-                10M queries against the replicated 10M references (weak scaling, so the driver's
-                1/2/4/8 values are one curve).  `extra` adds, at N = 1: C2 (1M x 1M, with the
-                exhaustive north-star kernel on the same data), the C3 radius-0.05 clustering leg
-                (-e path, 5M object points) and C4 (50 fixed ICP iterations, 2M x 2M); at N > 1:
-                C5 (32M queries sharded over the ranks vs 8M references, BASELINE configs[4]).
-  --config cX   only that configuration as the measured workload, no extras (profiling).
+  default       C3, 10M x 10M XYZRGB (north_star's target size).  N = 1: the whole configuration on one GPU.  N > 1: the SAME
+                10M queries sharded over the ranks against the replicated 10M references -- north_star's partition, STRONG
+                scaling: `value` = 10M / (slowest rank's step).  The index build (0.4 ms at 10M) is replicated on every rank,
+                so the whole step cannot scale linearly (Amdahl); `scaling_terms` carries step / query-only / build times so
+                the curve can be read both ways, `extra.c3_weak` is the weak form (every rank its own 10M queries).
+                `extra` adds, at N = 1: C2 (1M x 1M, with the exhaustive north-star kernel on the same data), the C3
+                radius-0.05 clustering leg (-e path, 5M object points), C4 (50 fixed ICP iterations, 2M x 2M), the C5 shard
+                and `scaling_projection` (one GPU doing a G-th of the queries, G = 1, 2, 4, 8: a PROJECTION of the
+                strong-scaling curve from one device, never a measurement of it); at every N: C5 (32M queries sharded over
+                the ranks vs 8M references, BASELINE configs[4]).
+  --config cX   only that configuration as the measured workload, no extras (profiling); c5_shard = what one of eight GPUs
+                does in C5 (4M queries vs 8M references).
 Multi GPU: one rank per GPU over RCCL.  `--gpus N` without a torch.distributed environment launches
   the N ranks itself (python -m torch.distributed.run ... as a CHILD process, before this process
   touches the GPU); under the driver's own launcher the ranks are used as they come.  The reference
-  cloud is broadcast once (outside the timed region), queries are sharded, no collective inside a step.
+  cloud is broadcast once (outside the timed region; 16 B per point -- the packed form, SURVEY.md 8e -- whatever the
+  workload's stride), queries are sharded, no collective inside a step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit..., "roofline"
 (dominant kernel of the measured path, HIP-event timed on the library's stream) and "cpu_baseline"
@@ -49,9 +55,12 @@ CONFIGS = {
     "c2": (1_000_000, 1_000_000, 3, "C2: 1M x 1M XYZ, k=1 NN"),
     "c3": (10_000_000, 10_000_000, 8, "C3: 10M x 10M XYZRGB (32-B stride), k=1 NN"),
     "c4": (2_000_000, 2_000_000, 3, "C4: 2M x 2M XYZ, -i ICP, 50 fixed iterations"),
-    "c5": (8_000_000, 4_000_000, 3, "C5: 32M queries in total, sharded over the ranks present (one 4M shard when run on a single GPU), vs 8M references"),
+    "c5": (8_000_000, 4_000_000, 3, "C5: 32M queries in total, sharded over the ranks present, vs 8M references"),
+    "c5_shard": (8_000_000, 4_000_000, 3, "C5 shard: what ONE of eight GPUs does in C5 -- 4M queries vs 8M references"),
 }
 C5_TOTAL_QUERIES = 32_000_000
+C3_TOTAL_QUERIES = 10_000_000
+PROJECTION_G = (1, 2, 4, 8)
 # sources whose kernels the committed PMC passes describe; a profile taken from other sources is flagged stale
 PROFILED_SOURCES = ["grid.hip", "grid_device.hpp", "cellsort.hip", "cellsort_mp.hip", "nn1_brute.hip", "pack.hip"]
 
@@ -97,11 +106,19 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def under_profiler() -> bool:
+    """rocprofv3 preloads its tool library into this process (and would into a child): no child process then -- on this pool
+    a program started from a GPU-initialised process is refused, and a profiled run does not need the pair count"""
+    if any(k.startswith(("ROCPROFILER", "ROCPROF_", "ROCP_")) for k in os.environ):
+        return True
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+
+
 def count_pairs(cfgs):
     """distances evaluated per call, counted by the PROFILING build of the library (libpcc_nn_prof.so, pcc_index_stats[4])
     in a child process -- the timed library carries no counter.  {} when the profiling build is missing or fails."""
     prof = ROOT / "pointcloudcomparator_amd" / "lib" / "libpcc_nn_prof.so"
-    if not prof.exists() or not cfgs:
+    if not prof.exists() or not cfgs or under_profiler():
         return {}
     env = dict(os.environ)
     env["PCC_LIB"] = str(prof)
@@ -147,17 +164,40 @@ def load_pmc_traffic(kernel_key, workload_key):
             d = json.loads(f.read_text())
         except Exception:
             continue
-        v = d.get(workload_key, {}).get(kernel_key)
+        v = d.get(workload_key, {}).get(kernel_key) if workload_key else None
         if v is not None:
             best = v
             stale = d.get("source_digest") != source_digest()
     return best, stale
 
 
+def compact(x):
+    """floats to six significant digits: the line stays within what a log tail keeps"""
+    if isinstance(x, float):
+        return float(f"{x:.6g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: compact(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [compact(v) for v in x]
+    return x
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+
+    # Pair counts of the workloads this run measures: the PROFILING build of the library in a CHILD process -- started here,
+    # before this process initialises the GPU or joins a process group (a child forked later would inherit a profiler's
+    # preload and keep the other ranks waiting in their first collective).  One-GPU runs only: the counts price the
+    # single-GPU rooflines; under rocprofv3 the child is skipped altogether.
+    primary_cfg = "c3" if args.config == "auto" else args.config
+    pairs = {}
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pairs:
+        want = [primary_cfg] if primary_cfg != "c1" else []
+        if args.config == "auto" and not args.no_extra:
+            want += ["c2", "c4", "c5_shard", "c5"]
+        pairs.update(count_pairs([c for c in dict.fromkeys(want) if c in ("c2", "c3", "c4", "c5", "c5_shard")]))
 
     import numpy as np
     import torch  # (import before the C-ABI so one HIP runtime is shared)
@@ -197,7 +237,7 @@ def main():
     bcast_name = "RCCL" if backend == "nccl" else backend
     engine = {"auto": capi.ENGINE_AUTO, "grid": capi.ENGINE_GRID, "brute": capi.ENGINE_BRUTE}[args.engine]
     K, W = args.steps, args.warmup
-    pairs = {}
+    from pointcloudcomparator_amd.sharding import shard_range
 
     def make_cloud(n, seed, floats, start=0, chunk=4_000_000):
         parts = [synth.corridor_cloud(min(chunk, n - o), seed, start=start + o) for o in range(0, n, chunk)]
@@ -229,28 +269,44 @@ def main():
         return max_over_ranks(time.perf_counter() - t0)
 
     def broadcast_refs(M, floats):
-        """the reference cloud: generated on rank 0, one broadcast to every rank (RCCL over xGMI)"""
+        """the reference cloud: generated on rank 0, ONE broadcast to every rank (RCCL over xGMI) of 16 B per point -- the
+        packed (x, y, z, pad) form SURVEY.md 8e and the library's own pcc_index_create_broadcast ship --, whatever the
+        workload's stride; each rank lays the points back into that stride (the colour words of XYZRGB are not on the
+        path), so the timed step reads the same 32-byte records on every rank"""
         ref_host = make_cloud(M, synth.SEED_A, floats) if rank == 0 else None
-        ref = torch.empty((M, floats), dtype=torch.float32, device=dev)
+        ref = torch.zeros((M, floats), dtype=torch.float32, device=dev)
         if rank == 0:
             ref.copy_(torch.from_numpy(ref_host))
-        ms = 0.0
+        ms, nbytes = 0.0, 0
         if dist is not None:
+            wire = ref if floats <= 4 else ref[:, :4].contiguous()
+            if floats > 4:
+                wire[:, 3] = 0.0
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            dist.broadcast(ref, src=0)
+            dist.broadcast(wire, src=0)
             torch.cuda.synchronize()
             ms = max_over_ranks((time.perf_counter() - t0) * 1e3)
-        return ref, ref_host, ms
+            nbytes = wire.numel() * 4
+            if floats > 4 and rank != 0:
+                ref[:, :3] = wire[:, :3]
+            del wire
+        return ref, ref_host, ms, nbytes
 
     # ---- k = 1 NN step of one configuration -----------------------------------------------------------------
-    def run_nn(cfg, n_per_rank=None, steps=K, warmup=W, with_exhaustive=False, with_cpu=False):
+    def run_nn(cfg, n_per_rank=None, total_queries=None, steps=K, warmup=W, with_exhaustive=False, with_cpu=False, project=False):
+        """total_queries: that many queries sharded over the ranks (strong scaling); else n_per_rank (or the config's size)
+        on every rank (weak).  project (one GPU only): the same step with a G-th of the queries, G in PROJECTION_G."""
         M, N, floats, desc = CONFIGS[cfg]
-        if n_per_rank is not None:
-            N = n_per_rank
-        ref, ref_host, bcast_ms = broadcast_refs(M, floats)
-        qry_host = make_cloud(N, synth.SEED_B, floats, start=rank * N)  # this rank's shard of cloud B
+        if total_queries is not None:
+            q_start, N = shard_range(total_queries, rank, n_gpus)
+            q_total = total_queries
+        else:
+            N = n_per_rank if n_per_rank is not None else N
+            q_start, q_total = rank * N, N * n_gpus
+        ref, ref_host, bcast_ms, bcast_bytes = broadcast_refs(M, floats)
+        qry_host = make_cloud(N, synth.SEED_B, floats, start=q_start)  # this rank's shard of cloud B
         qry = torch.from_numpy(qry_host).to(dev)
         idx = torch.empty(N, dtype=torch.int32, device=dev)
         d2 = torch.empty(N, dtype=torch.float32, device=dev)
@@ -287,17 +343,51 @@ def main():
             dist.all_reduce(t)
             per_rank_ms = [round(float(v), 4) for v in t.tolist()]
         r = {
-            "workload": f"{desc}; step = index build + {N} queries per GPU vs {M} references",
-            "value": N * n_gpus / (dt / steps), "unit": "queries/s", "ms_per_step": dt / steps * 1e3,
+            "workload": f"{desc}; step = index build over {M} references + {N} queries on each GPU "
+                        f"({q_total} over {n_gpus} GPU{'s' if n_gpus > 1 else ''})",
+            "value": q_total / (dt / steps), "unit": "queries/s", "ms_per_step": dt / steps * 1e3,
             "steps": steps, "engine": engine_name, "references": M, "queries_per_gpu": N,
-            "queries_total": N * n_gpus, "point_stride_bytes": floats * 4,
-            "query_only_queries_per_sec": N * n_gpus / (dtq / steps),
+            "queries_total": q_total, "point_stride_bytes": floats * 4,
+            "query_only_queries_per_sec": q_total / (dtq / steps),
             "build_ms": tm[3], "search_call_ms": tm[2], "query_sort_ms": tm[4], "main_kernel_ms": tm[0],
             "fallback_queries": stats[1] if engine_name == "grid" else 0,
-            "broadcast_ms": bcast_ms, "broadcast_bytes": M * floats * 4 if dist is not None else 0,
+            "broadcast_ms": bcast_ms, "broadcast_bytes": bcast_bytes,
+            # the terms of the scaling curve: the whole step (max over ranks), the query half alone (index kept: ICP's case) and
+            # the index build, which every rank repeats whatever its share of the queries -- the Amdahl term of query sharding
+            "scaling_terms": {"step_ms": dt / steps * 1e3, "query_only_ms": dtq / steps * 1e3, "build_ms": tm[3],
+                              "queries_per_gpu": N, "note": "build_ms is replicated on every rank; only query_only_ms shrinks with the shard"},
         }
         if per_rank_ms is not None:
             r["per_rank_ms_per_step"] = per_rank_ms
+        if project and n_gpus == 1:
+            # ONE GPU doing what each of G GPUs would do: the same index build + the first N / G queries.  With no collective
+            # inside a step the slowest rank's time IS the job's time, so step(1) / step(G) projects the strong-scaling
+            # speed-up -- a projection from one device (no xGMI, no launch jitter across ranks), never a measurement.
+            rows = []
+            for G in PROJECTION_G:
+                n = N // G
+                if G == 1:
+                    sm, qm = dt / steps * 1e3, dtq / steps * 1e3
+                else:
+                    qv, iv, dv = qry[:n], idx[:n], d2[:n]
+
+                    def step_g():
+                        ix.set_input(ref)
+                        ix.nn1(qv, iv, dv)
+
+                    for _ in range(2):
+                        step_g()
+                    kk = min(steps, 10)
+                    sm = timed(ix, step_g, kk) / kk * 1e3
+                    qm = timed(ix, lambda: ix.nn1(qv, iv, dv), kk) / kk * 1e3
+                rows.append({"gpus": G, "queries_per_gpu": n, "step_ms": sm, "query_only_ms": qm})
+            for row in rows:
+                row["projected_speedup_step"] = rows[0]["step_ms"] / row["step_ms"]
+                row["projected_speedup_query_only"] = rows[0]["query_only_ms"] / row["query_only_ms"]
+            r["projection"] = {"kind": "PROJECTION from one GPU (each row: this GPU doing one rank's share); not a multi-GPU measurement",
+                               "build_ms_replicated": tm[3], "rows": rows}
+            ix.set_input(ref)
+            ix.nn1(qry, idx, d2)  # (the full result again, for the checks below)
         # ---- roofline of the dominant kernel of the measured path -----------------------------------------
         if engine_name == "grid":
             # the pruned search (k_grid_nn1_flat2, plus k_nn1_open_flat for the lanes its cube leaves open from 2M queries on;
@@ -306,12 +396,18 @@ def main():
             # arithmetic among them is priced against the non-FMA fp32 roof from the profiling build's pair count
             alg = 12.0 * (M + N) + 8.0 * N
             ach = alg / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else 0.0
-            t_main, stale = load_pmc_traffic("k_grid_nn1_flat2", cfg)
-            t_open, _ = load_pmc_traffic("k_nn1_open_flat", cfg)
+            # (profiles and pair counts are keyed by WORKLOAD, not by config name: the 32M-query C5 and its 4M shard differ)
+            wl = cfg
+            if cfg in ("c5", "c5_shard"):
+                wl = "c5" if N == C5_TOTAL_QUERIES else ("c5_shard" if N == C5_TOTAL_QUERIES // 8 else None)
+            elif N != CONFIGS[cfg][1]:
+                wl = None
+            t_main, stale = load_pmc_traffic("k_grid_nn1_flat2", wl)
+            t_open, _ = load_pmc_traffic("k_nn1_open_flat", wl)
             if t_open is None:
-                t_open, _ = load_pmc_traffic("k_nn1_open", cfg)
+                t_open, _ = load_pmc_traffic("k_nn1_open", wl)
             traffic = None if t_main is None else t_main + (t_open or 0.0)
-            pk = pairs.get(cfg if n_per_rank is None or cfg != "c5" else ("c5" if N == C5_TOTAL_QUERIES else "c5_shard"))
+            pk = pairs.get(wl)
             hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg,
                    "bytes_per_unit": "12 B per reference + 12 B per query read, 8 B per query written (SURVEY.md 8d)"}
             r["roofline"] = {"kernel": "k_grid_nn1_flat2 (+ k_nn1_open_flat)", "kernel_ms": tm[0], "traffic": traffic, "traffic_stale": stale,
@@ -332,7 +428,7 @@ def main():
                                       "note": "pair count unavailable (libpcc_nn_prof.so missing): HBM figure only"})
         else:
             ach = float(M) * N * OPS_PER_PAIR / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else 0.0
-            traffic, stale = load_pmc_traffic("k_nn1_brute", cfg)
+            traffic, stale = load_pmc_traffic("k_nn1_brute", cfg if N == CONFIGS[cfg][1] else None)
             r["roofline"] = {"kernel": "k_nn1_brute", "bound": "valu", "achieved": ach, "peak": VALU_NOFMA_PEAK_TOPS,
                              "unit": "Top/s", "frac": ach / VALU_NOFMA_PEAK_TOPS, "traffic": traffic,
                              "traffic_stale": stale, "kernel_ms": tm[0]}
@@ -503,35 +599,32 @@ def main():
                 "split_ms_per_pass": {"nn_kernel": tm[0], "far_and_fallback": tm[1], "pass_total_events": tm[2],
                                       "sums_reduce_transform": max(tm[2] - tm[0] - tm[1], 0.0)}}
 
-    primary_cfg = "c3" if args.config == "auto" else args.config
-    # pair counts of the workloads this run measures (profiling build, child process, before any timing)
-    want = []
-    if rank == 0 and not args.no_pairs:
-        want = [primary_cfg if primary_cfg != "c5" or n_gpus == 1 else "c5_shard"] if primary_cfg != "c1" else []
-        if args.config == "auto" and not args.no_extra and n_gpus == 1:
-            want += ["c2", "c4", "c5_shard", "c5"]
-    pairs.update(count_pairs([c for c in dict.fromkeys(want) if c in ("c2", "c3", "c4", "c5", "c5_shard")]))
+    # ---- the measured workload ---------------------------------------------------------------------------------------
+    # C3 / C5: a FIXED total of queries sharded over the ranks present (north_star's partition: strong scaling, N = 1 is the
+    # whole configuration on one GPU); the other configurations keep their size on every rank (weak)
+    strong_total = {"c3": C3_TOTAL_QUERIES, "c5": C5_TOTAL_QUERIES}.get(primary_cfg)
     if primary_cfg == "c4":
         prim = None
         icp = run_icp()
         value, ms_per_step, workload = icp["nn_queries_per_sec"], icp["ms"], icp["workload"]
     else:
-        prim = run_nn(primary_cfg, n_per_rank=(C5_TOTAL_QUERIES // n_gpus if primary_cfg == "c5" else None),
-                      with_exhaustive=(not args.no_exhaustive and args.config != "auto"), with_cpu=not args.no_cpu)
+        prim = run_nn(primary_cfg, total_queries=strong_total,
+                      with_exhaustive=(not args.no_exhaustive and args.config != "auto"), with_cpu=not args.no_cpu,
+                      project=(args.config == "auto" and not args.no_extra))
         value, ms_per_step, workload = prim["value"], prim["ms_per_step"], prim["workload"]
 
     out = {
         "metric": "nn_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if primary_cfg == "c5" else "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong_total else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "name": primary_cfg, "backend": backend_name,
                    "parallelism": f"query-sharded x{n_gpus}, reference cloud replicated "
-                                  f"({bcast_name} broadcast, outside the timed region)"},
+                                  f"({bcast_name} broadcast of the packed cloud, outside the timed region)"},
     }
     if prim is not None:
         for k in ("engine", "references", "queries_per_gpu", "queries_total", "point_stride_bytes"):
             out["config"][k] = prim[k]
-        for k in ("query_only_queries_per_sec", "build_ms", "search_call_ms", "query_sort_ms", "fallback_queries",
+        for k in ("scaling_terms", "query_only_queries_per_sec", "build_ms", "search_call_ms", "query_sort_ms", "fallback_queries",
                   "broadcast_ms", "broadcast_bytes", "per_rank_ms_per_step", "roofline", "exhaustive", "cpu_baseline"):
             if k in prim:
                 out[k] = prim[k]
@@ -542,6 +635,14 @@ def main():
         extra = {}
         if n_gpus == 1:
             extra["c2"] = run_nn("c2", with_exhaustive=not args.no_exhaustive, with_cpu=False)
+            ex = extra["c2"].get("exhaustive")
+            if ex and "roofline" in out:
+                # the kernel north_star describes (tiled exhaustive k = 1), on C2's data, beside the pruned search's figures:
+                # top level, so that a truncated line still carries it
+                out["roofline"]["exhaustive"] = {"kernel": "k_nn1_brute", "workload": "C2 1M x 1M", "bound": "valu",
+                                                 "kernel_ms": ex["roofline"]["kernel_ms"], "achieved": ex["roofline"]["achieved"],
+                                                 "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s", "frac": ex["roofline"]["frac"],
+                                                 "pairs_per_sec": ex["pairs_per_sec"], "bit_identical_to_grid": ex["bit_identical_to_grid"]}
             extra["c3_clusters"] = run_clusters()
             extra["c4_icp"] = run_icp()
             extra["room"] = {"scan": run_room(synth.ROOM_SIZES[1]), "10M": run_room(synth.ROOM_SIZES[2], full=False)}
@@ -553,22 +654,31 @@ def main():
                     ops = json.loads(ops_files[-1].read_text())["operations"]
                     extra["ops_roofline"] = {"source": "profiles/" + ops_files[-1].name,
                                              "operations": [{"op": o["op"], "config": o["config"], "call_ms": round(o["call_ms"], 3),
-                                                             "achieved_GBps": round(o["achieved_GBps"], 1),
                                                              "frac_of_hbm": round(o["frac_of_hbm"], 4),
-                                                             "pairs_per_call": o.get("pairs_per_call"),
                                                              "frac_of_valu": round(o["frac_of_valu"], 4) if "frac_of_valu" in o else None}
                                                             for o in ops]}
                 except Exception:
                     pass
             # what ONE of eight GPUs does in BASELINE configs[4] (a 4M-query shard vs the 8M references)
-            shard = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // 8, steps=min(K, 10), warmup=2)
+            shard = run_nn("c5_shard", steps=min(K, 10), warmup=2)
             shard["scaling"] = "one shard of the 8-GPU configuration, measured on one GPU"
             extra["c5_shard"] = shard
+        else:
+            # the weak form beside the headline: every rank its own 10M queries against the replicated references
+            weak = run_nn("c3", steps=min(K, 10), warmup=2)
+            weak["scaling"] = "weak (10M queries per GPU)"
+            extra["c3_weak"] = weak
         # BASELINE configs[4]: 32M queries vs 8M references, sharded over the ranks present -- at EVERY N, one GPU
         # included (all 32M queries there), so that the strong-scaling curve has its N = 1 anchor
-        c5 = run_nn("c5", n_per_rank=C5_TOTAL_QUERIES // n_gpus, steps=min(K, 10), warmup=2)
+        c5 = run_nn("c5", total_queries=C5_TOTAL_QUERIES, steps=min(K, 10), warmup=2, project=True)
         c5["scaling"] = "strong (32M queries in total, whatever the rank count)"
         extra["c5"] = c5
+        if n_gpus == 1:
+            # what the one-GPU anchors say about 1 -> 8: the index build is replicated, so the whole step follows Amdahl while
+            # the query half alone comes close to linear.  A projection (labelled so in every entry), never a measurement.
+            extra["scaling_projection"] = {"c3": prim.get("projection") if prim else None, "c5": c5.pop("projection", None)}
+            if prim:
+                prim.pop("projection", None)
         out["extra"] = extra
 
     # the C-ABI's own RCCL path (pcc_comm_create_rank + pcc_index_create_broadcast: what a C++ host without torch uses),
@@ -605,7 +715,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(compact(out), separators=(",", ":")))
 
 
 if __name__ == "__main__":

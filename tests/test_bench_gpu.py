@@ -57,6 +57,19 @@ def test_single_rank_rccl_group_c5_sharding_arithmetic():
     assert out["config"]["references"] == 8_000_000
 
 
+def test_headline_leg_shards_the_ten_million_queries_and_ships_the_packed_cloud():
+    """the N > 1 headline is north_star's partition: C3's 10M queries SHARDED over the ranks present (strong scaling; with the
+    forced one-rank group the shard is all of them), the reference cloud broadcast at 16 B per point although the workload's
+    stride is 32, and the line carries the terms a scaling curve has to be read with"""
+    out = _run_rank(["--config", "c3", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-exhaustive", "--no-pairs"])
+    assert out["scaling"] == "strong" and out["config"]["name"] == "c3"
+    assert out["config"]["queries_total"] == 10_000_000 and out["config"]["queries_per_gpu"] == 10_000_000
+    assert out["config"]["point_stride_bytes"] == 32 and out["broadcast_bytes"] == 10_000_000 * 16
+    st = out["scaling_terms"]
+    assert 0 < st["build_ms"] < st["step_ms"] and 0 < st["query_only_ms"] < st["step_ms"]
+    assert out["fallback_queries"] == 0 and out["value"] > 1e9
+
+
 def test_more_ranks_than_gpus_is_refused_with_a_message():
     """`--gpus 8` on a box with fewer devices must fail at once and say why (no hang in the first collective)"""
     import torch
