@@ -137,8 +137,9 @@ enum pcc_option {
     PCC_OPT_FAR_MODE = 3,        /* queries the cell walk leaves: -1 auto, 0 exhaustive kernel, 1 seed scan + ball walk */
     PCC_OPT_ICP_WARM = 4,        /* pcc_icp_align: passes start from the previous pass's neighbours (default 1) */
     PCC_OPT_ICP_DEVICE_LOOP = 5, /* pcc_icp_align: loop resident on the device (default 1; 0 = host-driven, same bits) */
-    PCC_OPT_EC_CELLS = 6,        /* clustering over the clique-cell grid: 1 = lanes over a cell's neighbour cells (default),
-                                    2 = lanes over points; 0 = per-point ball scan on the search grid */
+    PCC_OPT_EC_CELLS = 6,        /* clustering over the clique-cell grid: 3 = union-find over the CELLS, face links first, the rest settled
+                                    against flat roots through the caches (default); 1 = one parent word per point, lanes over a cell's
+                                    neighbour cells; 2 = the same with lanes over points; 0 = per-point ball scan on the search grid */
     PCC_OPT_SORT_MP_MIN = 7,     /* reference clouds from this size take the three-level cell sort */
     PCC_OPT_SORT_MP_MIN_Q = 8,   /* the same for query clouds */
     PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query; 1 rows drained with lanes over candidates (default);

@@ -41,7 +41,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_FAR_MODE: return value >= -1 && value <= 1;
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: return value >= 0;
         case PCC_OPT_NN1_KERNEL: return value >= 0 && value <= 3;
-        case PCC_OPT_EC_CELLS: return value >= 0 && value <= 2;
+        case PCC_OPT_EC_CELLS: return value >= 0 && value <= 3;
         case PCC_OPT_KNN_CACHE_K: return value >= 0 && value <= 512;
         case PCC_OPT_NN1_DENSE_MIN: return value >= 1 && value <= 1000000;
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;

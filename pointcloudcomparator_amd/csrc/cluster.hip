@@ -174,6 +174,201 @@ k_uf_link_cells_wave(const float4* __restrict__ cr2, const unsigned int* __restr
     }
 }
 
+// ---- union-find over CELLS (round 5; PCC_OPT_EC_CELLS = 3, the default) ------------------------------------------
+// The kernels above keep one parent word per POINT and ask "linked already?" for each of the 84M (cell, forward neighbour)
+// pairs of a 5M-point scene through agent-scope loads -- the per-XCD L2s are not coherent, so every one of the ~170M reads
+// is a trip past them: 1.6 of the link kernel's 2.24 ms.  But a cell of the clustering grid IS a clique (diagonal < r), so the
+// graph whose components are wanted has the occupied cells as its nodes (1.3M instead of 5M, named by the sorted position of
+// their first point, which the bound load hands out for free -- no gather of the neighbour's first point), and the question
+// can be asked of a parent array that no union is touching:
+//   phase 1 (k_ecc_link_faces)  every occupied cell is tested against its +x / +y / +z neighbour and hooked to it when a pair
+//                               of points lies within r -- no "linked already?" at all, 3 pairs per cell.  Inside an object
+//                               these face links alone connect nearly everything.
+//   flatten (k_ecc_flatten)     a kernel boundary later nothing moves any more: parent[c] = root(c) with plain cached loads.
+//   phase 2 (k_ecc_link_rest)   the other 59 forward neighbours, lanes over neighbours as above: two cells are linked
+//                               already when their flat roots are EQUAL -- two plain loads through the caches, one of them
+//                               wave-uniform.  A stale root can only say "not linked" too often, never "linked" wrongly
+//                               (parents only move towards the root), so whatever phase 1 did not join is tested and hooked
+//                               here with the agent-scope union: every edge of the cell graph is either proven redundant or
+//                               offered, the components are those of the point graph.
+//   flatten + sizes, labels     points inherit their cell's root.
+// Roots are the lowest cell of a component in grid order; PCL's tie order among equal sizes (lowest member index first) comes
+// from a per-component minimum of the original indices.
+__global__ void __launch_bounds__(256)
+k_ecc_init(unsigned int* __restrict__ cparent, unsigned int* __restrict__ size, unsigned int* __restrict__ minidx,
+           int* __restrict__ id_of_root, unsigned int n, int32_t* __restrict__ labels, unsigned int n_labels) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(n, n_labels); i += gridDim.x * blockDim.x) {
+        if (i < n) { cparent[i] = i; size[i] = 0u; minidx[i] = 0xffffffffu; id_of_root[i] = -1; }
+        if (i < n_labels) labels[i] = -1;
+    }
+}
+
+// first pair of points of the cells [a0, a1) x [b0, b1) within r (squared: r2)?
+__device__ __forceinline__ bool ecc_cells_touch(const float4* __restrict__ cr2, unsigned int a0, unsigned int a1, unsigned int b0,
+                                                unsigned int b1, float r2) {
+    for (unsigned int pb = b0; pb < b1; ++pb) {
+        const float4 o = cr2[pb];
+        for (unsigned int pa = a0; pa < a1; ++pa) {
+            const float4 m = cr2[pa];
+            if (dist2(m.x, m.y, m.z, o) < r2) return true;
+        }
+    }
+    return false;
+}
+
+// phase 1: one lane per point, the heads of cells work: the three forward FACE neighbours, tested and hooked
+__global__ void __launch_bounds__(256)
+k_ecc_link_faces(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2, float r2,
+                 unsigned int* __restrict__ cparent) {
+    const GridParams g = gd2->g;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= gd2->n_valid) return;
+    const float4 me = cr2[t];
+    const int cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+    const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+    const unsigned int a0 = cs2[c];
+    if (t != a0) return;
+    const unsigned int a1 = cs2[c + 1];
+    // (+x: the next cell of the row, its bounds share the line; +y / +z: one row / one layer on)
+    const bool ok[3] = {cx + 1 < g.dim[0], cy + 1 < g.dim[1], cz + 1 < g.dim[2]};
+    const unsigned int cb[3] = {c + 1u, c + (unsigned int)g.dim[0], c + (unsigned int)g.dim[0] * (unsigned int)g.dim[1]};
+    unsigned int b0[3], b1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        b0[k] = b1[k] = 0u;
+        if (ok[k]) { b0[k] = cs2[cb[k]]; b1[k] = cs2[cb[k] + 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (b0[k] != b1[k] && ecc_cells_touch(cr2, a0, a1, b0[k], b1[k], r2)) uf_union(cparent, a0, b0[k]);
+}
+
+// parent[c] = root(c) for the heads of cells, when no union runs (plain loads: whatever a cache holds is an ancestor)
+__global__ void __launch_bounds__(256)
+k_ecc_flatten(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2,
+              unsigned int* __restrict__ cparent) {
+    const GridParams g = gd2->g;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= gd2->n_valid) return;
+    const float4 me = cr2[t];
+    if (t != cs2[cell_id(me, g)]) return;
+    const unsigned int r = uf_find_settled(cparent, t);
+    if (r != t) cparent[t] = r;
+}
+
+// phase 2: a wave takes the cells that start among its 64 points one at a time, lanes over the forward neighbours that are not
+// face neighbours; "linked already" = equal flat roots (plain loads)
+__global__ void __launch_bounds__(256)
+k_ecc_link_rest(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2, float r2,
+                unsigned int* __restrict__ cparent) {
+    const GridParams g = gd2->g;
+    const unsigned int n_valid = gd2->n_valid;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= n_valid) return;  // wave-uniform
+    const bool have = t < n_valid;
+    int cx = 0, cy = 0, cz = 0;
+    unsigned int a0 = 0, a1 = 0, ra = 0;
+    if (have) {
+        const float4 me = cr2[t];
+        cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+        const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+        a0 = cs2[c];
+        a1 = cs2[c + 1];
+        ra = cparent[a0];  // the cell's flat root as of phase 1 (plain load)
+    }
+    // this lane's forward neighbour in the 5 x 5 x 5 numbering (62 = the own cell; forward = beyond it); lanes 0, 4 and 24
+    // are +x, +y, +z: done in phase 1
+    const int lin = (int)lane + 63;
+    const int dz = lin / 25 - 2, dy = (lin / 5) % 5 - 2, dx = lin % 5 - 2;
+    const bool mine = lane < 62 && lane != 0 && lane != 4 && lane != 24;
+    unsigned long long heads = __ballot(have && t == a0);
+    while (heads) {
+        const int h = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const int hx = __builtin_amdgcn_readlane(cx, h), hy = __builtin_amdgcn_readlane(cy, h), hz = __builtin_amdgcn_readlane(cz, h);
+        const unsigned int ha0 = (unsigned int)__builtin_amdgcn_readlane((int)a0, h);
+        const unsigned int ha1 = (unsigned int)__builtin_amdgcn_readlane((int)a1, h);
+        const unsigned int hra = (unsigned int)__builtin_amdgcn_readlane((int)ra, h);
+        const int x = hx + dx, y = hy + dy, z = hz + dz;
+        if (!mine || x < 0 || x >= g.dim[0] || y < 0 || y >= g.dim[1] || z >= g.dim[2]) continue;
+        const unsigned int cb = ((unsigned int)z * g.dim[1] + y) * g.dim[0] + x;
+        const unsigned int b0 = cs2[cb], b1 = cs2[cb + 1];
+        if (b0 == b1) continue;
+        if (cparent[b0] == hra) continue;               // same component after phase 1: two cached words
+        if (uf_linked(cparent, ha0, b0)) continue;      // joined meanwhile (agent scope; the rare pairs that get here)
+        if (ecc_cells_touch(cr2, ha0, ha1, b0, b1, r2)) uf_union(cparent, ha0, b0);
+    }
+}
+
+// final flatten, component sizes and lowest member: one lane per point in grid order.  A wave's points belong to a handful of
+// components: per distinct root one atomicAdd of the count and one atomicMin of the lowest original index (a lane-wise
+// atomic per point onto a few hundred hot words is what cost the point-level form 2.1 ms)
+__global__ void __launch_bounds__(256)
+k_ecc_sizes(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2,
+            unsigned int* __restrict__ cparent, unsigned int* __restrict__ size, unsigned int* __restrict__ minidx) {
+    const GridParams g = gd2->g;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= gd2->n_valid) return;  // wave-uniform
+    const bool have = t < gd2->n_valid;
+    unsigned int r = 0xffffffffu, orig = 0xffffffffu;
+    if (have) {
+        const float4 me = cr2[t];
+        orig = (unsigned int)__float_as_int(me.w);
+        const unsigned int a0 = cs2[cell_id(me, g)];
+        r = uf_find_settled(cparent, a0);
+        if (t == a0 && r != a0) cparent[a0] = r;  // (the head writes the cell's flat root: k_ecc_label reads one word per point)
+    }
+    unsigned long long todo = __ballot(have);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        const unsigned int rr = (unsigned int)__builtin_amdgcn_readlane((int)r, l);
+        const unsigned long long same = __ballot(have && r == rr);
+        todo &= ~same;
+        unsigned int m = (have && r == rr) ? orig : 0xffffffffu;
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned int)__shfl_xor((int)m, off, 64));
+        if ((int)lane == l) {
+            atomicAdd(&size[rr], (unsigned int)__popcll(same));
+            atomicMin(&minidx[rr], m);
+        }
+    }
+}
+
+// roots whose size passes the filter: (root, size, lowest member)
+__global__ void __launch_bounds__(256)
+k_ecc_collect(const unsigned int* __restrict__ cparent, const unsigned int* __restrict__ size, const unsigned int* __restrict__ minidx,
+              unsigned int n, unsigned int min_size, unsigned int max_size, uint4* __restrict__ list, unsigned int* __restrict__ count,
+              unsigned int cap) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned int sz = size[i];  // > 0 only at the roots of components (heads of cells that are their own parent)
+        if (sz == 0 || cparent[i] != i) continue;
+        if (sz < min_size || sz > max_size) continue;
+        const unsigned int slot = atomicAdd(count, 1u);
+        if (slot < cap) list[slot] = make_uint4(i, sz, minidx[i], 0u);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_ecc_set_ids(const uint4* __restrict__ sorted_list, unsigned int ncl, int* __restrict__ id_of_root) {
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < ncl; k += gridDim.x * blockDim.x)
+        id_of_root[sorted_list[k].x] = (int)k;
+}
+__global__ void __launch_bounds__(256)
+k_ecc_label(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2,
+            const unsigned int* __restrict__ cparent, const int* __restrict__ id_of_root, int32_t* __restrict__ labels) {
+    const GridParams g = gd2->g;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= gd2->n_valid) return;
+    const float4 me = cr2[t];
+    const unsigned int a0 = cs2[cell_id(me, g)];
+    const int id = id_of_root[cparent[a0]];  // (flat since k_ecc_sizes)
+    if (id >= 0) labels[(unsigned int)__float_as_int(me.w)] = id;
+}
+
 __global__ void __launch_bounds__(256)
 k_uf_flatten_count(const float4* __restrict__ refs, unsigned int* __restrict__ parent, unsigned int n,
                    unsigned int* __restrict__ size) {
@@ -244,6 +439,65 @@ static inline int g1(size_t n) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// the union-find over cells (kernels k_ecc_*): the clustering grid is built (vox_a: points in its cell order, vox_c: CSR
+// starts, vox_b: its GridDev)
+static int grid_clusters_cells(pcc_index* ix, float r2, uint32_t min_size, uint32_t max_size, int32_t* labels_dev,
+                               int32_t* n_clusters, int32_t* sizes, int max_sizes) {
+    hipStream_t s = ix->stream;
+    const unsigned int n = (unsigned int)ix->n_orig;
+    const unsigned int cap = min_size > 0 ? n / min_size + 1 : n;
+    PCC_TRY(ix->scratch_c.reserve((size_t)n * 4));
+    PCC_TRY(ix->scratch_d.reserve((size_t)n * 4));
+    PCC_TRY(ix->scratch_e.reserve((size_t)n * 4));
+    PCC_TRY(ix->scratch_f.reserve((size_t)n * 4));
+    PCC_TRY(ix->scratch_b.reserve((size_t)cap * sizeof(uint4) + 16));
+    unsigned int* cparent = ix->scratch_c.as<unsigned int>();
+    unsigned int* size = ix->scratch_d.as<unsigned int>();
+    int* id_of_root = ix->scratch_e.as<int>();
+    unsigned int* minidx = ix->scratch_f.as<unsigned int>();
+    uint4* list = ix->scratch_b.as<uint4>();
+    unsigned int* d_count = ix->small.as<unsigned int>() + 40;
+    const float4* cr2 = ix->vox_a.as<float4>();
+    const unsigned int* cs2 = ix->vox_c.as<unsigned int>();
+    const GridDev* gd2 = ix->vox_b.as<GridDev>();
+    const dim3 gp((n + 255) / 256), blk(256);
+    ev_mark(ix, EV_MAIN0);
+    PCC_HIP(hipMemsetAsync(d_count, 0, 4, s));
+    hipLaunchKernelGGL(k_ecc_init, dim3(g1(n)), blk, 0, s, cparent, size, minidx, id_of_root, n, labels_dev, n);
+    hipLaunchKernelGGL(k_ecc_link_faces, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent);
+    hipLaunchKernelGGL(k_ecc_flatten, gp, blk, 0, s, cr2, cs2, gd2, cparent);
+    hipLaunchKernelGGL(k_ecc_link_rest, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent);
+    hipLaunchKernelGGL(k_ecc_sizes, gp, blk, 0, s, cr2, cs2, gd2, cparent, size, minidx);
+    hipLaunchKernelGGL(k_ecc_collect, dim3(g1(n)), blk, 0, s, cparent, size, minidx, n, min_size, max_size, list, d_count, cap);
+    PCC_HIP(hipGetLastError());
+    unsigned int* h = static_cast<unsigned int*>(ix->pinned);
+    PCC_HIP(hipMemcpyAsync(h, d_count, 4, hipMemcpyDeviceToHost, s));
+    PCC_HIP(hipStreamSynchronize(s));
+    const unsigned int ncl = h[0];
+    if (ncl > cap) { set_error("cluster list overflow (%u > %u)", ncl, cap); return PCC_ERR_OVERFLOW; }
+    std::vector<uint4> host_list(ncl);
+    if (ncl) {
+        PCC_HIP(hipMemcpyAsync(host_list.data(), list, (size_t)ncl * sizeof(uint4), hipMemcpyDeviceToHost, s));
+        PCC_HIP(hipStreamSynchronize(s));
+        // PCL: std::sort(clusters.rbegin(), clusters.rend(), by size) -> largest first; equal sizes are left unspecified there,
+        // here: lowest member index first (.z)
+        std::sort(host_list.begin(), host_list.end(), [](const uint4& a, const uint4& b) {
+            if (a.y != b.y) return a.y > b.y;
+            return a.z < b.z;
+        });
+        PCC_HIP(hipMemcpyAsync(list, host_list.data(), (size_t)ncl * sizeof(uint4), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_ecc_set_ids, dim3(g1(ncl)), blk, 0, s, list, ncl, id_of_root);
+        hipLaunchKernelGGL(k_ecc_label, gp, blk, 0, s, cr2, cs2, gd2, cparent, id_of_root, labels_dev);
+        PCC_HIP(hipGetLastError());
+    }
+    ev_mark(ix, EV_MAIN1);
+    PCC_HIP(hipStreamSynchronize(s));  // host_list must outlive the H2D copy
+    if (n_clusters) *n_clusters = (int32_t)ncl;
+    if (sizes)
+        for (unsigned int k = 0; k < ncl && (int)k < max_sizes; ++k) sizes[k] = (int32_t)host_list[k].y;
+    return PCC_OK;
+}
+
 int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t max_size,
                   int32_t* labels_dev, int32_t* n_clusters, int32_t* sizes, int max_sizes) {
     hipStream_t s = ix->stream;
@@ -279,6 +533,8 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
             cells_ok = true;
         }
     }
+    if (cells_ok && ix->opt.ec_cells == 3)
+        return grid_clusters_cells(ix, r2, min_size, max_size, labels_dev, n_clusters, sizes, max_sizes);
     // scratch: parent[n] | size[n] | id_of_root[n] | list[cap]
     const unsigned int cap = min_size > 0 ? n / min_size + 1 : n;
     PCC_TRY(ix->scratch_c.reserve((size_t)n * 4));

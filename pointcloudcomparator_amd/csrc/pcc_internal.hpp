@@ -93,7 +93,8 @@ struct Options {
     int far_mode = -1;              // PCC_OPT_FAR_MODE: -1 auto, 0 exhaustive fallback only, 1 always seed scan + ball walk
     int icp_warm = 1;               // PCC_OPT_ICP_WARM: ICP passes start from the previous pass's neighbours
     int icp_device_loop = 1;        // PCC_OPT_ICP_DEVICE_LOOP: 0 = the host-driven loop (same bits)
-    int ec_cells = 1;               // PCC_OPT_EC_CELLS: clustering on the clique-cell grid (0: per-point ball scan)
+    int ec_cells = 3;               // PCC_OPT_EC_CELLS: clustering on the clique-cell grid: 3 union-find over CELLS (round 5), 1 / 2 over points
+                                    // (lanes over neighbour cells / over points); 0: per-point ball scan on the search grid
     double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
     double sort_mp_min_q = 5e6;     // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds
     int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 rows drained flat, lanes over candidates (2 / 3: open lanes listed / in place)

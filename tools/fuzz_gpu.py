@@ -154,7 +154,7 @@ def main():
                 ix.set_option(capi.OPT_NN1_KERNEL, int(rng.integers(0, 4)))
                 ix.set_option(capi.OPT_NN1_OPEN_FLAT, int(rng.random() < 0.7))  # listed open lanes: drained flat / one lane each
                 ix.set_option(capi.OPT_KNN_KERNEL, int(rng.random() < 0.8))
-                ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([1, 1, 2, 0])))
+                ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([3, 3, 1, 2, 0])))
                 if rng.random() < 0.2:
                     ix.set_option(capi.OPT_NN1_DENSE_MIN, int(rng.choice([1, 2, 1000000])))
                 idx, d2 = ix.nn1(q)
