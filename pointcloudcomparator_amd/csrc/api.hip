@@ -286,7 +286,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c, &ix->rows_idx, &ix->rows_d2};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c, &ix->rows_idx, &ix->rows_d2, &ix->scan_flags};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)

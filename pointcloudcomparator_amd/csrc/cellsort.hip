@@ -208,7 +208,7 @@ int cell_sort(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, float4*
     hipLaunchKernelGGL(k_cs_hist, dim3(p.G), dim3(CS_T), p.B * sizeof(unsigned int), s, pts, n, gd, p.F, p.B, p.slice,
                        key_rank, H);
     PCC_HIP(hipGetLastError());
-    PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
+    PCC_TRY(launch_exclusive_scan(ix, s, H, h_elems, ix->scratch_a));
     if (n_sorted_dev) *n_sorted_dev = H + h_elems - 1;  // grand total == number of valid points
     const size_t lds3 = (((size_t)p.F + 4 + 3) & ~(size_t)3) * sizeof(unsigned int) + (out_pts ? (size_t)CS_FINE_STAGE * sizeof(float4) : 0);
     hipLaunchKernelGGL(k_cs_scatter, dim3(p.G), dim3(CS_T), 0, s, n, p.F, p.slice, key_rank, H, tmp_kv);

@@ -339,7 +339,7 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
     unsigned int* C = ix->mp_c.as<unsigned int>();
     hipLaunchKernelGGL(k_mp_hist1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, C, np);
     PCC_HIP(hipGetLastError());
-    PCC_TRY(launch_exclusive_scan(s, H, h_elems, ix->scratch_a));
+    PCC_TRY(launch_exclusive_scan(ix, s, H, h_elems, ix->scratch_a));
     unsigned int* n_valid = H + h_elems - 1;  // grand total == number of valid points
     if (n_sorted_dev) *n_sorted_dev = n_valid;
     // counters + scan words, then the staged output (points and / or order words)
@@ -355,7 +355,7 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
         else
             hipLaunchKernelGGL((k_mp_scatter1<float4>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         hipLaunchKernelGGL((k_mp_level2<false, float4>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
-        PCC_TRY(launch_exclusive_scan(s, C, np, ix->scratch_a));
+        PCC_TRY(launch_exclusive_scan(ix, s, C, np, ix->scratch_a));
         hipLaunchKernelGGL((k_mp_level2<true, float4>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
         if (refs)
             hipLaunchKernelGGL((k_mp_fine<true, float4>), dim3(np), dim3(MP_T), lds3, s, t2, C, gd, p.F2, out_pts, out_order, cell_start);
@@ -372,7 +372,7 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
         else
             hipLaunchKernelGGL((k_mp_scatter1<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         hipLaunchKernelGGL((k_mp_level2<false, uint2>), dim3(g2c), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
-        PCC_TRY(launch_exclusive_scan(s, C, np, ix->scratch_a));
+        PCC_TRY(launch_exclusive_scan(ix, s, C, np, ix->scratch_a));
         hipLaunchKernelGGL((k_mp_level2<true, uint2>), dim3(g2p), dim3(MP_T), 0, s, t1, n_valid, gd, p.F1, p.F2, C, t2);
         if (refs)
             hipLaunchKernelGGL((k_mp_fine<true, uint2>), dim3(np), dim3(MP_T), lds3, s, t2, C, gd, p.F2, out_pts, out_order, cell_start);

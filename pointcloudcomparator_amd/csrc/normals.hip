@@ -167,7 +167,7 @@ int normals_radius(pcc_index* ix, double radius, const float vp[3], float4* out)
     PCC_HIP(hipStreamSynchronize(s));
     const unsigned long long total = *h_total;
     if (total >= (1ull << 32)) { set_error("radius neighbourhoods hold %llu entries: more than a 32-bit CSR takes", total); return PCC_ERR_OVERFLOW; }
-    PCC_TRY(launch_exclusive_scan(s, off32, n + 1, ix->vox_b));
+    PCC_TRY(launch_exclusive_scan(ix, s, off32, n + 1, ix->vox_b));
     hipLaunchKernelGGL(k_widen_offsets, dim3(blocks), dim3(256), 0, s, off32, (unsigned int)(n + 1), off64);
     PCC_HIP(hipGetLastError());
     // sorted fill

@@ -223,6 +223,58 @@ k_scan_apply_fused(unsigned int* __restrict__ data, size_t n, const unsigned int
     }
 }
 
+// The scan in ONE launch (round 5): every workgroup scans its 2048 words, publishes its total in a word of its own tagged with
+// the launch's epoch, and adds up the totals of the workgroups in front of it as they appear -- the two-launch form above
+// costs a dependent launch (~5 us) per scan, and a 10M-point step runs four to six scans over 32k-131k counters.  The totals
+// travel as single 64-bit agent-scope atomics (epoch << 32 | total): no fence, no flag / value pair to order.  A workgroup
+// only ever waits for workgroups with LOWER ids, which the dispatcher starts first and which wait for nothing behind them, so
+// the chain cannot deadlock whatever else occupies the chip.  `flags` belongs to the handle and is used for nothing else
+// (a stale word never carries a future epoch).
+constexpr size_t SCAN_CHAIN_MAX = 512;
+__global__ void __launch_bounds__(SCAN_T)
+k_scan_chained(unsigned int* __restrict__ data, size_t n, unsigned long long* __restrict__ flags, unsigned int epoch) {
+    __shared__ unsigned int part[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
+    unsigned int v[SCAN_ITEMS];
+    const bool full = base + SCAN_ITEMS <= n;
+    if (full) {
+        const uint4* p = reinterpret_cast<const uint4*>(data + base);
+        uint4 a = p[0], b = p[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = (base + k < n) ? data[base + k] : 0u;
+    }
+    unsigned int sum = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) sum += v[k];
+    unsigned int tot;
+    unsigned int off = block_exclusive_scan(sum, &tot);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&flags[blockIdx.x], ((unsigned long long)epoch << 32) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int pre = 0;
+    for (unsigned int b = threadIdx.x; b < blockIdx.x; b += SCAN_T) {
+        unsigned long long w;
+        do {
+            w = __hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned int)(w >> 32) != epoch);
+        pre += (unsigned int)w;
+    }
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_down(pre, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    off += part[0] + part[1] + part[2] + part[3];
+    unsigned int o8[SCAN_ITEMS];
+    for (int k = 0; k < SCAN_ITEMS; ++k) { o8[k] = off; off += v[k]; }
+    if (full) {
+        uint4* p = reinterpret_cast<uint4*>(data + base);
+        p[0] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+        p[1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < n) data[base + k] = o8[k];
+    }
+}
+
 static int scan_rec(hipStream_t s, unsigned int* data, size_t n, unsigned int* tmp, size_t tmp_elems) {
     size_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (nb > 1 && nb <= SCAN_FUSED_MAX && tmp_elems >= nb) {
@@ -246,8 +298,23 @@ static int scan_rec(hipStream_t s, unsigned int* data, size_t n, unsigned int* t
     return PCC_OK;
 }
 
-int launch_exclusive_scan(hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp) {
+int launch_exclusive_scan(pcc_index* ix, hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp) {
     if (n == 0) return PCC_OK;
+    const size_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (ix && nb > 1 && nb <= SCAN_CHAIN_MAX) {
+        if (!ix->scan_flags.p) {  // (zeroed once: epochs start at 1)
+            PCC_TRY(ix->scan_flags.reserve(SCAN_CHAIN_MAX * sizeof(unsigned long long)));
+            PCC_HIP(hipMemsetAsync(ix->scan_flags.p, 0, SCAN_CHAIN_MAX * sizeof(unsigned long long), s));
+            ix->scan_epoch = 0;
+        }
+        if (++ix->scan_epoch == 0u) {  // (4G scans later: start over from clean words)
+            PCC_HIP(hipMemsetAsync(ix->scan_flags.p, 0, SCAN_CHAIN_MAX * sizeof(unsigned long long), s));
+            ix->scan_epoch = 1;
+        }
+        hipLaunchKernelGGL(k_scan_chained, dim3((unsigned)nb), dim3(SCAN_T), 0, s, data, n, ix->scan_flags.as<unsigned long long>(), ix->scan_epoch);
+        PCC_HIP(hipGetLastError());
+        return PCC_OK;
+    }
     size_t elems = 0;
     for (size_t k = (n + SCAN_BLOCK - 1) / SCAN_BLOCK; k > 1; k = (k + SCAN_BLOCK - 1) / SCAN_BLOCK)
         elems += ((k + 3) & ~(size_t)3);

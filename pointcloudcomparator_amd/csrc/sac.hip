@@ -155,7 +155,7 @@ int select_inliers(pcc_index* ix, const float4* pts, unsigned int n, const float
     const float4 model = make_float4(c[0], c[1], c[2], c[3]);
     hipLaunchKernelGGL(k_sac_flag, dim3(g1(n + 1)), dim3(256), 0, s, pts, n, model, threshold, pos);
     PCC_HIP(hipGetLastError());
-    PCC_TRY(launch_exclusive_scan(s, pos, (size_t)n + 1, ix->scratch_d));
+    PCC_TRY(launch_exclusive_scan(ix, s, pos, (size_t)n + 1, ix->scratch_d));
     hipLaunchKernelGGL(k_sac_scatter, dim3(g1(n)), dim3(256), 0, s, pts, n, model, threshold, pos, out_dev);
     PCC_HIP(hipGetLastError());
     unsigned int* h = static_cast<unsigned int*>(ix->pinned);

@@ -129,7 +129,7 @@ int voxel_grid(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
     int g1 = (int)std::min<size_t>((n + 256) / 256, 4096);
     hipLaunchKernelGGL(k_vox_heads, dim3(g1), dim3(256), 0, s, ix->vox_a.as<float4>(), order, n_sorted, d_gd, flags, (unsigned int)n);
     PCC_HIP(hipGetLastError());
-    PCC_TRY(launch_exclusive_scan(s, flags, n + 1, ix->vox_c));
+    PCC_TRY(launch_exclusive_scan(ix, s, flags, n + 1, ix->vox_c));
     unsigned int* h_cnt = static_cast<unsigned int*>(ix->pinned) + 48;
     PCC_HIP(hipMemcpyAsync(h_cnt, flags + n, 4, hipMemcpyDeviceToHost, s));
     // 5. centroids
