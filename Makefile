@@ -17,7 +17,7 @@ lib: $(LIBDIR)/libpcc_nn.so
 # the profiling build: same sources with the pair counter compiled in (pcc_index_stats[4]); never the timed library
 prof: $(LIBDIR)/libpcc_nn_prof.so
 PROF_OBJS  := $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(HIP_SRCS))
-build/prof/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
+build/prof/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/libm_f32.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
 	@mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) -DPCC_COUNT_PAIRS $(EXTRA_HIPFLAGS) -c $< -o $@
 $(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
@@ -25,10 +25,10 @@ $(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(PROF_OBJS) -ldl
 oracle: oracle/_build/libpcc_oracle.so
 ubench: build/ubench_valu build/ubench_gather
-hosttest: build/test_host_mirror build/test_lane_ops build/test_report
+hosttest: build/test_host_mirror build/test_lane_ops build/test_report build/test_libm
 cli: build/comparator build/ply_dump build/rgb_segments
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/libm_f32.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 
@@ -67,6 +67,10 @@ build/test_report: tests/cpp/test_report.cpp pointcloudcomparator_amd/host/repor
 build/rgb_segments: tests/cpp/rgb_segments.cpp include/pcc/region_growing_rgb.hpp include/pcc/search.hpp include/pcc/point_types.hpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc_nn.h $(LIBDIR)/libpcc_nn.so
 	@mkdir -p build
 	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Ipointcloudcomparator_amd/host $< -o $@ -L$(LIBDIR) -lpcc_nn -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+build/test_libm: tests/cpp/test_libm.cpp $(CSRC)/libm_f32.hpp
+	@mkdir -p build
+	$(CXX) -std=c++17 -O2 -ffp-contract=off -Wall -I$(CSRC) $< -o $@ -lm
 
 build/ply_dump: tests/cpp/ply_dump.cpp pointcloudcomparator_amd/host/ply_io.hpp include/pcc/point_types.hpp
 	@mkdir -p build

@@ -2,8 +2,9 @@
 // (optimizeModelCoefficients of the RANSAC refit): pcl::eigen33 = scale by the largest entry, closed-form
 // roots (pcl::computeRoots / computeRoots2), eigenvector of the smallest root from the largest cross product
 // of two rows of A - lambda I; curvature = |lambda_0 / trace|.  Unfused fp32 throughout (-ffp-contract=off).
-// The three transcendental calls: on the host the float libm versions PCL itself calls; on the device they
-// are evaluated in double and rounded once (= a correctly rounded float libm), see DESIGN.md 4.6.
+// The three transcendental calls (atan2f, cosf, sinf) are glibc's algorithms restated in libm_f32.hpp: the same bits on the
+// device as the host libm PCL itself calls (round 5; until then the device rounded double results once and 2.3 % of all
+// points differed from the host in their last bits), see DESIGN.md 4.6.
 #pragma once
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -17,6 +18,7 @@
 #endif
 #include <cfloat>
 #include <cmath>
+#include "libm_f32.hpp"
 
 namespace pcc {
 
@@ -44,13 +46,10 @@ __host__ __device__ inline void pf_roots3(const float m[9], float r[3]) {
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.f) q = 0.f;
     const float rho = sqrtf(-a_over_3);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
-    const float ct = (float)cos((double)theta), st = (float)sin((double)theta);
-#else
-    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-    const float ct = cosf(theta), st = sinf(theta);
-#endif
+    // (PCL calls std::atan2 / std::cos / std::sin on floats: the host libm's atan2f, cosf, sinf -- restated bit for bit in
+    // libm_f32.hpp, so that device and host take the same roots)
+    const float theta = lm_atan2f(sqrtf(-q), half_b) * s_inv3;
+    const float ct = lm_cosf(theta), st = lm_sinf(theta);
     r[0] = c2_over_3 + 2.f * rho * ct;
     r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
     r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);

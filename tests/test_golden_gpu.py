@@ -68,11 +68,10 @@ def test_golden_segmentation_rows(gpu):
         assert (_bits(coeff) == g["sac_coeff_bits"]).all()
         nrm = ix.normals(50)
         want = g["normals_bits"].view(np.float32)
-        same = (_bits(nrm) == g["normals_bits"]).all(axis=1)
-        assert same.mean() > 0.9                     # atan2f/cosf/sinf of libm vs the device's
-        dots = np.abs((nrm[:, :3].astype(np.float64) * want[:, :3]).sum(1))
-        assert (dots > 1 - 1e-6).all()
-        np.testing.assert_allclose(nrm[:, 3], want[:, 3], rtol=0, atol=3e-7)
+        # every bit: the device evaluates glibc's atan2f / cosf / sinf (csrc/libm_f32.hpp), the fixture holds
+        # what the oracle computed with the host's libm
+        same = (_bits(nrm) == g["normals_bits"]).all(axis=1) | (np.isnan(nrm).all(axis=1) & np.isnan(want).all(axis=1))
+        assert same.all(), int((~same).sum())
         labels, ncl = ix.region_growing(want, k=30, smoothness=3.0 / 180.0 * np.pi, curvature_threshold=1.0,
                                         min_size=50, max_size=1000000)
     assert ncl == int(g["rg_clusters"]) and (labels == g["rg_labels"]).all()

@@ -31,18 +31,14 @@ def _same_bits(a, b):
     return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
 
 
-def _assert_normals_close(got, want, min_same=0.9):
-    """Covariance, scaling, cross products and the flip are the same float operations on both sides; the
-    closed-form roots call atan2f/cosf/sinf, which the device evaluates in double and rounds once while the
-    host libm's float versions are only ~1 ulp accurate.  The smallest root is a difference of O(1) terms, so
-    one ulp there moves the curvature by <= 3e-7 absolute and the normal by <= 1e-6: that is the tolerance."""
+def _assert_normals_close(got, want, min_same=None):
+    """Covariance, scaling, cross products and the flip are the same float operations on both sides, and so -- since
+    round 5 -- are the three transcendental calls of the closed-form roots: csrc/libm_f32.hpp restates the host libm's
+    atan2f / cosf / sinf (glibc 2.35) operation for operation, tests/test_libm_cpu.py pins it.  Every normal and every
+    curvature carries the oracle's bits; rows that are NaN are NaN on both sides.  (Until round 5 the device rounded
+    double results once and 2.3 % of all points differed in their last bits.)"""
     same = _same_bits(got, want).all(axis=1)
-    assert same.mean() >= min_same, same.mean()
-    bad = ~same
-    if bad.any():
-        dots = np.abs((got[bad, :3].astype(np.float64) * want[bad, :3]).sum(1))
-        assert (dots > 1 - 1e-6).all(), dots.min()
-        np.testing.assert_allclose(got[bad, 3], want[bad, 3], rtol=0, atol=3e-7)
+    assert same.all(), (int((~same).sum()), len(same), np.nonzero(~same)[0][:5])
 
 
 @pytest.mark.parametrize("k", [3, 10, 50])
@@ -174,7 +170,7 @@ def test_normals_with_radius_search(radius):
     assert (np.isnan(got).all(1) == np.isnan(want).all(1)).all()
     ok = ~both_nan
     same = (got[ok].view(np.uint32) == want[ok].view(np.uint32)).all(axis=1)
-    assert same.mean() > 0.9
+    assert same.mean() > 0.99                  # (all but the rows where two neighbours tie in distance)
     dots = np.abs((got[ok, :3].astype(np.float64) * want[ok, :3]).sum(1))
     assert (dots > 1 - 1e-5).all()
     np.testing.assert_allclose(got[ok, 3], want[ok, 3], rtol=0, atol=1e-6)
