@@ -4,17 +4,17 @@
 # One rocprofv3 pass per kind: --kernel-trace --stats for durations, --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
 # passes (MI355X_MICROARCH.md: they do not fit one pass), never combined with other trace domains.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 S=$O/summary
 mkdir -p $S
-for c in c2 c3 c4 c5; do
+for c in c2 c3 c4 c5 c5_shard; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -- python3 bench.py --config $c --no-cpu --no-pairs > $S/${TAG}_${c}_trace_bench.json 2> $O/trace_$c.err
   cp $(find $O/trace_$c -name "*kernel_stats.csv" | head -1) $S/${TAG}_${c}_kernel_stats.csv
   echo "trace $c done"
 done
-for c in c2 c3 c4 c5; do
+for c in c2 c3 c4 c5 c5_shard; do
   for k in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $k --kernel-trace --output-format csv -d $O/pmc_${c}_$k -- python3 bench.py --config $c --steps 6 --warmup 2 --no-cpu --no-exhaustive --no-pairs > $O/pmc_${c}_$k.json 2> $O/pmc_${c}_$k.err
   done
