@@ -26,6 +26,7 @@
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
 #include "uf_device.hpp"
+#include "lane_ops.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -216,33 +217,52 @@ __device__ __forceinline__ bool ecc_cells_touch(const float4* __restrict__ cr2, 
     return false;
 }
 
-// phase 1: one lane per point, the heads of cells work: the three forward FACE neighbours, tested and hooked
+// phase 1: the three forward FACE neighbours of every occupied cell, tested and hooked.  One lane per point finds the heads of
+// cells (about one lane in four); the wave then deals its heads out THREE LANES EACH, one per face neighbour, 21 heads at a
+// time -- with one lane per head walking its three neighbours in turn a wave ran at a quarter of its lanes for three times as
+// long (0.59 ms at 5M points)
 __global__ void __launch_bounds__(256)
 k_ecc_link_faces(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2, float r2,
                  unsigned int* __restrict__ cparent) {
     const GridParams g = gd2->g;
+    const unsigned int n_valid = gd2->n_valid;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= gd2->n_valid) return;
-    const float4 me = cr2[t];
-    const int cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
-    const int cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
-    const int cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
-    const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
-    const unsigned int a0 = cs2[c];
-    if (t != a0) return;
-    const unsigned int a1 = cs2[c + 1];
-    // (+x: the next cell of the row, its bounds share the line; +y / +z: one row / one layer on)
-    const bool ok[3] = {cx + 1 < g.dim[0], cy + 1 < g.dim[1], cz + 1 < g.dim[2]};
-    const unsigned int cb[3] = {c + 1u, c + (unsigned int)g.dim[0], c + (unsigned int)g.dim[0] * (unsigned int)g.dim[1]};
-    unsigned int b0[3], b1[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        b0[k] = b1[k] = 0u;
-        if (ok[k]) { b0[k] = cs2[cb[k]]; b1[k] = cs2[cb[k] + 1]; }
+    const unsigned int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= n_valid) return;  // wave-uniform
+    __shared__ unsigned int head_lane[4][64];
+    unsigned int* hl = head_lane[threadIdx.x >> 6];
+    int cx = 0, cy = 0, cz = 0;
+    unsigned int c = 0, a0 = 0xffffffffu, a1 = 0;
+    if (t < n_valid) {
+        const float4 me = cr2[t];
+        cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+        c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+        a0 = cs2[c];
+        a1 = cs2[c + 1];
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (b0[k] != b1[k] && ecc_cells_touch(cr2, a0, a1, b0[k], b1[k], r2)) uf_union(cparent, a0, b0[k]);
+    const bool head = t == a0;
+    const unsigned long long heads = __ballot(head);
+    const unsigned int nheads = (unsigned int)__popcll(heads);
+    if (head) hl[__popcll(heads & ((1ull << lane) - 1ull))] = lane;
+    wave_lds_sync();
+    const unsigned int sub = lane / 3u, nb = lane - 3u * sub;  // lane 63 idles
+    for (unsigned int h0 = 0; h0 < nheads; h0 += 21u) {
+        const unsigned int hi = h0 + sub;
+        const bool mine = lane < 63u && hi < nheads;
+        const int src = (int)hl[mine ? hi : 0u];
+        const int hx = __shfl(cx, src, 64), hy = __shfl(cy, src, 64), hz = __shfl(cz, src, 64);
+        const unsigned int hc = (unsigned int)__shfl((int)c, src, 64);
+        const unsigned int ha0 = (unsigned int)__shfl((int)a0, src, 64), ha1 = (unsigned int)__shfl((int)a1, src, 64);
+        if (!mine) continue;
+        // (+x: the next cell of the row, its bounds share the line; +y / +z: one row / one layer on)
+        const bool ok = nb == 0 ? hx + 1 < g.dim[0] : (nb == 1 ? hy + 1 < g.dim[1] : hz + 1 < g.dim[2]);
+        if (!ok) continue;
+        const unsigned int cb = hc + (nb == 0 ? 1u : (nb == 1 ? (unsigned int)g.dim[0] : (unsigned int)g.dim[0] * (unsigned int)g.dim[1]));
+        const unsigned int b0 = cs2[cb], b1 = cs2[cb + 1];
+        if (b0 != b1 && ecc_cells_touch(cr2, ha0, ha1, b0, b1, r2)) uf_union(cparent, ha0, b0);
+    }
 }
 
 // parent[c] = root(c) for the heads of cells, when no union runs (plain loads: whatever a cache holds is an ancestor)
