@@ -691,7 +691,10 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
     const unsigned int ns = n_sorted_ptr ? *n_sorted_ptr : n;
     unsigned int qi = 0;
     float4 qv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-    if (t < ns) { qi = order ? order[t] : t; qv = q[(PCC_ABLATE & 64) ? t : qi]; }
+    if (t < ns) {
+        qi = order ? order[t] : t;
+        qv = q[(PCC_ABLATE & 64) ? t : qi];
+    }
     if (PCC_ABLATE & 32) qi = t;
     const bool active = __float_as_int(qv.w) >= 0;
     const float qx = qv.x, qy = qv.y, qz = qv.z;
@@ -784,7 +787,11 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
     if (OPENK) {
         // the lanes phase 1 leaves open go to a device-wide list, finished by k_nn1_open with every lane busy (in place,
         // a workgroup's dozen open lanes ran the ball walk at a fifth of the lanes: 45 % of the kernel's instructions)
-        if (active && resolved) out[qi] = best;
+        // (a NON-TEMPORAL store: the key is scattered through the sort order -- 64 sectors per wave, none of them written again
+        // by this kernel -- and a plain store leaves 10M partly written lines to age in the L2s beside the rows the search
+        // re-reads.  Round 5, same box, two runs each: 696 / 691 -> 668 / 671 us.  The scatter stays the most expensive single
+        // thing the kernel does: with the key stored at out[t] instead the kernels take 447 us, profiles/r05_nn1_ablation.txt)
+        if (active && resolved) __builtin_nontemporal_store(best, &out[qi]);
         const bool open = active && !resolved;
         const unsigned long long om = __ballot(open);
         if (om != 0ull) {

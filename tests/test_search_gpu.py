@@ -483,6 +483,20 @@ def test_voxel_grid_matches_pcl_restatement(gpu, leaf):
     assert (np.diff(key) > 0).mean() > 0.999  # a centroid may round onto a voxel face
 
 
+@pytest.mark.parametrize("n", [2047, 2048, 4096, 1_048_575, 1_048_576])
+def test_voxel_grid_sizes_around_the_scan_forms(gpu, n):
+    """pcc_voxel_grid scans n + 1 flags: 2048 words are one workgroup of the scan, up to 512 workgroups (1 048 576 words) take
+    the single-launch chained form (csrc/pack.hip k_scan_chained: tagged totals, a workgroup waits for the ones before it),
+    one word more the two-level form -- every form and every edge of them must give the oracle's voxels"""
+    pts = synth.corridor_cloud(n, synth.SEED_B)
+    with capi.Index(pts[:64]) as ctx:
+        out = ctx.voxel_grid(pts, 0.05)
+        again = ctx.voxel_grid(pts, 0.05)          # (a second scan on the handle: the next epoch over the same flag words)
+    ref, nv = oracle.voxel_grid(pts, 0.05)
+    assert len(out) == nv == len(again)
+    assert np.allclose(out[:, :3], ref[:, :3], rtol=0, atol=1e-4) and (out.view(np.uint32) == again.view(np.uint32)).all()
+
+
 def test_voxel_grid_refuses_absurd_leaf(gpu):
     pts = synth.corridor_cloud(5000, synth.SEED_A)
     with capi.Index(pts) as ctx:
