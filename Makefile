@@ -24,7 +24,7 @@ $(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(PROF_OBJS) -ldl
 oracle: oracle/_build/libpcc_oracle.so
-ubench: build/ubench_valu build/ubench_gather
+ubench: build/ubench_valu build/ubench_gather build/ubench_scatter
 hosttest: build/test_host_mirror build/test_lane_ops build/test_report build/test_libm
 cli: build/comparator build/ply_dump build/rgb_segments
 
@@ -41,6 +41,10 @@ oracle/_build/libpcc_oracle.so: oracle/pcc_oracle.c oracle/pcc_oracle.h
 	$(CC) -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread -o $@ oracle/pcc_oracle.c -lm
 
 build/ubench_gather: $(CSRC)/ubench_gather.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
+build/ubench_scatter: $(CSRC)/ubench_scatter.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
