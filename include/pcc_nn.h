@@ -125,7 +125,8 @@ int pcc_index_set_engine(pcc_index *index, int engine);
 
 int pcc_index_set_tie_order(pcc_index *index, int ties);
 
-/* Tuning knobs of one handle.  None of them changes a result bit (every mode is exact); they select between
+/* Tuning knobs of one handle.  None of them changes a result bit of a SEARCH (every mode is exact; PCC_OPT_ICP_SORTED is the
+ * one knob that shows in a result -- the order a double sum is added up in, see there); they select between
  * implementations that the tests compare with each other and that measurements are taken with.  The PCC_*
  * environment variables of the same names give the DEFAULTS a new handle starts with; the library does not read
  * the environment anywhere else.  Options that shape the index (GRID_PPC, GRID_TRIM, SORT_MP_MIN)
@@ -156,8 +157,13 @@ enum pcc_option {
                                     same cloud -- one search instead of two).  Costs n x K x 8 bytes of device memory */
     PCC_OPT_NN1_OPEN_FLAT = 14,  /* flat k = 1 kernel, listed open lanes: 1 = their rows drained with lanes over candidates (default),
                                     0 = one lane per listed query (round 3) */
-    PCC_OPT_SORT_STAGE1 = 15     /* three-level cell sort, level 1: 1 = reference points leave in bucket-sorted LDS tiles, whole runs
+    PCC_OPT_SORT_STAGE1 = 15,    /* three-level cell sort, level 1: 1 = reference points leave in bucket-sorted LDS tiles, whole runs
                                     stored (default); 0 = one store per point; 2 = tiles for the queries' 8-byte pairs too */
+    PCC_OPT_ICP_SORTED = 16      /* pcc_icp_align: 1 = the source cloud is brought into the target grid's cell order once and every pass
+                                    reads and writes it front to back (default); 0 = caller's order, gathered / scattered in every pass.
+                                    (The one option whose setting shows in a result: the 17 double sums of a pass are added up in the
+                                    working order, so T and fitness can differ between 0 and 1 in their last bits; every form of the
+                                    loop -- device, host, sharded -- agrees to the bit under either.) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -67,6 +67,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_KNN_CACHE_K: *as_int = &o.knn_cache_k; return nullptr;
         case PCC_OPT_NN1_OPEN_FLAT: *as_int = &o.nn1_open_flat; return nullptr;
         case PCC_OPT_SORT_STAGE1: *as_int = &o.sort_stage1; return nullptr;
+        case PCC_OPT_ICP_SORTED: *as_int = &o.icp_sorted; return nullptr;
         default: return nullptr;
     }
 }
@@ -79,7 +80,8 @@ void Options::from_env() {
         {"PCC_ICP_WARM", PCC_OPT_ICP_WARM}, {"PCC_ICP_DEVICE_LOOP", PCC_OPT_ICP_DEVICE_LOOP}, {"PCC_EC_CELLS", PCC_OPT_EC_CELLS},
         {"PCC_SORT_MP_MIN", PCC_OPT_SORT_MP_MIN}, {"PCC_SORT_MP_MIN_Q", PCC_OPT_SORT_MP_MIN_Q}, {"PCC_NN1_KERNEL", PCC_OPT_NN1_KERNEL},
         {"PCC_FLANN_SPLIT", PCC_OPT_FLANN_SPLIT}, {"PCC_NN1_DENSE_MIN", PCC_OPT_NN1_DENSE_MIN}, {"PCC_KNN_KERNEL", PCC_OPT_KNN_KERNEL},
-        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1}};
+        {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1},
+        {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;
@@ -1240,6 +1242,7 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
     bool conv = false;
     double prev_mse = 1.79769313486231570e308;
     double* center_dev = nullptr;
+    bool sorted = false;
     // Everything that can fail on ONE rank alone -- argument checks, staging, allocations -- comes before the first
     // collective and ends in a status the ranks agree on (hooks->agree: all-reduce MIN of one word), so a rank that
     // cannot go on takes the others out with it instead of leaving them in the broadcast below (comm.hip).
@@ -1255,6 +1258,21 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
         // the source stays resident: q_packed is the moving cloud, icp_src keeps the input
         PCC_TRY(stage_queries(ix, src, n, stride, mem));
         PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
+        // Round 5: the loop's working set in the target grid's CELL order.  Nothing of the loop leaves per point -- T, fitness,
+        // counts -- so the permutation that a search pays per call (queries gathered through the sort order, keys scattered
+        // back: ~60 us of a 215-us pass at 2M points, csrc/ubench_scatter.hip) is paid ONCE: the source is sorted by the
+        // cell it starts in, gathered into that order, and every pass reads it front to back with the identity as its order
+        // (a rigid motion keeps neighbouring points neighbours; any order is correct, as before).  The sums are added up in
+        // this order by every form of the loop -- device-resident, host-driven, sharded -- so they agree with each other to
+        // the bit as before; against the caller's order they differ in the last bits of a double sum.
+        sorted = ix->opt.icp_sorted != 0 && ix->engine == PCC_ENGINE_GRID && ix->has_grid && n >= 4096;
+        if (sorted) {
+            unsigned int *order = nullptr, *n_sorted = nullptr;
+            PCC_TRY(grid_sort_queries(ix, ix->q_packed.as<float4>(), n, &order, &n_sorted));
+            PCC_TRY(launch_gather_sorted(ix->stream, ix->q_packed.as<float4>(), order, n_sorted, n, ix->icp_src.as<float4>(),
+                                         ix->small.as<unsigned int>() + 48));
+            PCC_HIP(hipMemcpyAsync(ix->q_packed.p, ix->icp_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ix->stream));
+        } else
         PCC_HIP(hipMemcpyAsync(ix->icp_src.p, ix->q_packed.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ix->stream));
         // the sums of every pass are taken about a point of the source cloud (k_icp_center: no cancellation in the
         // covariance for clouds far from the origin); it sits behind the loop state in device memory
@@ -1277,6 +1295,12 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
         explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }
         ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; ix->warm_start = false; }
     } keep_order_guard(ix);
+    if (sorted) {  // (the passes take the identity as their order; the count of valid points sits in a word of its own)
+        ix->order_valid = true;
+        ix->order_nq = n;
+        ix->order_ptr = nullptr;
+        ix->order_nsorted = ix->small.as<unsigned int>() + 48;
+    }
     if (loop_env) {
         // The loop lives on the device: every pass is NN -> sums -> k_icp_solve (one workgroup: the transform, the running
         // product and the convergence criteria) -> transform with the matrix the solver left in device memory.  Passes

@@ -402,6 +402,25 @@ k_copy_w(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i].w = src[i].w;
 }
+// The ICP loop's working set in CELL order (round 5): dst[t] = q[order[t]] for the n_sorted valid points, the rest
+// flagged invalid; *ns_word = n_sorted (a word that outlives the sort's scratch).  One gather, once per pcc_icp_align: every
+// pass after it reads its queries front to back and stores its keys where it found them.
+__global__ void __launch_bounds__(256)
+k_gather_sorted(const float4* __restrict__ q, const unsigned int* __restrict__ order, const unsigned int* __restrict__ n_sorted,
+                size_t n, float4* __restrict__ dst, unsigned int* __restrict__ ns_word) {
+    const unsigned int ns = *n_sorted;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ns_word = ns;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)
+        dst[t] = t < ns ? q[order[t]] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+}
+int launch_gather_sorted(hipStream_t s, const float4* q, const unsigned int* order, const unsigned int* n_sorted, size_t n, float4* dst,
+                         unsigned int* ns_word) {
+    if (n == 0) return PCC_OK;
+    hipLaunchKernelGGL(k_gather_sorted, dim3(grid_for(n, 256)), dim3(256), 0, s, q, order, n_sorted, n, dst, ns_word);
+    PCC_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
 int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n) {
     if (n == 0) return PCC_OK;
     hipLaunchKernelGGL(k_copy_w, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n);

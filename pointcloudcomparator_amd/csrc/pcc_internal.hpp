@@ -91,6 +91,8 @@ struct Options {
                                     // prefer 0.25-0.5, those of the reference's sizes 1.0: DESIGN.md 5)
     int grid_trim = 3;              // PCC_OPT_GRID_TRIM: k of the trimmed bounding box (0: plain bounding box)
     int far_mode = -1;              // PCC_OPT_FAR_MODE: -1 auto, 0 exhaustive fallback only, 1 always seed scan + ball walk
+    int icp_sorted = 1;             // PCC_OPT_ICP_SORTED: pcc_icp_align keeps its source cloud in the target grid's cell order (one gather, then
+                                    // every pass reads queries and writes keys front to back); 0 = caller's order, gathered / scattered per pass
     int icp_warm = 1;               // PCC_OPT_ICP_WARM: ICP passes start from the previous pass's neighbours
     int icp_device_loop = 1;        // PCC_OPT_ICP_DEVICE_LOOP: 0 = the host-driven loop (same bits)
     int ec_cells = 3;               // PCC_OPT_EC_CELLS: clustering on the clique-cell grid: 3 union-find over CELLS (round 5), 1 / 2 over points
@@ -228,6 +230,8 @@ int launch_transform(hipStream_t s, const float* T16_dev_or_null, const float T[
 // packed points whose w flags them invalid get NaN coordinates again (in place): what a raw cloud looked like
 int launch_nanify(hipStream_t s, float4* pts, size_t n);
 // dst[i].w = src[i].w (validity flags of packed points)
+int launch_gather_sorted(hipStream_t s, const float4* q, const unsigned int* order, const unsigned int* n_sorted, size_t n, float4* dst,
+                         unsigned int* ns_word);
 int launch_copy_w(hipStream_t s, const float4* src, float4* dst, size_t n);
 // SOR: mean_dist[orig(i)] = float(sum_{j=1..K-1} sqrt(double(d2_j)) / (K-1)) from the K-NN keys of
 // the self query; rows with fewer than K neighbours keep 0

@@ -147,6 +147,12 @@ def test_c4_icp_50_iterations_2m_x_2m(gpu):
     with capi.Index(tt) as ix:
         T, fit, it, conv = ix.icp_align(ts, max_iter=50, fixed=True)
         assert it == 50 and conv
+        # (the loop as it was until round 5: the source in the caller's order, the sums added up in the order pcc_icp_step adds
+        # them -- the replay below reproduces THIS one to the last bit of the fitness too)
+        ix.set_option(capi.OPT_ICP_SORTED, 0)
+        T0, fit0, it0, conv0 = ix.icp_align(ts, max_iter=50, fixed=True)
+        ix.set_option(capi.OPT_ICP_SORTED, 1)
+        assert it0 == 50 and conv0
         cur = ts.clone()
         Tacc = np.eye(4, dtype=np.float32)
         mse = []
@@ -169,8 +175,11 @@ def test_c4_icp_50_iterations_2m_x_2m(gpu):
             Tacc = _mat4_mul_f32(Ti, Tacc)
         # getFitnessScore: the INPUT moved by the final matrix, one more NN pass, mean squared distance
         _, _, fs = ix.icp_step(ix.transform(T, ts), want_corr=False)
+    assert (T0.view(np.uint32) == Tacc.view(np.uint32)).all() and fit0 == fs[15] / fs[16]
+    # the default loop keeps its source in the target grid's cell order: the same correspondences, the 17 double sums added up in
+    # another order -- the transform comes out with the same float bits here, the fitness within the rounding of a 2M-term sum
     assert (T.view(np.uint32) == Tacc.view(np.uint32)).all()
-    assert fit == fs[15] / fs[16]
+    assert abs(fit - fs[15] / fs[16]) <= 1e-12 * fit
     assert mse[-1] < mse[0]  # (the floor is the sampling distance of two different samples of the scene, not zero)
     R = T[:3, :3].astype(np.float64)
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
