@@ -70,6 +70,24 @@ def test_headline_leg_shards_the_ten_million_queries_and_ships_the_packed_cloud(
     assert out["fallback_queries"] == 0 and out["value"] > 1e9
 
 
+def test_two_ranks_shard_the_headline_queries_between_them():
+    """`bench.py --gpus 2` as the driver starts it, on the one-GPU box: two ranks share device 0 (PCC_BENCH_SHARE_DEVICES, gloo --
+    RCCL refuses two ranks per device), launched by bench.py itself.  The headline leg must split C3's 10M queries 5M / 5M against
+    the broadcast references (strong scaling) and report both ranks' step times; the times themselves mean nothing here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"PCC_BENCH_SHARE_DEVICES": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--config", "c3", "--steps", "2", "--warmup", "1", "--no-cpu",
+                        "--no-exhaustive", "--no-pairs"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["backend"] == "gloo"
+    assert out["config"]["queries_total"] == 10_000_000 and out["config"]["queries_per_gpu"] == 5_000_000
+    assert out["broadcast_bytes"] == 10_000_000 * 16 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["scaling_terms"]["queries_per_gpu"] == 5_000_000 and out["fallback_queries"] == 0
+
+
 def test_more_ranks_than_gpus_is_refused_with_a_message():
     """`--gpus 8` on a box with fewer devices must fail at once and say why (no hang in the first collective)"""
     import torch
