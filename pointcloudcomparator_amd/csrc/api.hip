@@ -165,14 +165,15 @@ struct DeviceGuard {
 // host: one H2D copy of the raw AoS, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
                         DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr,
-                        unsigned int* zero_word = nullptr, float4* seeds = nullptr, unsigned long long* invalid_keys = nullptr) {
+                        unsigned int* zero_word = nullptr, float4* seeds = nullptr, unsigned long long* invalid_keys = nullptr,
+                        unsigned int* cells = nullptr, const GridDev* gd = nullptr) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys);
+    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd);
 }
 
 int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -190,8 +191,18 @@ int stage_queries(pcc_index* ix, const void* q, size_t nq, size_t stride, int me
     // the pack kernel also zeroes the GRID engine's fallback counter (small + 32) and presets the result key of
     // every non-finite query to "nothing found"
     ix->fb_zeroed = true;
+    // clouds that will take the three-level sort: the pack kernel also writes every query's grid cell (4 B), which level 1 of
+    // the sort then reads instead of the points (pcc_index::q_cells; valid until the sort has used it)
+    unsigned int* cells = nullptr;
+    ix->q_cells_n = 0;
+    if (ix->engine == PCC_ENGINE_GRID && ix->has_grid && nq >= (size_t)ix->opt.sort_mp_min_q) {
+        PCC_TRY(ix->q_cells.reserve(nq * sizeof(unsigned int) + 64));
+        cells = ix->q_cells.as<unsigned int>();
+        ix->q_cells_n = nq;
+    }
     return stage_points(ix, q, nq, stride, mem, ix->q_raw, ix->q_packed.as<float4>(), nullptr, nullptr,
-                        ix->small.as<unsigned int>() + 32, nullptr, ix->out_packed.as<unsigned long long>());
+                        ix->small.as<unsigned int>() + 32, nullptr, ix->out_packed.as<unsigned long long>(), cells,
+                        cells ? ix->d_grid.as<GridDev>() : nullptr);
 }
 
 // deliver device results to the caller's memory space
@@ -288,7 +299,7 @@ int pcc_index_destroy(pcc_index* ix) {
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf* bufs[] = {&ix->refs, &ix->cell_refs, &ix->cell_start, &ix->q_raw, &ix->q_packed, &ix->out_packed,
                       &ix->out_idx, &ix->out_d2, &ix->scratch_a, &ix->scratch_b, &ix->scratch_c, &ix->scratch_d, &ix->scratch_e, &ix->scratch_f, &ix->scratch_g,
-                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c, &ix->rows_idx, &ix->rows_d2, &ix->scan_flags};
+                      &ix->small, &ix->blk_stats, &ix->icp_src, &ix->icp_state, &ix->d_grid, &ix->seeds, &ix->vox_a, &ix->vox_b, &ix->vox_c, &ix->tie_buf, &ix->knn_fb, &ix->occ, &ix->self_rows, &ix->flann_nodes, &ix->flann_leaf, &ix->mp_a, &ix->mp_b, &ix->mp_c, &ix->rows_idx, &ix->rows_d2, &ix->scan_flags, &ix->q_cells};
     for (DevBuf* b : bufs) b->release();
     for (int sl = 0; sl < PCC_EV_SLOTS; ++sl)
         for (int k = 0; k < PCC_EV_KINDS; ++k)

@@ -111,6 +111,45 @@ k_mp_scatter1(const float4* __restrict__ pts, unsigned int n, const GridDev* __r
     }
 }
 
+// Level 1 of a QUERY cloud whose cells the pack kernel has written (pcc_index::q_cells): histogram and scatter read 4 bytes per
+// query -- its cell, ~0 for a non-finite one -- instead of the 16-byte point, whose cell they would work out again
+__global__ void __launch_bounds__(MP_T)
+k_mp_hist1_cells(const unsigned int* __restrict__ cells, unsigned int n, unsigned int F1, unsigned int B1, unsigned int slice,
+                 unsigned int* __restrict__ H, unsigned int* __restrict__ zero, unsigned int n_zero) {
+    for (unsigned int z = blockIdx.x * MP_T + threadIdx.x; z < n_zero; z += gridDim.x * MP_T) zero[z] = 0u;
+    __shared__ unsigned int cnt[MP_MAX_B1];
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) cnt[b] = 0;
+    __syncthreads();
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 8 * MP_T) {
+        unsigned int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = i0 + u * MP_T < end ? cells[i0 + u * MP_T] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c[u] != 0xffffffffu) atomicAdd(&cnt[c[u] / F1], 1u);
+    }
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) H[(size_t)b * gridDim.x + blockIdx.x] = cnt[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[(size_t)B1 * gridDim.x] = 0;  // slot of the grand total
+}
+__global__ void __launch_bounds__(MP_T)
+k_mp_scatter1_cells(const unsigned int* __restrict__ cells, unsigned int n, unsigned int F1, unsigned int B1, unsigned int slice,
+                    const unsigned int* __restrict__ H, uint2* __restrict__ out) {
+    __shared__ unsigned int cur[MP_MAX_B1];
+    for (unsigned int b = threadIdx.x; b < B1; b += MP_T) cur[b] = H[(size_t)b * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const unsigned int beg = blockIdx.x * slice, end = min(n, beg + slice);
+    for (unsigned int i0 = beg + threadIdx.x; i0 < end; i0 += 8 * MP_T) {
+        unsigned int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = i0 + u * MP_T < end ? cells[i0 + u * MP_T] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c[u] != 0xffffffffu) out[atomicAdd(&cur[c[u] / F1], 1u)] = make_uint2(c[u], i0 + u * MP_T);
+    }
+}
+
 // The same scatter with the slice taken in TILES that are sorted by bucket in LDS first: a wave's store then covers a few
 // whole 128-byte runs instead of 64 pieces of 16 (or 8) bytes going to 64 different buckets -- the pass moved exactly its
 // algorithmic bytes already (PMC) but at 49 % of the HBM roof: it is the L2's write transactions that it was short of.
@@ -337,6 +376,14 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
     // per (b1, b2) bucket: counts -> (scan) first position -> (placement advances it) one past its last point,
     // which is also where the next bucket starts: level 3 reads its range from there
     unsigned int* C = ix->mp_c.as<unsigned int>();
+    // (the queries' cells as the pack kernel left them: this cloud, this grid, nothing has moved since -- used once)
+    const unsigned int* cells = nullptr;
+    if (!refs && !out_pts && !gd_override && pts == ix->q_packed.as<float4>() && ix->q_cells_n == n_pts && n_pts != 0)
+        cells = ix->q_cells.as<unsigned int>();
+    if (!refs) ix->q_cells_n = 0;
+    if (cells)
+        hipLaunchKernelGGL(k_mp_hist1_cells, dim3(p.G1), dim3(MP_T), 0, s, cells, n, p.F1, p.B1, p.slice1, H, C, np);
+    else
     hipLaunchKernelGGL(k_mp_hist1, dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, C, np);
     PCC_HIP(hipGetLastError());
     PCC_TRY(launch_exclusive_scan(ix, s, H, h_elems, ix->scratch_a));
@@ -367,7 +414,9 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
         const unsigned int g2p = (n + MP_STAGE_BYTES / sizeof(uint2) - 1) / (MP_STAGE_BYTES / sizeof(uint2));
         // (the 8-byte pairs lose with the staged form: 10M queries 0.218 vs 0.209 ms for the whole sort -- their pieces are half
         // as long and the tile's LDS round trip costs what the stores save; option value 2 forces it for measurements)
-        if (ix->opt.sort_stage1 == 2)
+        if (cells)
+            hipLaunchKernelGGL(k_mp_scatter1_cells, dim3(p.G1), dim3(MP_T), 0, s, cells, n, p.F1, p.B1, p.slice1, H, t1);
+        else if (ix->opt.sort_stage1 == 2)
             hipLaunchKernelGGL((k_mp_scatter1_staged<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);
         else
             hipLaunchKernelGGL((k_mp_scatter1<uint2>), dim3(p.G1), dim3(MP_T), 0, s, pts, n, gd, p.F1, p.B1, p.slice1, H, t1);

@@ -6,6 +6,7 @@
 
 #include "pcc_internal.hpp"
 #include "lane_ops.hpp"
+#include "grid_device.hpp"
 
 namespace pcc {
 
@@ -28,11 +29,14 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 // by workgroup b, blk[b*8 + 1..3] = min xyz, blk[b*8 + 4..6] = max xyz of its valid points
 // (floats; +inf/-inf when it saw none).  The host reduces the <= PACK_MAX_BLOCKS rows it
 // reads back.  (Atomics on six shared words serialise: 0.56 ms for 1M points, measured.)
+// cells (query clouds, when the index holds a grid): the grid cell of every point, ~0 for a non-finite one, written beside the
+// packed point -- the first level of the three-level sort then reads 4 bytes per query instead of the 16-byte point twice
+// (histogram and scatter: 320 MB of 10M queries' 560)
 template <bool VEC16, bool STATS>
 __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
        float* __restrict__ blk, unsigned int* __restrict__ zero_word, float4* __restrict__ seeds,
-       unsigned long long* __restrict__ invalid_keys) {
+       unsigned long long* __restrict__ invalid_keys, unsigned int* __restrict__ cells, const GridDev* __restrict__ gd) {
     if (zero_word && blockIdx.x == 0 && threadIdx.x < 64) {  // counters of the search that follows: saves a 5 us memset node
         if (threadIdx.x < 2) zero_word[threadIdx.x] = 0u;                      // fallback list, far list
         zero_word[PCC_OPEN_CTR0 - 32 + threadIdx.x * PCC_OPEN_CTR_STRIDE] = 0u;  // the sharded open-lane counters (grid.hip)
@@ -40,6 +44,8 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
     unsigned int bad = 0;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    GridParams g;
+    if (!STATS && cells) g = gd->g;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         float x, y, z;
@@ -66,6 +72,7 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
             if (invalid_keys) invalid_keys[i] = ~0ull;
         }
         out[i] = o;
+        if (!STATS && cells) cells[i] = __float_as_int(o.w) >= 0 ? cell_id(o, g) : 0xffffffffu;
         if (STATS && seeds && (i & (PCC_SEED_STRIDE - 1)) == 0) seeds[i >> PCC_SEED_SHIFT] = o;  // upper bounds for far queries
     }
     if (STATS) {
@@ -101,7 +108,8 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
 }
 
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                float* blk_stats, int* n_blocks, unsigned int* zero_word, float4* seeds, unsigned long long* invalid_keys) {
+                float* blk_stats, int* n_blocks, unsigned int* zero_word, float4* seeds, unsigned long long* invalid_keys,
+                unsigned int* cells, const GridDev* gd) {
     if (n_blocks) *n_blocks = 0;
     if (n == 0) return PCC_OK;
     bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
@@ -110,10 +118,10 @@ int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4*
     if (n_blocks) *n_blocks = g;
     const char* a = (const char*)aos;
     bool st = blk_stats != nullptr;
-    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
-    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
-    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
-    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys);
+    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
+    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
+    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
+    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -154,6 +154,7 @@ struct pcc_index {
     pcc::DevBuf q_raw, q_packed, out_packed, out_idx, out_d2, scratch_a, scratch_b,
         scratch_c, scratch_d, scratch_e, scratch_f, scratch_g, small, blk_stats, icp_src, icp_state, vox_a, vox_b, vox_c,
         mp_a, mp_b, mp_c,  // cellsort_mp.hip: two intermediate point buffers, bucket counters
+        q_cells,     // grid cell of every staged query (k_pack), read by level 1 of the three-level sort instead of the points
         scan_flags,  // k_scan_chained: one tagged total per workgroup (pack.hip); nothing else ever writes here
         rows_idx, rows_d2;  // pcc_radius_fill_max: the k-NN rows it cuts at the radius (no scratch the query sort touches)
     // PCC_TIES_FLANN (flann_tree.hpp): kd-tree of FLANN's shape, built on the host at the first search after every
@@ -168,6 +169,7 @@ struct pcc_index {
     pcc::DevBuf tie_buf, flann_nodes, flann_leaf;
     pcc::DevBuf knn_fb;  // a list of up to n indices + its count, one user at a time: queries the k-NN selection kernel hands back,
                          // rows a fused radius fill leaves to k_sort_rows, region growing's points with a cross edge
+    size_t q_cells_n = 0;                         // q_cells describes q_packed[0 .. q_cells_n) as staged (0: stale -- consumed, or q_packed has moved since)
     unsigned int scan_epoch = 0;                  // tag of the last chained scan on this handle
     bool sor_exact_last = true;                   // the last pcc_sor took its sums on the device (no addition of PCL's order rounds)
     bool open_pending = false;                    // the open-lane counters of the last listed k = 1 search are still on the device
@@ -215,8 +217,8 @@ inline void ev_next(pcc_index* ix) {
 // [0] bits(invalid count), [1..3] min xyz, [4..6] max xyz of its valid points; *n_blocks rows.
 constexpr int PACK_MAX_BLOCKS = 1024;
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
-                float* blk_stats, int* n_blocks, unsigned int* zero_word = nullptr, float4* seeds = nullptr,
-                unsigned long long* invalid_keys = nullptr);
+                float* blk_stats = nullptr, int* n_blocks = nullptr, unsigned int* zero_word = nullptr, float4* seeds = nullptr,
+                unsigned long long* invalid_keys = nullptr, unsigned int* cells = nullptr, const GridDev* gd = nullptr);
 // exclusive scan of uint32 data[n] in place; data[n] receives the total when
 // write_total.  tmp is grown as needed.
 int launch_exclusive_scan(pcc_index* ix, hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
