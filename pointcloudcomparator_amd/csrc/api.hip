@@ -268,6 +268,7 @@ int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) 
     ix->order_valid = false;
     ix->flann_valid = false;
     ix->occ_valid = false;
+    ix->q_cells_n = 0;  // (cells staged against the grid that is about to be replaced)
     ix->self_rows_k = 0;
     ix->n_orig = n;  // the build steps size their launches from it
     const int st = set_input_impl(ix, pts, n, stride, mem);
