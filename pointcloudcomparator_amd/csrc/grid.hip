@@ -223,6 +223,7 @@ int grid_build(pcc_index* ix) {
     PCC_TRY(cell_sort(ix, ix->refs.as<float4>(), n, true, ix->cell_refs.as<float4>(), nullptr,
                       ix->cell_start.as<unsigned int>(), nullptr));
     ix->has_grid = true;  // (the seed subset for far queries was written by the pack kernel)
+    ix->q_cells_n = 0;    // (query cells staged against an earlier grid are void)
     return PCC_OK;
 }
 
