@@ -1,6 +1,7 @@
 """CPU-side host logic: the report writer of the CLI (tests/cpp/test_report.cpp, no device call) and bench.py's own
 rank launcher (the command it would start, and that it starts it before anything touches the GPU)."""
 import subprocess
+import os
 import sys
 from pathlib import Path
 
@@ -60,6 +61,30 @@ def test_bench_configs_match_baseline_json():
     assert bench.CONFIGS["c4"][:2] == (2_000_000, 2_000_000)
     assert bench.CONFIGS["c5"][0] == 8_000_000 and bench.C5_TOTAL_QUERIES == 32_000_000
     assert bench.C5_TOTAL_QUERIES // 8 == bench.CONFIGS["c5"][1]       # 8 shards of 4M
+
+
+def test_bench_line_helpers(monkeypatch):
+    """what bench.py does to its own line and around the pair-counting child process, without a GPU: floats rounded to six
+    digits (NaN / inf -> null: the line must stay valid JSON), the headline totals, the profiler guard"""
+    import json
+    import math
+    sys.path.insert(0, str(ROOT))
+    import bench
+    out = bench.compact({"a": 1.23456789, "b": [float("nan"), float("inf"), 3, "x", {"c": 1e-12 / 3}], "n": 10_000_000, "t": True})
+    assert out == {"a": 1.23457, "b": [None, None, 3, "x", {"c": 3.33333e-13}], "n": 10_000_000, "t": True}
+    assert json.loads(json.dumps(out)) == out and not any(isinstance(v, float) and math.isnan(v) for v in out["b"][:2] if v is not None)
+    assert bench.C3_TOTAL_QUERIES == bench.CONFIGS["c3"][1] == 10_000_000 and bench.CONFIGS["c5_shard"][:2] == (8_000_000, 4_000_000)
+    assert bench.PROJECTION_G == (1, 2, 4, 8)
+    for k in list(os.environ):
+        if k.startswith(("ROCPROFILER", "ROCPROF_", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    assert not bench.under_profiler()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler() and bench.count_pairs(["c2"]) == {}     # no child process under a profiler's preload
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+    assert bench.under_profiler()
 
 
 def _flann_tree_answers(tmp_path, pts, qs, rule, threads):
