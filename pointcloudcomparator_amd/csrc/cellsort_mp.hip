@@ -29,7 +29,16 @@ constexpr unsigned int MP_MAX_G = 512;    // level-1 workgroups
 constexpr unsigned int MP_SLICE2 = 8192;  // points per level-2 workgroup (counting form)
 constexpr unsigned int MP_STAGE_BYTES = 32768;  // LDS the placing form stages its slice in (2048 points or 4096 pairs)
 constexpr unsigned int MP_WIN = 8;        // level-1 buckets a level-2 slice keeps LDS counters for
-constexpr unsigned int MP_FINE_STAGE = 1536;  // points a level-3 bucket places in LDS before writing them out in whole lines
+// elements a level-3 bucket places in LDS before writing them out in whole lines: 16-byte points (reference clouds) / 4-byte order
+// words (query clouds).  Round 5, same box: points 768 / 1536 / 3072 / 6144 -> build 450 / 418 / 413 / 473 us at 10M; order words
+// see DESIGN.md 4.3
+#ifndef PCC_MP_STAGE_PTS
+#define PCC_MP_STAGE_PTS 3072
+#endif
+#ifndef PCC_MP_STAGE_ORD
+#define PCC_MP_STAGE_ORD 6144
+#endif
+constexpr unsigned int MP_FINE_STAGE_PTS = PCC_MP_STAGE_PTS, MP_FINE_STAGE_ORD = PCC_MP_STAGE_ORD;
 
 struct MpPlan {
     unsigned int F1, F2, B1, G1, slice1;
@@ -323,11 +332,12 @@ k_mp_fine(const E* __restrict__ in, const unsigned int* __restrict__ ends /* cur
         run += c;
     }
     __syncthreads();
-    // A bucket of up to MP_FINE_STAGE points (the usual case) is placed in LDS and leaves in whole lines; bigger ones
+    // A bucket of up to stage_cap elements (the usual case) is placed in LDS and leaves in whole lines; bigger ones
     // scatter their 16-byte (or 4-byte) pieces straight to memory.
-    const bool staged = end - beg <= MP_FINE_STAGE;
+    const unsigned int stage_cap = out_pts ? MP_FINE_STAGE_PTS : MP_FINE_STAGE_ORD;
+    const bool staged = end - beg <= stage_cap;
     float4* st_pts = reinterpret_cast<float4*>(lds + ((F2 + 4 + 3) & ~3u));
-    unsigned int* st_ord = reinterpret_cast<unsigned int*>(st_pts + (out_pts ? MP_FINE_STAGE : 0));
+    unsigned int* st_ord = reinterpret_cast<unsigned int*>(st_pts + (out_pts ? MP_FINE_STAGE_PTS : 0));
     for (unsigned int j0 = beg + threadIdx.x; j0 < end; j0 += 4 * MP_T) {
         E v[4];
 #pragma unroll
@@ -391,7 +401,8 @@ int cell_sort_mp(pcc_index* ix, const float4* pts, size_t n_pts, bool refs, floa
     if (n_sorted_dev) *n_sorted_dev = n_valid;
     // counters + scan words, then the staged output (points and / or order words)
     const size_t lds3 = (((size_t)p.F2 + 4 + 3) & ~(size_t)3) * sizeof(unsigned int) +
-                        (size_t)MP_FINE_STAGE * ((out_pts ? sizeof(float4) : 0) + (out_order ? sizeof(unsigned int) : 0));
+                        (out_pts ? (size_t)MP_FINE_STAGE_PTS * (sizeof(float4) + (out_order ? sizeof(unsigned int) : 0))
+                                 : (size_t)MP_FINE_STAGE_ORD * sizeof(unsigned int));
     const unsigned int g2c = (n + MP_SLICE2 - 1) / MP_SLICE2;
     if (out_pts) {  // the points travel (reference clouds)
         float4* t1 = ix->mp_a.as<float4>();
