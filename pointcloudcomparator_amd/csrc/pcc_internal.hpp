@@ -97,7 +97,8 @@ struct Options {
     int icp_device_loop = 1;        // PCC_OPT_ICP_DEVICE_LOOP: 0 = the host-driven loop (same bits)
     int ec_cells = 3;               // PCC_OPT_EC_CELLS: clustering on the clique-cell grid: 3 union-find over CELLS (round 5), 1 / 2 over points
                                     // (lanes over neighbour cells / over points); 0: per-point ball scan on the search grid
-    double sort_mp_min = 1.5e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used
+    double sort_mp_min = 1.8e6;     // PCC_OPT_SORT_MP_MIN: references from which the three-level sort is used (round 5, build us two-level /
+                                    // three-level: 1M 89 / 124, 1.5M 122 / 135, 2M 155 / 149)
     double sort_mp_min_q = 2.5e6;   // PCC_OPT_SORT_MP_MIN_Q: the same for query clouds (5M until round 5: with the cells from the pack kernel and the
                                     // larger level-3 stage the three-level form wins from ~2.5M on -- 3M 117 -> 88 us, 4M 131 -> 98 us, 2M 75 = 77)
     int nn1_kernel = 1;             // PCC_OPT_NN1_KERNEL: 0 one lane per query; 1 rows drained flat, lanes over candidates (2 / 3: open lanes listed / in place)
