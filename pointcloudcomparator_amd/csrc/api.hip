@@ -1305,8 +1305,9 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
     struct KeepOrder {  // the passes below share the first pass's lane order (see pcc_index::keep_order)
         pcc_index* ix;
         explicit KeepOrder(pcc_index* i) : ix(i) { ix->keep_order = true; ix->order_valid = false; ix->warm_start = false; }
-        ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; ix->warm_start = false; }
+        ~KeepOrder() { ix->keep_order = false; ix->order_valid = false; ix->warm_start = false; ix->pre_transform = nullptr; }
     } keep_order_guard(ix);
+    const bool fold = sorted && loop_env && grid_nn1_takes_transform(ix);  // the pass's transform applied by the next pass's search
     if (sorted) {  // (the passes take the identity as their order; the count of valid points sits in a word of its own)
         ix->order_valid = true;
         ix->order_nq = n;
@@ -1336,22 +1337,26 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
             for (int c = 0; c < chunk && pass < max_iter; ++c, ++pass) {
                 ev_next(ix);  // instrumentation: every pass is one "call" (NN kernel, far/fallback, whole pass)
                 ev_mark(ix, EV_CALL0);
+                // (cell-ordered loop: the search applies the previous pass's matrix -- the identity before the first -- to the
+                // queries it reads and writes them back; no transform kernel, grid.hip k_grid_nn1_flat2)
+                ix->pre_transform = fold ? st->Ti : nullptr;
                 PCC_TRY(nn1_packed(ix, n));  // determineCorrespondences: one NN per source point
+                ix->pre_transform = nullptr;
                 ix->warm_start = warm_env != 0;  // from now on out_packed holds the last pass's keys of these same points
                 int nb = 0;
+                unsigned int* zw = ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr;
                 PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
-                                        ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb,
-                                        ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr,
+                                        ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb, zw,
                                         static_cast<unsigned int*>(ix->pinned) + 40, center_dev));
                 if (hooks) {  // rows -> 17 sums (workgroup order, as the solver adds them) -> sum over the ranks -> solve
                     PCC_TRY(launch_icp_rows_to_sums(ix->stream, ix->scratch_a.as<double>(), nb, sums_dev));
                     PCC_TRY(hooks->allreduce_sum_f64(hooks->ctx, sums_dev, 17, ix->stream));
-                    PCC_TRY(launch_icp_solve(ix->stream, sums_dev, 1, st, max_iter, fixed, center_dev));
+                    PCC_TRY(launch_icp_solve(ix->stream, sums_dev, 1, st, max_iter, fixed, center_dev, fold ? zw : nullptr));
                 } else
-                PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed, center_dev));
-                // (the transform also zeroes the counters of the next pass's search)
-                unsigned int* zw = ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr;
-                PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4), zw));
+                PCC_TRY(launch_icp_solve(ix->stream, ix->scratch_a.as<double>(), nb, st, max_iter, fixed, center_dev, fold ? zw : nullptr));
+                // (the transform -- or, when the next search applies it itself, the solver -- also zeroes the counters of the next
+                // pass's search)
+                if (!fold) PCC_TRY(launch_transform(ix->stream, st->Ti, nullptr, ix->q_packed.p, n, sizeof(float4), ix->q_packed.p, sizeof(float4), zw));
                 if (zw && n > 0) ix->fb_zeroed = true;
                 ev_mark(ix, EV_CALL1);
             }

@@ -663,13 +663,13 @@ __device__ __forceinline__ void flat2_pass(FW& fw, const float4* __restrict__ ce
 template <int U, int B, int NW, bool OPENK>
 __global__ void __launch_bounds__(NW * 64)
 k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
-                 const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
+                 const GridDev* __restrict__ gd, const float4* q, const unsigned int* __restrict__ order,
                  const unsigned int* __restrict__ n_sorted_ptr, unsigned int n,
                  unsigned long long* __restrict__ out, unsigned int* __restrict__ fb_list,
                  unsigned int* __restrict__ fb_count, unsigned int xcd_run, bool ball_walk,
                  const float4* __restrict__ warm_refs, unsigned int dense_min,
                  unsigned int* __restrict__ open_list, unsigned long long* __restrict__ open_keys,
-                 unsigned int* __restrict__ open_total) {
+                 unsigned int* __restrict__ open_total, const float* __restrict__ pre_T, float4* q_rw) {
     const GridParams g = gd->g;
     const float slack = gd->slack;
     unsigned int bid = blockIdx.x;  // XCD-aware order of the workgroups, as in k_grid_nn1
@@ -698,6 +698,16 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
     }
     if (PCC_ABLATE & 32) qi = t;
     const bool active = __float_as_int(qv.w) >= 0;
+    // ICP passes in cell order (pcc_index::pre_transform): the previous pass's rigid motion is applied HERE, to the query the lane
+    // has just read, and written back for the kernels that follow (open lanes, far walk, sums) -- pcl::transformPointCloud's
+    // rounding, ((m0 x + m1 y) + m2 z) + m3, exactly as k_transform does it; the pass then has no transform kernel of its own
+    if (pre_T && active) {
+        const float x = qv.x, y = qv.y, z = qv.z;
+        qv.x = ((pre_T[0] * x + pre_T[1] * y) + pre_T[2] * z) + pre_T[3];
+        qv.y = ((pre_T[4] * x + pre_T[5] * y) + pre_T[6] * z) + pre_T[7];
+        qv.z = ((pre_T[8] * x + pre_T[9] * y) + pre_T[10] * z) + pre_T[11];
+        q_rw[qi] = qv;
+    }
     const float qx = qv.x, qy = qv.y, qz = qv.z;
     const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
     const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
@@ -1104,6 +1114,9 @@ int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** 
     return PCC_OK;
 }
 
+// can the k = 1 search of this handle apply the ICP loop's transform itself (flat kernel form)?
+bool grid_nn1_takes_transform(const pcc_index* ix) { return ix->opt.nn1_kernel != 0 && ix->n_orig <= F2_MAX_REFS; }
+
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out) {
     hipStream_t s = ix->stream;
     const unsigned int n = (unsigned int)nq;
@@ -1144,6 +1157,9 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     // list / the in-place finish (tests, measurements)
     int form = ix->opt.nn1_kernel;
     if (form != 0 && ix->n_orig > F2_MAX_REFS) form = 0;  // (the packed span record holds 26 bits of reference position)
+    // (the folded transform needs the flat kernel and the identity order; the caller checks with grid_nn1_takes_transform)
+    const float* pre_T = form != 0 && order == nullptr ? ix->pre_transform : nullptr;
+    if (ix->pre_transform && !pre_T) { set_error("internal: pre_transform without the flat kernel / identity order"); return PCC_ERR_INVALID; }
     if (form != 0) {
         const bool listed = form == 2 || (form == 1 && nq >= 2000000);
         const unsigned int dm = (unsigned int)ix->opt.nn1_dense_min;
@@ -1159,7 +1175,8 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
             open_keys = reinterpret_cast<unsigned long long*>(ix->scratch_f.as<char>() + ((list_cap * 4 + 15) & ~(size_t)15));
         }
 #define PCC_F2_ARGS ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, \
-                               fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr, dm, open_list, open_keys, open_total
+                               fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr, dm, open_list, open_keys, open_total, pre_T, \
+                               const_cast<float4*>(q)
         ix->open_pending = listed;
         if (!listed) ix->stats[7] = 0;
         if (listed) {

@@ -58,7 +58,13 @@ k_icp_sums(const float4* __restrict__ src, unsigned int n, const unsigned long l
 // enqueued applies the identity.
 __global__ void __launch_bounds__(1024)
 k_icp_solve(const double* __restrict__ partials, int n_blocks, IcpState* __restrict__ st, int max_iter, int fixed,
-            const double* __restrict__ center_dev) {
+            const double* __restrict__ center_dev, unsigned int* __restrict__ zero_word) {
+    // (the counters of the search that follows -- fallback list, far list, the sharded open-lane counters -- as k_pack / k_transform
+    // zero them: when the next pass's search applies the transform itself there is no k_transform in between)
+    if (zero_word && threadIdx.x < 64) {
+        if (threadIdx.x < 2) zero_word[threadIdx.x] = 0u;
+        zero_word[PCC_OPEN_CTR0 - 32 + threadIdx.x * PCC_OPEN_CTR_STRIDE] = 0u;
+    }
     __shared__ double sums[17];
     extern __shared__ double part[];  // all partial rows, staged with coalesced loads (the rows come from other XCDs'
                                       // write-backs: read one by one in a dependent loop they cost 120 us)
@@ -130,9 +136,9 @@ int launch_icp_rows_to_sums(hipStream_t s, const double* partials, int n_blocks,
 }
 
 int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed,
-                     const double* center_dev) {
+                     const double* center_dev, unsigned int* zero_word) {
     hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(1024), (size_t)n_blocks * 17 * sizeof(double), s, partials, n_blocks, state,
-                       max_iter, fixed, center_dev);
+                       max_iter, fixed, center_dev, zero_word);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -147,6 +147,8 @@ struct pcc_index {
     // ICP moves the same source cloud rigidly from pass to pass: the lane order of its first pass keeps
     // neighbouring lanes on neighbouring points, so later passes skip the query sort
     bool keep_order = false, order_valid = false;
+    const float* pre_transform = nullptr;  // ICP loop in cell order: the 3 x 4 matrix (device memory) the next k = 1 search applies to its
+                                           // queries, and writes back, before it looks -- the pass's k_transform folded into the search
     bool warm_start = false;  // ICP passes after the first: out_packed holds the previous pass's keys (grid_nn1 starts from them)
     size_t order_nq = 0;
     unsigned int* order_ptr = nullptr;
@@ -271,6 +273,7 @@ int sync_info(pcc_index* ix);                                              // wa
 unsigned int grid_nc_cap(size_t n, double ppc);
 int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out);
 // sort queries by reference-grid cell: order[0..*n_sorted) (device) lists the valid queries
+bool grid_nn1_takes_transform(const pcc_index* ix);
 int grid_sort_queries(pcc_index* ix, const float4* q, size_t nq, unsigned int** order_dev,
                       unsigned int** n_sorted_dev);
 float grid_slack(const GridParams& g);
@@ -329,7 +332,7 @@ struct IcpState {
     int converged;    // pcl::DefaultConvergenceCriteria's verdict at the stop
 };
 int launch_icp_solve(hipStream_t s, const double* partials, int n_blocks, IcpState* state, int max_iter, int fixed,
-                     const double* center_dev);
+                     const double* center_dev, unsigned int* zero_word = nullptr);
 int launch_icp_center(hipStream_t s, const float4* src, size_t n, double* center_dev);  // first valid point of src
 // the per-workgroup rows added up in workgroup order (what k_icp_solve does before it solves): sums17[k] on the device
 int launch_icp_rows_to_sums(hipStream_t s, const double* partials, int n_blocks, double* sums17);
