@@ -159,11 +159,15 @@ enum pcc_option {
                                     0 = one lane per listed query (round 3) */
     PCC_OPT_SORT_STAGE1 = 15,    /* three-level cell sort, level 1: 1 = reference points leave in bucket-sorted LDS tiles, whole runs
                                     stored (default); 0 = one store per point; 2 = tiles for the queries' 8-byte pairs too */
-    PCC_OPT_ICP_SORTED = 16      /* pcc_icp_align: 1 = the source cloud is brought into the target grid's cell order once and every pass
+    PCC_OPT_ICP_SORTED = 16,     /* pcc_icp_align: 1 = the source cloud is brought into the target grid's cell order once and every pass
                                     reads and writes it front to back (default); 0 = caller's order, gathered / scattered in every pass.
                                     (The one option whose setting shows in a result: the 17 double sums of a pass are added up in the
                                     working order, so T and fitness can differ between 0 and 1 in their last bits; every form of the
                                     loop -- device, host, sharded -- agrees to the bit under either.) */
+    PCC_OPT_OVERLAP_PREP = 17    /* pcc_nn1 called directly after pcc_index_set_input / pcc_index_create (the reference's pattern,
+                                    src/comparator.cpp:564-577: setInputCloud, then the query loop): 1 = the queries are packed and
+                                    sorted on a second stream of the library WHILE the build's cell sort runs (default); 0 = one stream,
+                                    one kernel after the other.  Same kernels, same results; only their placement in time differs. */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -19,7 +19,7 @@ KNN_MAX_K = 65536
 # enum pcc_option
 (OPT_GRID_PPC, OPT_GRID_TRIM, OPT_FAR_MODE, OPT_ICP_WARM, OPT_ICP_DEVICE_LOOP, OPT_EC_CELLS, OPT_SORT_MP_MIN,
  OPT_SORT_MP_MIN_Q, OPT_NN1_KERNEL, OPT_FLANN_SPLIT, OPT_NN1_DENSE_MIN, OPT_KNN_KERNEL, OPT_KNN_CACHE_K, OPT_NN1_OPEN_FLAT, OPT_SORT_STAGE1,
- OPT_ICP_SORTED) = range(1, 17)
+ OPT_ICP_SORTED, OPT_OVERLAP_PREP) = range(1, 18)
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PCC_LIB", _HERE / "lib" / "libpcc_nn.so"))
@@ -390,6 +390,15 @@ class Index:
 
     def set_stream(self, stream_ptr: int):
         _check(LIB.pcc_index_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def wait_stream(self, stream_ptr: int):
+        """pcc_index_wait_stream: calls made after this one start only when everything submitted so far to the stream
+        `stream_ptr` (a hipStream_t as an integer, e.g. torch.cuda.Stream().cuda_stream) has finished"""
+        _check(LIB.pcc_index_wait_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def stream_wait(self, stream_ptr: int):
+        """pcc_stream_wait_index: work submitted to `stream_ptr` from now on waits for what the index has been asked so far"""
+        _check(LIB.pcc_stream_wait_index(self._h, C.c_void_p(stream_ptr)))
 
     def sync(self):
         _check(LIB.pcc_index_sync(self._h))

@@ -234,17 +234,20 @@ int pcc_index_create_broadcast(pcc_comm* c, int root, const void* pts, size_t n,
     st = PCC_OK;
     if (c->rank != root) {
         std::lock_guard<std::mutex> lock(ix->mu);
+        pcc::entered(ix);
         st = n64 ? ix->icp_src.reserve((size_t)n64 * sizeof(float4)) : PCC_ERR_EMPTY;
     }
     if ((st = agree_status(c, st)) != PCC_OK) return fail(st);
     // step 4: the packed cloud, 16 B per point, in one broadcast on the handle's stream; every other rank builds over its copy
     if (c->rank == root) {
         std::lock_guard<std::mutex> lock(ix->mu);
+        pcc::entered(ix);
         ncclResult_t r = rccl()->Broadcast(ix->refs.p, ix->refs.p, (size_t)n64 * 4, ncclFloat, root, c->nccl, ix->stream);
         if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); st = PCC_ERR_DEVICE; }
         else if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("broadcast failed: %s", hipGetErrorString(hipGetLastError())); st = PCC_ERR_DEVICE; }
     } else {
         std::lock_guard<std::mutex> lock(ix->mu);
+        pcc::entered(ix);
         ncclResult_t r = rccl()->Broadcast(ix->icp_src.p, ix->icp_src.p, (size_t)n64 * 4, ncclFloat, root, c->nccl, ix->stream);
         if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); st = PCC_ERR_DEVICE; }
         // (non-finite points get their NaN back so that the build sees what the root's upload saw; then the usual build)
@@ -301,6 +304,7 @@ static int sor_shard_means(pcc_index* ix, size_t start, size_t count, int mean_k
 int pcc_sor_partial(pcc_index* ix, size_t start, size_t count, int mean_k, int mem, float* mean_dist, double sums[4]) {
     if (!ix) { set_error("null index"); return PCC_ERR_INVALID; }
     std::lock_guard<std::mutex> lock(ix->mu);
+    pcc::entered(ix);
     SetDevice g(ix->device);
     if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return PCC_ERR_INVALID; }
     if (!sums) { set_error("null sums"); return PCC_ERR_INVALID; }
@@ -336,6 +340,7 @@ int pcc_sor_sharded(pcc_index* ix, pcc_comm* c, size_t start, size_t count, int 
     if (ix->device != c->device) { set_error("index on device %d, communicator on device %d", ix->device, c->device); return agree_status(c, PCC_ERR_INVALID); }
     if (mem != PCC_MEM_HOST && mem != PCC_MEM_DEVICE) { set_error("bad mem space"); return agree_status(c, PCC_ERR_INVALID); }
     std::lock_guard<std::mutex> lock(ix->mu);
+    pcc::entered(ix);
     SetDevice g(ix->device);
     hipStream_t s = ix->stream;
     const int K = mean_k + 1;

@@ -1131,7 +1131,11 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     }
     ix->fb_zeroed = false;
     unsigned int *order = nullptr, *n_sorted = nullptr;
-    if (ix->keep_order && ix->order_valid && ix->order_nq == nq) {
+    if (ix->pre_order && ix->pre_order_nq == nq && !ix->keep_order) {
+        order = ix->pre_order;  // sorted beside the index build by the caller (api.hip: PrepOverlap), for this search only
+        n_sorted = ix->pre_nsorted;
+        ix->pre_order = nullptr;
+    } else if (ix->keep_order && ix->order_valid && ix->order_nq == nq) {
         order = ix->order_ptr;  // (any permutation of the valid queries is correct; this one is still coherent)
         n_sorted = ix->order_nsorted;
     } else {

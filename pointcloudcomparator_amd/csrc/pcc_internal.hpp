@@ -108,6 +108,8 @@ struct Options {
     int sort_stage1 = 1;            // PCC_OPT_SORT_STAGE1: level 1 of the three-level sort writes bucket-sorted LDS tiles (1: reference points; 2: query pairs too; 0: one store per point)
     int nn1_open_flat = 1;          // PCC_OPT_NN1_OPEN_FLAT: the listed open lanes drained flat (k_nn1_open_flat); 0 = one lane per query
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
+    int overlap_prep = 1;           // PCC_OPT_OVERLAP_PREP: a k = 1 search that follows setInputCloud directly packs and sorts its queries on a
+                                    // second stream while the build's cell sort is still running (they share nothing but the grid parameters)
     void from_env();
 };
 
@@ -123,6 +125,23 @@ struct pcc_index {
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // library-owned stream
     hipEvent_t edge_ev = nullptr;      // pcc_index_wait_stream / pcc_stream_wait_index
+    // Query staging beside the build (PCC_OPT_OVERLAP_PREP, api.hip: PrepOverlap).  params_ev is recorded behind k_grid_params of
+    // every build; a search that is the NEXT call on the handle (build_fresh) sends its pack + query sort to side_stream behind
+    // that event -- not behind the build's sort -- and the main stream picks the result up through side_ev.  The sort's scratch is
+    // swapped for the `side` set meanwhile, so the two sorts share no buffer.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t params_ev = nullptr, side_ev = nullptr;
+    bool params_ev_set = false;        // params_ev was recorded by the build the handle currently holds, on the stream in use
+    bool build_fresh = false;          // nothing has been enqueued on the handle since that build
+    bool after_build = false;          // build_fresh as the entry point in progress found it
+    bool edge_fresh = false;           // one pcc_index_wait_stream came between the build and now: side_stream waits for edge_ev too
+    struct SideScratch {
+        pcc::DevBuf a, b, c, e, mp_a, mp_b, mp_c, scan_flags;
+        unsigned int scan_epoch = 0;
+    } side;
+    unsigned int* pre_order = nullptr;    // a query order prepared ahead of grid_nn1 (this call only): order, count word, queries
+    unsigned int* pre_nsorted = nullptr;
+    size_t pre_order_nq = 0;
     size_t n_orig = 0;                 // points handed to pcc_index_create / set_input
     size_t n_valid = 0;                // finite points (PCL total_nr_points_); valid after sync_info()
     unsigned int nc_cap = 0;           // upper bound of the grid's cell count the host sizes launches with
@@ -202,6 +221,12 @@ __host__ __device__
 inline bool key_none(unsigned long long key) { return (unsigned int)(key >> 32) >= 0x7f7fffffu; }
 
 enum { EV_MAIN0 = 0, EV_MAIN1, EV_FB0, EV_FB1, EV_CALL0, EV_CALL1, EV_BUILD0, EV_BUILD1, EV_SORT0, EV_SORT1 };
+// every entry point that may enqueue work passes here once it holds the handle's mutex
+inline void entered(pcc_index* ix) {
+    ix->after_build = ix->build_fresh;
+    ix->build_fresh = false;
+    ix->pre_order = nullptr;  // (an order prepared by a call that failed before using it)
+}
 inline void ev_mark(pcc_index* ix, int id) {
     if (!ix->timing || (ix->timing == 1 && id > EV_MAIN1)) return;
     unsigned int s = ix->ev_slot % PCC_EV_SLOTS;

@@ -66,6 +66,75 @@ def test_c3_10m_xyzrgb_stride_sampled(gpu):
     _sample_check(a, b, idx.cpu().numpy(), d2.cpu().numpy(), n_sample=10000)
 
 
+def test_search_staged_beside_the_build_equals_the_search_behind_it(gpu):
+    """PCC_OPT_OVERLAP_PREP: a k = 1 search that follows setInputCloud directly packs and sorts its queries on the library's
+    second stream while the build's sort runs.  Same bits as one stream; calls in between fall back to one stream; a
+    producer stream announced between the two calls is honoured by the second stream as well."""
+    a = synth.corridor_cloud(3_000_000, synth.SEED_A)
+    a2 = synth.corridor_cloud(2_500_000, synth.SEED_A + 5)
+    b = synth.corridor_cloud(2_600_000, synth.SEED_B)
+    b[7] = np.nan
+    ta, ta2, tb = torch.from_numpy(a).cuda(), torch.from_numpy(a2).cuda(), torch.from_numpy(b).cuda()
+    torch.cuda.synchronize()
+
+    def same(x, y):
+        return bool((x[0] == y[0]).all()) and bool((x[1].view(torch.int32) == y[1].view(torch.int32)).all())
+
+    def outs(n):
+        return torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda")
+
+    # (auto_sync off: nothing orders the library's stream against torch's but ix.sync(), so every result has buffers of its own)
+    nq = len(b)
+    ref_a, ref_a2, got_a, got_a2, got, small = outs(nq), outs(nq), outs(nq), outs(nq), outs(nq), outs(100_000)
+    with capi.Index(ta, engine=capi.ENGINE_GRID, auto_sync=False) as ix:
+        ix.set_option(capi.OPT_OVERLAP_PREP, 0)
+        ix.set_input(ta)
+        ix.nn1(tb, *ref_a)
+        ix.set_input(ta2)
+        ix.nn1(tb, *ref_a2)
+        ix.sync()
+        _sample_check(a, b[100:], ref_a[0][100:].cpu().numpy(), ref_a[1][100:].cpu().numpy(), n_sample=3000)
+        assert int(ref_a[0][7]) == -1
+        ix.set_option(capi.OPT_OVERLAP_PREP, 1)
+        for _ in range(3):  # back to back, no host wait in between: the next build follows the search on the stream
+            ix.set_input(ta)
+            ix.nn1(tb, *got_a)
+            ix.set_input(ta2)
+            ix.nn1(tb, *got_a2)
+        ix.sync()
+        assert same(got_a, ref_a) and same(got_a2, ref_a2)
+        # something else between the build and the search: the search runs behind it on the one stream
+        ix.set_input(ta)
+        ki, kd = ix.knn(tb[:50_000], 4)
+        ix.nn1(tb, *got)
+        ix.sync()
+        assert same(got, ref_a)
+        assert bool((ki[:, 0] == ref_a[0][:50_000]).all())
+        # a second search on the same build, and one of a shard below the staging's crossover
+        got[0].fill_(-5)
+        torch.cuda.synchronize()
+        ix.nn1(tb, *got)
+        ix.nn1(tb[:100_000], *small)
+        ix.sync()
+        assert same(got, ref_a) and same(small, (ref_a[0][:100_000], ref_a[1][:100_000]))
+        # the queries are produced on another stream, announced between the build and the search
+        producer = torch.cuda.Stream()
+        tq = torch.zeros_like(tb)
+        big = torch.randn(4096, 4096, device="cuda")
+        got[0].fill_(-5)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(producer):
+            for _ in range(30):
+                big = (big @ big) * 1e-3
+            tq.copy_(tb)
+        ix.set_input(ta2)
+        ix.wait_stream(producer.cuda_stream)
+        ix.nn1(tq, *got)
+        ix.sync()
+        torch.cuda.synchronize()
+        assert same(got, ref_a2)
+
+
 def test_c3_object_layer_clusters_known_partition(gpu):
     # 5M points of the object layer: the 256 balls are the clusters by construction
     pts = synth.corridor_cloud(5_000_000, synth.SEED_A, layer="objects")
