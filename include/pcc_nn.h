@@ -167,7 +167,8 @@ enum pcc_option {
     PCC_OPT_OVERLAP_PREP = 17    /* pcc_nn1 called directly after pcc_index_set_input / pcc_index_create (the reference's pattern,
                                     src/comparator.cpp:564-577: setInputCloud, then the query loop): 1 = the queries are packed and
                                     sorted on a second stream of the library WHILE the build's cell sort runs (default); 0 = one stream,
-                                    one kernel after the other.  Same kernels, same results; only their placement in time differs. */
+                                    one kernel after the other.  Same kernels, same results; only their placement in time differs.
+                                    It acts from 2M queries on (below that it hides nothing); 2 = at every size (tests). */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -46,6 +46,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_NN1_DENSE_MIN: return value >= 1 && value <= 1000000;
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
         case PCC_OPT_SORT_STAGE1: return value >= 0 && value <= 2;
+        case PCC_OPT_OVERLAP_PREP: return value >= 0 && value <= 2;
         default: return value == 0 || value == 1;
     }
 }
@@ -307,7 +308,7 @@ struct PrepOverlap {
     static constexpr size_t min_queries = 2000000;
     static bool wanted(const pcc_index* ix, size_t nq) {
         return ix->opt.overlap_prep && ix->after_build && ix->params_ev_set && ix->engine == PCC_ENGINE_GRID && ix->has_grid &&
-               !ix->keep_order && nq >= min_queries;
+               !ix->keep_order && (nq >= min_queries || ix->opt.overlap_prep == 2);  // (2: whatever the size -- tests, fuzz)
     }
     explicit PrepOverlap(pcc_index* i) : ix(i) {}
     void swap_scratch() {

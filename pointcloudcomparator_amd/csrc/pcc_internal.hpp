@@ -109,7 +109,8 @@ struct Options {
     int nn1_open_flat = 1;          // PCC_OPT_NN1_OPEN_FLAT: the listed open lanes drained flat (k_nn1_open_flat); 0 = one lane per query
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     int overlap_prep = 1;           // PCC_OPT_OVERLAP_PREP: a k = 1 search that follows setInputCloud directly packs and sorts its queries on a
-                                    // second stream while the build's cell sort is still running (they share nothing but the grid parameters)
+                                    // second stream while the build's cell sort is still running (they share nothing but the grid parameters);
+                                    // from 2M queries on, 2 = at every size
     void from_env();
 };
 

@@ -85,7 +85,7 @@ def test_search_staged_beside_the_build_equals_the_search_behind_it(gpu):
 
     # (auto_sync off: nothing orders the library's stream against torch's but ix.sync(), so every result has buffers of its own)
     nq = len(b)
-    ref_a, ref_a2, got_a, got_a2, got, small = outs(nq), outs(nq), outs(nq), outs(nq), outs(nq), outs(100_000)
+    ref_a, ref_a2, got_a, got_a2, got, small, mid = outs(nq), outs(nq), outs(nq), outs(nq), outs(nq), outs(100_000), outs(2_200_000)
     with capi.Index(ta, engine=capi.ENGINE_GRID, auto_sync=False) as ix:
         ix.set_option(capi.OPT_OVERLAP_PREP, 0)
         ix.set_input(ta)
@@ -110,6 +110,11 @@ def test_search_staged_beside_the_build_equals_the_search_behind_it(gpu):
         ix.sync()
         assert same(got, ref_a)
         assert bool((ki[:, 0] == ref_a[0][:50_000]).all())
+        # 2.2M queries: beside the build too, and the TWO-level query sort (below PCC_OPT_SORT_MP_MIN_Q) on the second scratch set
+        ix.set_input(ta)
+        ix.nn1(tb[:2_200_000], *mid)
+        ix.sync()
+        assert same(mid, (ref_a[0][:2_200_000], ref_a[1][:2_200_000]))
         # a second search on the same build, and one of a shard below the staging's crossover
         got[0].fill_(-5)
         torch.cuda.synchronize()

@@ -300,3 +300,37 @@ def test_ties_flann_with_non_finite_queries_at_wave_leaders(gpu, engine):
     assert (_bits(d2[good]) == _bits(fd)).all()
     assert (idx[good] == fi).all(), np.nonzero(idx[good] != fi)[0][:8]
     assert st[5] == good.sum() and st[6] == (fi != li).sum(), (st[5], st[6], good.sum(), (fi != li).sum())
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+@pytest.mark.parametrize("m,n", [(5000, 1), (5000, 63), (4097, 4097), (70000, 20011), (300000, 150000)])
+def test_nn1_staged_beside_the_build_at_every_size(gpu, engine, m, n):
+    """PCC_OPT_OVERLAP_PREP = 2: the search that follows setInputCloud stages its queries on the second stream whatever the
+    size (the default acts from 2M queries on) -- small grids, the two-level sort, host and device clouds, non-finite
+    queries, rebuilds over other clouds on the same handle.  The exhaustive engine has no grid: the option must not act."""
+    torch = pytest.importorskip("torch")
+    a = synth.corridor_cloud(m, synth.SEED_A)
+    a2 = synth.corridor_cloud(max(m // 2, 4097), synth.SEED_A + 3)
+    b = synth.with_rgb_stride(synth.corridor_cloud(n, synth.SEED_B))
+    b[n // 2, 1] = np.nan
+    want = {id(a): oracle.nn1_exhaustive(a, b), id(a2): oracle.nn1_exhaustive(a2, b)}
+
+    def ok(got, ref):
+        return (np.asarray(got[0]) == ref[0]).all() and (_bits(got[1]) == _bits(ref[1])).all()
+
+    with capi.Index(a, engine=engine) as ix:
+        ix.set_option(capi.OPT_OVERLAP_PREP, 2)
+        assert ok(ix.nn1(b), want[id(a)])            # first call on a fresh handle (the build has finished)
+        for cloud in (a2, a, a2):                    # host clouds: build and search back to back
+            ix.set_input(cloud)
+            assert ok(ix.nn1(b), want[id(cloud)])
+        ta, ta2, tb = torch.from_numpy(a).cuda(), torch.from_numpy(a2).cuda(), torch.from_numpy(b).cuda()
+        for cloud, t in ((a, ta), (a2, ta2), (a, ta)):   # device clouds through torch's stream (auto_sync edges on both sides)
+            ix.set_input(t)
+            gi, gd = ix.nn1(tb)
+            ix.sync()
+            assert ok((gi.cpu().numpy(), gd.cpu().numpy()), want[id(cloud)])
+        ix.set_input(a2)
+        ki, _ = ix.knn(b[:50], 2)                    # another call in between: one stream
+        assert ok(ix.nn1(b), want[id(a2)])
+        assert (ki[:, 0] == want[id(a2)][0][:50]).all()

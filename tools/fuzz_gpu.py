@@ -157,9 +157,16 @@ def main():
                 ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([3, 3, 1, 2, 0])))
                 if rng.random() < 0.2:
                     ix.set_option(capi.OPT_NN1_DENSE_MIN, int(rng.choice([1, 2, 1000000])))
+                # the staging of a search that follows the build directly: behind it / beside it on the second stream (2: at every size)
+                ix.set_option(capi.OPT_OVERLAP_PREP, int(rng.choice([0, 1, 2, 2])))
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
                 check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
+                if rng.random() < 0.3:
+                    # setInputCloud + search back to back on the used handle (the build still in flight when the staging starts)
+                    ix.set_input(a)
+                    i3, d3 = ix.nn1(q)
+                    check("nn1_after_rebuild", (i3 == oi).all() and (bits(d3) == bits(od)).all(), a=a, q=q, engine=engine)
                 op = rng.integers(0, 11)
                 if args.trace:
                     with open(args.trace, "a") as f:
