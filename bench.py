@@ -359,9 +359,11 @@ def main():
             "scaling_terms": {"step_ms": dt / steps * 1e3, "query_only_ms": dtq / steps * 1e3, "build_ms": dtb / steps * 1e3,
                               "build_ms_inside_step": tm[3], "queries_per_gpu": N,
                               "note": "build_ms (the build alone, its own loop) is replicated on every rank; only query_only_ms shrinks with "
-                                      "the shard.  From 2M queries per GPU on the queries are packed and sorted on a second stream beside the "
-                                      "build's sort (PCC_OPT_OVERLAP_PREP), so step_ms is a little below build_ms + query_only_ms and the "
-                                      "build's events inside a step (build_ms_inside_step) span the staging's kernels too"},
+                                      "the shard.  The two parts are looped separately and do not add up to step_ms exactly (a step also "
+                                      "carries the hand-over between the two calls).  From 2M queries per GPU on the queries are packed and "
+                                      "sorted on a second stream beside the build's sort (PCC_OPT_OVERLAP_PREP: 2 % of the step in a same-box "
+                                      "A/B, DESIGN.md 4.3), so the build's events inside a step (build_ms_inside_step) span the staging's "
+                                      "kernels too and are no measure of the build"},
         }
         if per_rank_ms is not None:
             r["per_rank_ms_per_step"] = per_rank_ms
