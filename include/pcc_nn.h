@@ -164,11 +164,19 @@ enum pcc_option {
                                     (The one option whose setting shows in a result: the 17 double sums of a pass are added up in the
                                     working order, so T and fitness can differ between 0 and 1 in their last bits; every form of the
                                     loop -- device, host, sharded -- agrees to the bit under either.) */
-    PCC_OPT_OVERLAP_PREP = 17    /* pcc_nn1 called directly after pcc_index_set_input / pcc_index_create (the reference's pattern,
+    PCC_OPT_OVERLAP_PREP = 17,   /* pcc_nn1 called directly after pcc_index_set_input / pcc_index_create (the reference's pattern,
                                     src/comparator.cpp:564-577: setInputCloud, then the query loop): 1 = the queries are packed and
                                     sorted on a second stream of the library WHILE the build's cell sort runs (default); 0 = one stream,
                                     one kernel after the other.  Same kernels, same results; only their placement in time differs.
-                                    It acts from 2M queries on (below that it hides nothing); 2 = at every size (tests). */
+                                    It acts from 2M queries on (below that it hides nothing); 2 = at every size (tests).  Only on the
+                                    library's own stream: after pcc_index_set_stream the caller's stream is the one order there is. */
+    PCC_OPT_GRID_AXES = 18,      /* which coordinate of the cloud the grid's three axes -- along a row of cells, over the rows of a
+                                    layer, over the layers -- follow: -1 = chosen per index from the cloud's extents (second shortest,
+                                    shortest, longest: the rows and layers next to a query's row are then as close to it in memory as
+                                    the cloud allows; default); 0 = x, y, z (rounds 1-5); 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx.  Takes
+                                    effect at the next pcc_index_set_input.  No result bit depends on it. */
+    PCC_OPT_XCD_RUN = 19         /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
+                                    i.e. the stretch of the grid one L2 works on at a time (default 32) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -47,6 +47,8 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
         case PCC_OPT_SORT_STAGE1: return value >= 0 && value <= 2;
         case PCC_OPT_OVERLAP_PREP: return value >= 0 && value <= 2;
+        case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
+        case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
         default: return value == 0 || value == 1;
     }
 }
@@ -70,6 +72,8 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_SORT_STAGE1: *as_int = &o.sort_stage1; return nullptr;
         case PCC_OPT_ICP_SORTED: *as_int = &o.icp_sorted; return nullptr;
         case PCC_OPT_OVERLAP_PREP: *as_int = &o.overlap_prep; return nullptr;
+        case PCC_OPT_GRID_AXES: *as_int = &o.grid_axes; return nullptr;
+        case PCC_OPT_XCD_RUN: *as_int = &o.xcd_run; return nullptr;
         default: return nullptr;
     }
 }
@@ -83,7 +87,8 @@ void Options::from_env() {
         {"PCC_SORT_MP_MIN", PCC_OPT_SORT_MP_MIN}, {"PCC_SORT_MP_MIN_Q", PCC_OPT_SORT_MP_MIN_Q}, {"PCC_NN1_KERNEL", PCC_OPT_NN1_KERNEL},
         {"PCC_FLANN_SPLIT", PCC_OPT_FLANN_SPLIT}, {"PCC_NN1_DENSE_MIN", PCC_OPT_NN1_DENSE_MIN}, {"PCC_KNN_KERNEL", PCC_OPT_KNN_KERNEL},
         {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1},
-        {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}, {"PCC_OVERLAP_PREP", PCC_OPT_OVERLAP_PREP}};
+        {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}, {"PCC_OVERLAP_PREP", PCC_OPT_OVERLAP_PREP},
+        {"PCC_GRID_AXES", PCC_OPT_GRID_AXES}, {"PCC_XCD_RUN", PCC_OPT_XCD_RUN}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;
@@ -306,8 +311,11 @@ struct PrepOverlap {
     // (below ~2M queries the staging is a few launches of 10-20 us each and the second stream's events cost what they hide:
     // 1M x 1M 0.221 / 0.222 / 0.226 ms without, 0.225 with; 10M x 10M 1.331 / 1.334 / 1.319 -> 1.308 / 1.303 / 1.301)
     static constexpr size_t min_queries = 2000000;
+    // Only on the library's OWN stream: a caller that has handed its stream over (pcc_index_set_stream) may have enqueued the
+    // kernel that produces the queries on it between the build and this search -- "enqueued on the index's stream" is the
+    // ordering pcc_nn.h promises -- and the side stream, which waits for the build's k_grid_params only, would read them early.
     static bool wanted(const pcc_index* ix, size_t nq) {
-        return ix->opt.overlap_prep && ix->after_build && ix->params_ev_set && ix->engine == PCC_ENGINE_GRID && ix->has_grid &&
+        return ix->opt.overlap_prep && ix->stream == ix->own_stream && ix->after_build && ix->params_ev_set && ix->engine == PCC_ENGINE_GRID && ix->has_grid &&
                !ix->keep_order && (nq >= min_queries || ix->opt.overlap_prep == 2);  // (2: whatever the size -- tests, fuzz)
     }
     explicit PrepOverlap(pcc_index* i) : ix(i) {}

@@ -51,9 +51,11 @@ k_uf_link(const float4* __restrict__ cell_refs, const unsigned int* __restrict__
     const unsigned int mypos = (unsigned int)__float_as_int(me.w);
     int x0, x1, y0, y1, z0, z1;
     const float rr = r + slack;
-    cell_range(me.x, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
-    cell_range(me.y, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
-    cell_range(me.z, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
+    float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+    grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+    cell_range(ux, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
+    cell_range(uy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
+    cell_range(uz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
     for (int z = z0; z <= z1; ++z)
         for (int y = y0; y <= y1; ++y) {
             const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
@@ -75,9 +77,11 @@ k_uf_link_cells(const float4* __restrict__ cr2, const unsigned int* __restrict__
     if (t >= gd2->n_valid) return;
     const float4 me = cr2[t];
     const unsigned int mypos = (unsigned int)__float_as_int(me.w);
-    const int cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
-    const int cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
-    const int cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+    float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+    grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+    const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
     const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
     const unsigned int a0 = cs2[c], a1 = cs2[c + 1];
     const unsigned int first = (unsigned int)__float_as_int(cr2[a0].w);
@@ -133,9 +137,11 @@ k_uf_link_cells_wave(const float4* __restrict__ cr2, const unsigned int* __restr
     unsigned int a0 = 0, a1 = 0, first = 0;
     if (have) {
         const float4 me = cr2[t];
-        cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
-        cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
-        cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+        float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+        grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+        cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
         const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
         a0 = cs2[c];
         a1 = cs2[c + 1];
@@ -235,9 +241,11 @@ k_ecc_link_faces(const float4* __restrict__ cr2, const unsigned int* __restrict_
     unsigned int c = 0, a0 = 0xffffffffu, a1 = 0;
     if (t < n_valid) {
         const float4 me = cr2[t];
-        cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
-        cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
-        cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+        float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+        grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+        cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
         c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
         a0 = cs2[c];
         a1 = cs2[c + 1];
@@ -293,9 +301,11 @@ k_ecc_link_rest(const float4* __restrict__ cr2, const unsigned int* __restrict__
     unsigned int a0 = 0, a1 = 0, ra = 0;
     if (have) {
         const float4 me = cr2[t];
-        cx = cell_coord(me.x, g.org[0], g.inv_h, g.dim[0]);
-        cy = cell_coord(me.y, g.org[1], g.inv_h, g.dim[1]);
-        cz = cell_coord(me.z, g.org[2], g.inv_h, g.dim[2]);
+        float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+        grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+        cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
         const unsigned int c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
         a0 = cs2[c];
         a1 = cs2[c + 1];
@@ -532,11 +542,18 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
         memset(&hd, 0, sizeof(hd));
         const float h = r * 0.57f;
         double cells = 1;
+        // (the same layout rule as the search grid: the face links of k_ecc_link_faces reach one row and one layer ahead)
+        float ext3[3];
+        for (int a = 0; a < 3; ++a) ext3[a] = ix->bbox_hi[a] - ix->bbox_lo[a];
+        grid_axes_for(ext3, ix->opt.grid_axes, hd.g.ax);
         for (int a = 0; a < 3; ++a) {
-            const double ext = (double)ix->bbox_hi[a] - (double)ix->bbox_lo[a];
-            hd.g.org[a] = ix->bbox_lo[a];
+            const int c = hd.g.ax[a];
+            const double ext = (double)ix->bbox_hi[c] - (double)ix->bbox_lo[c];
+            hd.g.org[a] = ix->bbox_lo[c];
             hd.g.dim[a] = (int)std::min(ext / h + 2.0, 2.0e9);
             cells *= (double)hd.g.dim[a];
+            hd.lo[c] = hd.glo[a] = ix->bbox_lo[c];
+            hd.hi[c] = hd.ghi[a] = ix->bbox_hi[c];
         }
         if (ix->n_valid > 0 && cells <= (double)(1u << 26)) {
             hd.g.h = h;

@@ -48,9 +48,11 @@ k_tie_flags_grid(const float4* __restrict__ cell_refs, const unsigned int* __res
     int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
     bool tie = false;
     if (valid) {
-        cell_range(qv.x, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
-        cell_range(qv.y, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
-        cell_range(qv.z, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
+        float ux, uy, uz;  // the query in the grid's frame (grid_device.hpp)
+        grid_frame(g, qv.x, qv.y, qv.z, ux, uy, uz);
+        cell_range(ux, rb, g.org[0], g.inv_h, g.dim[0], x0, x1);
+        cell_range(uy, rb, g.org[1], g.inv_h, g.dim[1], y0, y1);
+        cell_range(uz, rb, g.org[2], g.inv_h, g.dim[2], z0, z1);
         tie = !(rb < __builtin_inff()) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > 4096;
     }
     for (int z = z0; z <= z1 && !tie; ++z)

@@ -82,7 +82,7 @@ __device__ __forceinline__ void wave_kth_max6(float v[6], int k) {
 // as open-ended (cell_coord clamps, outside_bound2 takes no bound from a face on the grid's edge, cell_range
 // clamps): results stay exact, and the handle still reports the true bounding box.
 __global__ void __launch_bounds__(1024)
-k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap, int trim_k,
+k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc, unsigned int nc_cap, int trim_k, int axes,
               GridDev* __restrict__ out, GridDev* __restrict__ host_mirror) {
     __shared__ float red[16][8];
     __shared__ float rob[16][6];  // (1024 threads: one wave per group of 64 rows)
@@ -160,14 +160,20 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
     if (cells_wanted > (double)nc_cap) cells_wanted = (double)nc_cap;
     double hcell = nd ? pow(vol / cells_wanted, 1.0 / (double)nd) : 1.0;
     if (!(hcell > 0.0) || !(hcell < 1e300)) hcell = 1.0;
+    // Which coordinate each grid axis follows (GridParams::ax).  A query's neighbourhood is its own row of cells, the rows above
+    // and below it (dim0 cells away in memory) and the same rows of the layers before and behind (dim0 * dim1 cells away): the
+    // SHORTEST extent goes on axis 1 and the longest on axis 2, so that a layer -- what the searches of neighbouring queries keep
+    // re-reading from the L2 -- is as small as the cloud allows.  A room scan is long and wide and 2.7 m high: with z on axis 2
+    // (rounds 1-5) the rows of the layer above were a whole floor plan away.  Ties keep x, y, z order.
     GridParams g;
+    grid_axes_for(ext, axes, g.ax);
     for (int iter = 0; iter < 200; ++iter) {  // grow the cell until the grid fits nc_cap
         g.h = (float)hcell;
         g.inv_h = 1.0f / g.h;
         if (!(g.inv_h > 0.f) || !(g.inv_h < __builtin_inff()) || !(g.h > 0.f)) { g.h = 1.f; g.inv_h = 1.f; }
         double tot = 1.0;
         for (int a = 0; a < 3; ++a) {
-            double dd = floor((double)ext[a] * (double)g.inv_h) + 1.0;
+            double dd = floor((double)ext[g.ax[a]] * (double)g.inv_h) + 1.0;
             if (dd > 1048576.0) dd = 1048576.0;
             g.dim[a] = (int)dd;
             tot *= dd;
@@ -176,7 +182,11 @@ k_grid_params(const float* __restrict__ blk, int nblk, unsigned int n, float ppc
         hcell *= 1.26;
     }
     if ((double)g.dim[0] * g.dim[1] * g.dim[2] > (double)nc_cap) { g.dim[0] = g.dim[1] = g.dim[2] = 1; }  // cannot happen; stay in bounds
-    for (int a = 0; a < 3; ++a) g.org[a] = lo[a];
+    for (int a = 0; a < 3; ++a) {
+        g.org[a] = lo[g.ax[a]];
+        d.glo[a] = d.lo[g.ax[a]];
+        d.ghi[a] = d.hi[g.ax[a]];
+    }
     g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
     d.g = g;
     float far = 0.f;
@@ -193,7 +203,7 @@ int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks) {
     ix->nc_cap = grid_nc_cap(ix->n_orig, ix->opt.grid_ppc);
     // (trimming needs enough rows to tell an outlier from the scene: 128 pack workgroups = 64k points)
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1024), 0, ix->stream, blk_stats_dev, n_blocks, (unsigned int)ix->n_orig,
-                       ppc, ix->nc_cap, n_blocks >= 128 ? trim : 0, ix->d_grid.as<GridDev>(), ix->h_grid);
+                       ppc, ix->nc_cap, n_blocks >= 128 ? trim : 0, ix->opt.grid_axes, ix->d_grid.as<GridDev>(), ix->h_grid);
     PCC_HIP(hipGetLastError());
     ix->info_pending = true;
     return PCC_OK;
@@ -294,10 +304,11 @@ __device__ __forceinline__ unsigned long long scan_ball_outside(const float4* __
                                                                 const GridParams& g, float slack, int x0, int x1, int y0,
                                                                 int y1, int z0, int z1, int cx0, int cx1, int cy0, int cy1,
                                                                 int cz0, int cz1, float qx, float qy, float qz,
-                                                                unsigned long long best) {
+                                                                float ux, float uy, float uz, unsigned long long best) {
+    // (qx, qy, qz): the query, for the distances; (ux, uy, uz): the same point in the grid's frame, for the cells
     for (int z = z0; z <= z1; ++z) {
-        const float gz = fmaxf(fmaxf((z == 0 ? -__builtin_inff() : g.org[2] + z * g.h) - qz,
-                                     qz - (z == g.dim[2] - 1 ? __builtin_inff() : g.org[2] + (z + 1) * g.h)) - slack, 0.f);
+        const float gz = fmaxf(fmaxf((z == 0 ? -__builtin_inff() : g.org[2] + z * g.h) - uz,
+                                     uz - (z == g.dim[2] - 1 ? __builtin_inff() : g.org[2] + (z + 1) * g.h)) - slack, 0.f);
         for (int yb = y0; yb <= y1; yb += 4) {
             unsigned int as[4], ae[4], bs[4], be[4];  // per row: the part left of the cube (or the whole chord), the part right of it
             const float bd = __uint_as_float((unsigned int)(best >> 32));
@@ -306,12 +317,12 @@ __device__ __forceinline__ unsigned long long scan_ball_outside(const float4* __
                 const int y = yb + i;
                 as[i] = ae[i] = bs[i] = be[i] = 0u;
                 if (y > y1) continue;
-                const float gy = fmaxf(fmaxf((y == 0 ? -__builtin_inff() : g.org[1] + y * g.h) - qy,
-                                             qy - (y == g.dim[1] - 1 ? __builtin_inff() : g.org[1] + (y + 1) * g.h)) - slack, 0.f);
+                const float gy = fmaxf(fmaxf((y == 0 ? -__builtin_inff() : g.org[1] + y * g.h) - uy,
+                                             uy - (y == g.dim[1] - 1 ? __builtin_inff() : g.org[1] + (y + 1) * g.h)) - slack, 0.f);
                 const float rem = bd - (gy * gy + gz * gz) * 0.9999f;
                 if (!(rem >= 0.f)) continue;
                 int xa, xb;
-                cell_range(qx, sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
+                cell_range(ux, sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
                 xa = max(xa, x0);
                 xb = min(xb, x1);
                 if (xa > xb) continue;
@@ -351,9 +362,11 @@ __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs,
         const unsigned long long pk = out[qi];
         if (pk != ~0ull) best = fold(best, qx, qy, qz, warm_refs[(unsigned int)pk]);
     }
-    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    float ux, uy, uz;  // the query in the grid's frame: everything about CELLS below; the distances take (qx, qy, qz)
+    grid_frame(g, qx, qy, qz, ux, uy, uz);
+    const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
     // ---- phase 1b: nothing within the 3x3x3 cube -> double the cube until a point shows up
     bool give_up = false, done = false;
     int k = 1;
@@ -370,7 +383,7 @@ __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs,
     // far fewer rows than the next bigger cube.  Exact by construction: no bound test after it.
     if (!give_up) {
         // (the ball cut down to what the cloud's bounding box leaves of it: grid_device.hpp)
-        const BallBox bb = ball_box(qx, qy, qz, __uint_as_float((unsigned int)(best >> 32)), gd, g, slack);
+        const BallBox bb = ball_box(ux, uy, uz, __uint_as_float((unsigned int)(best >> 32)), gd, g, slack);
         const int x0 = bb.x0, x1 = bb.x1, y0 = bb.y0, y1 = bb.y1, z0 = bb.z0, z1 = bb.z1;
         const int span = 2 * GRID_KMAX + 1;
         if (!bb.finite || x1 - x0 >= span || y1 - y0 >= span || z1 - z0 >= span) {
@@ -379,7 +392,7 @@ __device__ __forceinline__ void nn1_finish(const float4* __restrict__ cell_refs,
             // the cube of half-width k around the query's cell is done (phase 1, or the last doubling)
             if (ball) best = scan_ball_outside<U>(cell_refs, cell_start, g, slack, x0, x1, y0, y1, z0, z1, max(cx - k, 0),
                                         min(cx + k, g.dim[0] - 1), max(cy - k, 0), min(cy + k, g.dim[1] - 1),
-                                        max(cz - k, 0), min(cz + k, g.dim[2] - 1), qx, qy, qz, best);
+                                        max(cz - k, 0), min(cz + k, g.dim[2] - 1), qx, qy, qz, ux, uy, uz, best);
             else best = scan_box<U>(cell_refs, cell_start, g, x0, x1, y0, y1, z0, z1, qx, qy, qz, best);
             done = true;
         }
@@ -427,9 +440,11 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     if (t < ns) { qi = order ? order[t] : t; qv = q[qi]; }
     const bool active = __float_as_int(qv.w) >= 0;
     float qx = qv.x, qy = qv.y, qz = qv.z;
-    int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-    int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-    int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    float ux, uy, uz;  // the query in the grid's frame (cells, gaps); distances take (qx, qy, qz)
+    grid_frame(g, qx, qy, qz, ux, uy, uz);
+    int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+    int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+    int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long best = ~0ull;  // (d2 bits << 32) | original index: u64 min == (d2, idx) lexicographic
     bool resolved = false;
     // ---- phase 1: the 3x3x3 cube.  Bounds of all 9 rows first (9 independent 16-byte loads, one latency), then the
@@ -462,9 +477,9 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         // at ~60 candidates instead of 230, and so does a lane NEXT to one once its first full row has given it a
         // bound.  C2 140 -> 121 us, C3 1290 -> 1070 us; uniform clouds unchanged.
         const float fx = g.org[0] + cx * g.h, fy = g.org[1] + cy * g.h, fz = g.org[2] + cz * g.h;
-        const float gxl = fmaxf((qx - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - qx) - slack, 0.f);
-        const float gyl = fmaxf((qy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - qy) - slack, 0.f);
-        const float gzl = fmaxf((qz - fz) - slack, 0.f), gzr = fmaxf(((fz + g.h) - qz) - slack, 0.f);
+        const float gxl = fmaxf((ux - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - ux) - slack, 0.f);
+        const float gyl = fmaxf((uy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - uy) - slack, 0.f);
+        const float gzl = fmaxf((uz - fz) - slack, 0.f), gzr = fmaxf(((fz + g.h) - uz) - slack, 0.f);
         const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
         const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
         const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
@@ -499,7 +514,7 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
         const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
         const float bd = __uint_as_float((unsigned int)(best >> 32));
-        const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+        const float lb2 = outside_bound2(ux, uy, uz, x0, x1, y0, y1, z0, z1, g, slack);
         if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
     }
     // The lanes phase 1 leaves open (about one in ten in sparse regions, spread over every wave) used to be finished
@@ -709,9 +724,11 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
         q_rw[qi] = qv;
     }
     const float qx = qv.x, qy = qv.y, qz = qv.z;
-    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    float ux, uy, uz;  // the query in the grid's frame (cells, gaps); the drain's distances take fw.q = (qx, qy, qz)
+    grid_frame(g, qx, qy, qz, ux, uy, uz);
+    const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
     fw.q[lane] = make_float4(qx, qy, qz, __uint_as_float(0xffffffffu));
     fw.best[lane] = ~0ull;
     flat_sync();
@@ -722,9 +739,9 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
         const bool shifted = cx == 0;
         const bool has_right = cx + 1 < g.dim[0];
         const float fx = g.org[0] + cx * g.h, fy = g.org[1] + cy * g.h, fz = g.org[2] + cz * g.h;
-        const float gxl = fmaxf((qx - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - qx) - slack, 0.f);
-        const float gyl = fmaxf((qy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - qy) - slack, 0.f);
-        const float gzl = fmaxf((qz - fz) - slack, 0.f), gzr = fmaxf(((fz + g.h) - qz) - slack, 0.f);
+        const float gxl = fmaxf((ux - fx) - slack, 0.f), gxr = fmaxf(((fx + g.h) - ux) - slack, 0.f);
+        const float gyl = fmaxf((uy - fy) - slack, 0.f), gyr = fmaxf(((fy + g.h) - uy) - slack, 0.f);
+        const float gzl = fmaxf((uz - fz) - slack, 0.f), gzr = fmaxf(((fz + g.h) - uz) - slack, 0.f);
         const float gxl2 = gxl * gxl * 0.9999f, gxr2 = gxr * gxr * 0.9999f;
         const float gy2[3] = {gyl * gyl * 0.9999f, 0.f, gyr * gyr * 0.9999f};
         const float gz2[3] = {gzl * gzl * 0.9999f, 0.f, gzr * gzr * 0.9999f};
@@ -790,7 +807,7 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
             const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
             const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
             const float bd = __uint_as_float((unsigned int)(best >> 32));
-            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+            const float lb2 = outside_bound2(ux, uy, uz, x0, x1, y0, y1, z0, z1, g, slack);
             if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
             if (PCC_ABLATE & 8) resolved = true;
         }
@@ -903,19 +920,21 @@ k_nn1_open_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
             const unsigned long long pk = out[qi];
             if (pk != ~0ull) key = fold(key, qx, qy, qz, warm_refs[(unsigned int)pk]);
         }
+        float ux, uy, uz;  // the query in the grid's frame (cells, gaps, chords); distances take (qx, qy, qz)
+        grid_frame(g, qx, qy, qz, ux, uy, uz);
         int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
         float ex2 = 0.f;
         bool flat = valid && key != ~0ull;
         if (flat) {
-            const BallBox bb = ball_box(qx, qy, qz, __uint_as_float((unsigned int)(key >> 32)), gd, g, slack);
+            const BallBox bb = ball_box(ux, uy, uz, __uint_as_float((unsigned int)(key >> 32)), gd, g, slack);
             x0 = bb.x0; x1 = bb.x1; y0 = bb.y0; y1 = bb.y1; z0 = bb.z0; z1 = bb.z1;
             ex2 = bb.ex2;
             const int span = 2 * GRID_KMAX + 1;  // (beyond it the lane walk hands the query to the far list)
             flat = bb.finite && x1 - x0 < span && y1 - y0 < span && z1 - z0 < span;
         }
-        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+        const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
         const bool cube_done = true;  // (every listed query comes from k_grid_nn1_flat2, which has scanned the cube around its cell)
         const int ny = flat ? y1 - y0 + 1 : 0, nz = flat ? z1 - z0 + 1 : 0;
         const int max_ny = __builtin_amdgcn_readlane((int)wave_incl_scan_max((unsigned int)ny), 63);
@@ -933,12 +952,12 @@ k_nn1_open_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
                 float gy2[OPEN_NY], gz2[OPEN_NZ];
 #pragma unroll
                 for (int a = 0; a < OPEN_NY; ++a) {
-                    const float gy = axis_gap(qy, min(y0 + yb + a, g.dim[1] - 1), g.dim[1], g.org[1], g.h, slack);
+                    const float gy = axis_gap(uy, min(y0 + yb + a, g.dim[1] - 1), g.dim[1], g.org[1], g.h, slack);
                     gy2[a] = yb + a < ny ? gy * gy : __builtin_inff();  // (+inf: a row the lane does not have)
                 }
 #pragma unroll
                 for (int a = 0; a < OPEN_NZ; ++a) {
-                    const float gz = axis_gap(qz, min(z0 + zb + a, g.dim[2] - 1), g.dim[2], g.org[2], g.h, slack);
+                    const float gz = axis_gap(uz, min(z0 + zb + a, g.dim[2] - 1), g.dim[2], g.org[2], g.h, slack);
                     gz2[a] = zb + a < nz ? gz * gz : __builtin_inff();
                 }
                 bool iny[OPEN_NY], inz[OPEN_NZ];  // the row runs through the cube around the query's cell
@@ -955,7 +974,7 @@ k_nn1_open_flat(const float4* __restrict__ cell_refs, const unsigned int* __rest
                     // (else every reference of the row is strictly farther than the best: the chord does not reach the
                     // cloud's bounding box, let alone the row; -inf for rows the lane does not have)
                     ok[r] = rem >= ex2;
-                    cell_range(qx, __builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa[r], xb[r]);
+                    cell_range(ux, __builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa[r], xb[r]);
                     xa[r] = max(xa[r], x0);
                     xb[r] = min(xb[r], x1);
                     // a row through the 3x3x3 cube the search kernel has dealt with (what it skipped there was farther than its
@@ -1033,15 +1052,17 @@ k_grid_far(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
         const unsigned int qi = list[t];
         const float4 qv = q[qi];
         const float qx = qv.x, qy = qv.y, qz = qv.z;
+        float ux, uy, uz;  // the query in the grid's frame (cells, gaps, chords); distances take (qx, qy, qz)
+        grid_frame(g, qx, qy, qz, ux, uy, uz);
         unsigned long long best = out[qi];  // from the seed scan: a real point, hence a valid upper bound
         bool exhaustive = best == ~0ull;
-        const float exg = fmaxf(fmaxf(gd->lo[0] - qx, qx - gd->hi[0]) - slack, 0.f);  // gap to the cloud's bounding box along x
+        const float exg = fmaxf(fmaxf(gd->glo[0] - ux, ux - gd->ghi[0]) - slack, 0.f);  // gap to the cloud's bounding box along the rows
         const float ex2 = exg * exg * 0.9999f;
         const float rb0 = sqrtf(__uint_as_float((unsigned int)(best >> 32))) * 1.00001f + slack;
         if (!exhaustive && !(rb0 * g.inv_h < (float)FAR_SPAN)) exhaustive = true;  // ball too large for a cell walk
         if (!exhaustive) {
-            const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-            const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+            const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+            const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
             const int rho_max = max(max(cy, g.dim[1] - 1 - cy), max(cz, g.dim[2] - 1 - cz));
             for (int rho = 0; rho <= rho_max; ++rho) {
                 const float bd = __uint_as_float((unsigned int)(best >> 32));
@@ -1059,13 +1080,13 @@ k_grid_far(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
                     else { dy = rho; dz = r - 2 * (2 * rho + 1) - (2 * rho - 1) - rho + 1; }
                     const int y = cy + dy, z = cz + dz;
                     if (y < 0 || y >= g.dim[1] || z < 0 || z >= g.dim[2]) continue;
-                    const float gy = axis_gap(qy, y, g.dim[1], g.org[1], g.h, slack), gz = axis_gap(qz, z, g.dim[2], g.org[2], g.h, slack);
+                    const float gy = axis_gap(uy, y, g.dim[1], g.org[1], g.h, slack), gz = axis_gap(uz, z, g.dim[2], g.org[2], g.h, slack);
                     const float lbd = __uint_as_float((unsigned int)(best >> 32));
                     const float rem = lbd * 1.00002f - (gz * gz + gy * gy);
                     // the whole row is at least as far as the current best -- or its chord ends short of the cloud's bounding box
                     if (!(rem > 0.f) || rem < ex2) continue;
                     int rx0, rx1;
-                    cell_range(qx, sqrtf(rem) + slack, g.org[0], g.inv_h, g.dim[0], rx0, rx1);
+                    cell_range(ux, sqrtf(rem) + slack, g.org[0], g.inv_h, g.dim[0], rx0, rx1);
                     const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
                     best = scan_span<U>(cell_refs, cell_start[row + rx0], cell_start[row + rx1 + 1], qx, qy, qz, best);
                 }
@@ -1147,7 +1168,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     }
     ev_mark(ix, EV_MAIN0);
     const int BS = 256;  // 128 and 512 measured 9-12 % slower (fewer lanes to pack / longer wait at the barrier)
-    const unsigned int xcd_run = 16;  // consecutive workgroups per XCD (see k_grid_nn1)
+    const unsigned int xcd_run = (unsigned int)ix->opt.xcd_run;  // consecutive workgroups per XCD (see k_grid_nn1; PCC_OPT_XCD_RUN)
     // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
     // phase 2 as the ball outside the finished cube, except in ICP passes: while the source is still misaligned the
     // balls are several cells wide and the per-row chord arithmetic costs more than the rows it drops
@@ -1179,7 +1200,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
             open_keys = reinterpret_cast<unsigned long long*>(ix->scratch_f.as<char>() + ((list_cap * 4 + 15) & ~(size_t)15));
         }
 #define PCC_F2_ARGS ix->cell_refs.as<float4>(), ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list, \
-                               fb_count, xcd_run * 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr, dm, open_list, open_keys, open_total, pre_T, \
+                               fb_count, xcd_run, ball_walk, warm ? ix->refs.as<float4>() : nullptr, dm, open_list, open_keys, open_total, pre_T, \
                                const_cast<float4*>(q)
         ix->open_pending = listed;
         if (!listed) ix->stats[7] = 0;
@@ -1204,7 +1225,7 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     if (form == 0)
         hipLaunchKernelGGL(k_grid_nn1<4>, dim3((n + BS - 1) / BS), dim3(BS), 0, s, ix->cell_refs.as<float4>(),
                            ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, n, out, fb_list,
-                           fb_count, xcd_run, ball_walk, warm ? ix->refs.as<float4>() : nullptr);
+                           fb_count, (xcd_run + 1) / 2, ball_walk, warm ? ix->refs.as<float4>() : nullptr);
     PCC_HIP(hipGetLastError());
     ev_mark(ix, EV_MAIN1);
     // queries the cell walk could not resolve.  When an earlier search on this index had such

@@ -12,10 +12,22 @@ __device__ __forceinline__ int cell_coord(float v, float org, float inv_h, int d
     float t = fminf(fmaxf((v - org) * inv_h, 0.f), (float)(dim - 1));
     return (int)t;
 }
+// A point's coordinates along the GRID's axes: axis 0 runs along the cells of a row (fastest in the linear cell id), axis 1
+// over the rows of a layer, axis 2 over the layers.  Which coordinate of the cloud each of them follows is chosen per index
+// from the extents of the cloud (GridParams::ax, k_grid_params) -- the cell arithmetic of every kernel works in this frame
+// (ux, uy, uz; cells cx, cy, cz), the DISTANCES stay in the cloud's own (x, y, z): their bits depend on the order of the sum.
+__device__ __forceinline__ float axis_pick(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
+__device__ __forceinline__ void grid_frame(const GridParams& g, float x, float y, float z, float& ux, float& uy, float& uz) {
+    ux = axis_pick(g.ax[0], x, y, z);
+    uy = axis_pick(g.ax[1], x, y, z);
+    uz = axis_pick(g.ax[2], x, y, z);
+}
 __device__ __forceinline__ unsigned int cell_id(const float4& v, const GridParams& g) {
-    int cx = cell_coord(v.x, g.org[0], g.inv_h, g.dim[0]);
-    int cy = cell_coord(v.y, g.org[1], g.inv_h, g.dim[1]);
-    int cz = cell_coord(v.z, g.org[2], g.inv_h, g.dim[2]);
+    float ux, uy, uz;
+    grid_frame(g, v.x, v.y, v.z, ux, uy, uz);
+    int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+    int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+    int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
     return ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
 }
 
@@ -73,7 +85,7 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, const float
 }
 
 // lower bound (squared, shrunk) of the distance from q to any point outside the cell cube
-// [x0..x1] x [y0..y1] x [z0..z1]; +inf when the cube covers the whole grid
+// [x0..x1] x [y0..y1] x [z0..z1]; +inf when the cube covers the whole grid.  (qx, qy, qz): the query in the GRID's frame
 __device__ __forceinline__ float outside_bound2(float qx, float qy, float qz, int x0, int x1, int y0,
                                                 int y1, int z0, int z1, const GridParams& g, float slack) {
     float lb = __builtin_inff();
@@ -105,6 +117,7 @@ __device__ __forceinline__ void cell_range(float v, float r, float org, float in
 // one outside it (an ICP source that is still misaligned, 5 % of the C4 cloud for dozens of passes) the box of cells
 // shrinks from (2 d / h)^3 to the few cells of the cap the ball cuts out of the cloud.  Gaps shrunk by the slack and
 // 1e-4 relative, the radius stretched by 1e-5 and the slack: conservative like every other bound here.
+// Everything here is in the GRID's frame (grid_frame): the query as (ux, uy, uz), the box as GridDev::glo / ghi.
 struct BallBox {
     int x0, x1, y0, y1, z0, z1;
     float ex2, ey2, ez2;  // squared (shrunk) gaps from q to the cloud's bounding box, per axis
@@ -113,9 +126,9 @@ struct BallBox {
 __device__ __forceinline__ BallBox ball_box(float qx, float qy, float qz, float bd, const GridDev* __restrict__ gd, const GridParams& g,
                                             float slack) {
     BallBox b;
-    const float ex = fmaxf(fmaxf(gd->lo[0] - qx, qx - gd->hi[0]) - slack, 0.f);
-    const float ey = fmaxf(fmaxf(gd->lo[1] - qy, qy - gd->hi[1]) - slack, 0.f);
-    const float ez = fmaxf(fmaxf(gd->lo[2] - qz, qz - gd->hi[2]) - slack, 0.f);
+    const float ex = fmaxf(fmaxf(gd->glo[0] - qx, qx - gd->ghi[0]) - slack, 0.f);
+    const float ey = fmaxf(fmaxf(gd->glo[1] - qy, qy - gd->ghi[1]) - slack, 0.f);
+    const float ez = fmaxf(fmaxf(gd->glo[2] - qz, qz - gd->ghi[2]) - slack, 0.f);
     b.ex2 = ex * ex * 0.9999f;
     b.ey2 = ey * ey * 0.9999f;
     b.ez2 = ez * ez * 0.9999f;

@@ -67,9 +67,11 @@ k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
     const unsigned int qi = order[t];
     const float4 qv = q[qi];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
-    const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-    const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-    const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    float ux, uy, uz;  // the query in the grid's frame (grid_device.hpp): cells and bounds; the distances take (qx, qy, qz)
+    grid_frame(g, qx, qy, qz, ux, uy, uz);
+    const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+    const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
     unsigned long long* list = keys + (size_t)qi * K;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;  // k clamped to the valid points
     int k = 1;
@@ -84,7 +86,7 @@ k_grid_knn(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
                 const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
                 knn_scan_span(cell_refs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, list, K, worst);
             }
-        const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+        const float lb2 = outside_bound2(ux, uy, uz, x0, x1, y0, y1, z0, z1, g, slack);
         const unsigned long long kth = list[want - 1];
         if (lb2 == __builtin_inff()) break;  // whole grid scanned
         if (kth != ~0ull && __uint_as_float((unsigned int)(kth >> 32)) < lb2) break;
@@ -210,9 +212,11 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
         const float qx = qv.x, qy = qv.y, qz = qv.z;
-        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+        float ux, uy, uz;  // the query in the grid's frame (grid_device.hpp): cells and bounds; the distances take (qx, qy, qz)
+        grid_frame(g, qx, qy, qz, ux, uy, uz);
+        const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
         // first pass: the smallest cube that holds at least 2 x `want` points (its K-th key is then an upper
         // bound); the second pass covers what the ball of that bound adds around the cube.  Every pass scans
         // its box MINUS the box already scanned, so no point is seen twice and nothing is rescanned.
@@ -357,14 +361,14 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
             bool go_whole = false;
             if (tau != ~0ull) {
                 const float td = __uint_as_float((unsigned int)(tau >> 32));
-                const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+                const float lb2 = outside_bound2(ux, uy, uz, x0, x1, y0, y1, z0, z1, g, slack);
                 if (td < lb2) break;  // nothing outside the scanned box can beat the K-th key
                 // cover the ball of the bound (plus what is scanned already, so the subtraction stays a box)
                 const float rb = sqrtf(td) * 1.00001f + slack;
                 int a0, a1, b0, b1, c0, c1;
-                cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
-                cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
-                cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], c0, c1);
+                cell_range(ux, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
+                cell_range(uy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
+                cell_range(uz, rb, g.org[2], g.inv_h, g.dim[2], c0, c1);
                 x0 = min(x0, a0); x1 = max(x1, a1); y0 = min(y0, b0); y1 = max(y1, b1); z0 = min(z0, c0); z1 = max(z1, c1);
                 ball_pass = rb < __builtin_inff();
                 go_whole = !ball_pass;
@@ -546,9 +550,11 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
         const float qx = qv.x, qy = qv.y, qz = qv.z;
-        const int cx = cell_coord(qx, g.org[0], g.inv_h, g.dim[0]);
-        const int cy = cell_coord(qy, g.org[1], g.inv_h, g.dim[1]);
-        const int cz = cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+        float ux, uy, uz;  // the query in the grid's frame (grid_device.hpp): cells and bounds; the distances take (qx, qy, qz)
+        grid_frame(g, qx, qy, qz, ux, uy, uz);
+        const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
         auto give_up = [&]() {
             if (lane == 0) fb_list[atomicAdd(fb_count, 1u)] = qi;
         };
@@ -727,14 +733,14 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 wave_lds_sync();
             }
             // ---- pass 2: what the ball of the bound holds outside the cube
-            const float lb2 = outside_bound2(qx, qy, qz, x0, x1, y0, y1, z0, z1, g, slack);
+            const float lb2 = outside_bound2(ux, uy, uz, x0, x1, y0, y1, z0, z1, g, slack);
             bool fits = true;
             if (!(bound < lb2)) {
                 const float rb = sqrtf(bound) * 1.00001f + slack;
                 int a0, a1, b0, b1, e0, e1;
-                cell_range(qx, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
-                cell_range(qy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
-                cell_range(qz, rb, g.org[2], g.inv_h, g.dim[2], e0, e1);
+                cell_range(ux, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
+                cell_range(uy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
+                cell_range(uz, rb, g.org[2], g.inv_h, g.dim[2], e0, e1);
                 ix0 = x0; ix1 = x1; iy0 = y0; iy1 = y1; iz0 = z0; iz1 = z1;
                 x0 = min(x0, a0); x1 = max(x1, a1); y0 = min(y0, b0); y1 = max(y1, b1); z0 = min(z0, e0); z1 = max(z1, e1);
                 if ((y1 - y0 + 1) * (z1 - z0 + 1) > ROWCAP) fits = false;
@@ -880,11 +886,13 @@ k_grid_radius(const float4* __restrict__ cell_refs, const unsigned int* __restri
     const unsigned int qi = order[t];
     const float4 qv = q[qi];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
+    float ux, uy, uz;  // the query in the grid's frame: cells; the distances take (qx, qy, qz)
+    grid_frame(g, qx, qy, qz, ux, uy, uz);
     int x0, x1, y0, y1, z0, z1;
     const float rr = r + slack;  // cells that can hold a point within r (conservative)
-    cell_range(qx, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
-    cell_range(qy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
-    cell_range(qz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
+    cell_range(ux, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
+    cell_range(uy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
+    cell_range(uz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
     unsigned int cnt = 0;
     unsigned long long* row_out = FILL ? keys + offsets[qi] : nullptr;
     for (int z = z0; z <= z1; ++z)
@@ -921,9 +929,11 @@ k_grid_first_within(const float4* __restrict__ cell_refs, const unsigned int* __
     const float4 qv = q[qi];
     int x0, x1, y0, y1, z0, z1;
     const float rr = (float)radius * 1.000001f + slack;
-    cell_range(qv.x, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
-    cell_range(qv.y, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
-    cell_range(qv.z, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
+    float ux, uy, uz;  // the query in the grid's frame
+    grid_frame(g, qv.x, qv.y, qv.z, ux, uy, uz);
+    cell_range(ux, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
+    cell_range(uy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
+    cell_range(uz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
     unsigned int first = 0xffffffffu;
     for (int z = z0; z <= z1; ++z)
         for (int y = y0; y <= y1; ++y) {
@@ -1102,9 +1112,11 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
         }
         int x0, x1, y0, y1, z0, z1;
         const float rr = r + slack;
-        cell_range(qx, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
-        cell_range(qy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
-        cell_range(qz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
+        float ux, uy, uz;  // this turn's query in the grid's frame: cells, gaps, chords; the distances take (qx, qy, qz)
+        grid_frame(g, qx, qy, qz, ux, uy, uz);
+        cell_range(ux, rr, g.org[0], g.inv_h, g.dim[0], x0, x1);
+        cell_range(uy, rr, g.org[1], g.inv_h, g.dim[1], y0, y1);
+        cell_range(uz, rr, g.org[2], g.inv_h, g.dim[2], z0, z1);
         const unsigned int row_len = (unsigned int)(row_end - row_beg);
         const bool in_lds = fused && row_len <= ROW_LDS_MAX;
         if (fused && !in_lds && lane == 0) long_list[atomicAdd(long_count, 1u)] = qi;  // left as keys for k_sort_rows
@@ -1127,7 +1139,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 const float rem = rr * rr - g2sum * 0.9999f;
                 if (valid && rem >= 0.f) {
                     int xa, xb;
-                    cell_range(qx, __builtin_amdgcn_sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
+                    cell_range(ux, __builtin_amdgcn_sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
                     xa = max(xa, x0);
                     xb = min(xb, x1);
                     if (xa <= xb) {
@@ -1163,7 +1175,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 // axis each, so lanes 0-7 work out the y gaps, lanes 8-15 the z gaps -- one evaluation -- and every lane
                 // picks up its two (ds_bpermute).  Same values, same row order as the general form below.
                 const bool zlane = (lane & 8u) != 0u;
-                const float gp = gap_of(zlane ? qz : qy, (zlane ? z0 : y0) + (int)(lane & 7u), zlane ? g.dim[2] : g.dim[1],
+                const float gp = gap_of(zlane ? uz : uy, (zlane ? z0 : y0) + (int)(lane & 7u), zlane ? g.dim[2] : g.dim[1],
                                         zlane ? g.org[2] : g.org[1]);
                 const int g2 = __float_as_int(gp * gp);
                 const float gy2 = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane & 7u) << 2), g2));
@@ -1177,7 +1189,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 const int rr_i = base + (int)lane;
                 const int rrow = rbase + rr_i;
                 const int z = z0 + rrow / ny, y = y0 + rrow % ny;
-                const float gy = gap_of(qy, y, g.dim[1], g.org[1]), gz = gap_of(qz, z, g.dim[2], g.org[2]);
+                const float gy = gap_of(uy, y, g.dim[1], g.org[1]), gz = gap_of(uz, z, g.dim[2], g.org[2]);
                 unsigned int s0, cnt;
                 span_of(rr_i < rchunk, y, z, gy * gy + gz * gz, s0, cnt);
                 record(s0, cnt);

@@ -59,17 +59,37 @@ struct HostBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// Uniform-grid parameters (device + host copy).  Cell of a point:
-//   c_a = clamp(int((p_a - org_a) * inv_h), 0, dim_a - 1)
-// The same expression (same rounding) is used at build and query time.
+// Uniform-grid parameters (device + host copy).  Cell of a point along GRID axis a (0: the cells of a row, fastest in the
+// linear id (c2 * dim1 + c1) * dim0 + c0; 1: the rows of a layer; 2: the layers):
+//   c_a = clamp(int((p[ax_a] - org_a) * inv_h), 0, dim_a - 1)
+// The same expression (same rounding) is used at build and query time.  ax[] names the coordinate of the cloud (0 x, 1 y, 2 z)
+// each grid axis follows: k_grid_params puts the cloud's SHORTEST extent on axis 1 and the longest on axis 2, so that the rows
+// above / below and the layers before / behind a query's row lie as close to it in memory as the cloud allows.
 struct GridParams {
-    float org[3];
+    float org[3];  // grid axes
     float h;
     float inv_h;
-    int dim[3];
+    int dim[3];    // grid axes
     int ncells;
+    int ax[3];     // grid axis -> coordinate of the cloud
 };
 
+
+// The rule behind GridParams::ax (one place: k_grid_params on the device, the clustering grid on the host): the coordinate
+// with the second shortest extent runs along the rows, the shortest over the rows of a layer, the longest over the layers;
+// ties keep x, y, z order.  forced 0..5 = xyz, xzy, yxz, yzx, zxy, zyx (PCC_OPT_GRID_AXES), anything else: by extent.
+__host__ __device__ inline void grid_axes_for(const float ext[3], int forced, int ax[3]) {
+    int o[3] = {0, 1, 2};  // coordinates by ascending extent (stable)
+    for (int i = 1; i < 3; ++i)
+        for (int j = i; j > 0 && ext[o[j]] < ext[o[j - 1]]; --j) { const int t = o[j]; o[j] = o[j - 1]; o[j - 1] = t; }
+    ax[0] = o[1]; ax[1] = o[0]; ax[2] = o[2];
+    if (forced >= 0 && forced < 6) {
+        ax[0] = forced >> 1;                          // 0 0 1 1 2 2
+        const int r0 = ax[0] == 0 ? 1 : 0, r1 = ax[0] == 2 ? 1 : 2;  // the other two, ascending
+        ax[1] = (forced & 1) ? r1 : r0;
+        ax[2] = (forced & 1) ? r0 : r1;
+    }
+}
 
 // Device-resident description of the grid, written by k_grid_params from the pack kernel's
 // per-workgroup statistics.  The host never waits for it on the build path: launches are sized
@@ -79,7 +99,8 @@ struct GridDev {
     float slack;            // absolute slack of the outside-of-cube bound (cell-boundary rounding)
     unsigned int n_valid;   // finite points (PCL total_nr_points_)
     unsigned int n_invalid;
-    float lo[3], hi[3];     // bounding box of the valid points
+    float lo[3], hi[3];     // bounding box of the valid points (x, y, z: what the handle reports)
+    float glo[3], ghi[3];   // the same box along the grid's axes (ball_box, k_grid_far)
     unsigned int voxel;     // 1: cells are PCL VoxelGrid voxels -- id from floor(v*inv_h) - org (org = float(min_b))
 };
 
@@ -108,6 +129,9 @@ struct Options {
     int sort_stage1 = 1;            // PCC_OPT_SORT_STAGE1: level 1 of the three-level sort writes bucket-sorted LDS tiles (1: reference points; 2: query pairs too; 0: one store per point)
     int nn1_open_flat = 1;          // PCC_OPT_NN1_OPEN_FLAT: the listed open lanes drained flat (k_nn1_open_flat); 0 = one lane per query
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
+    int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
+                                    // shortest, shortest, longest); 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
+    int xcd_run = 32;               // PCC_OPT_XCD_RUN: consecutive workgroups of the k = 1 search steered to the same XCD (its L2)
     int overlap_prep = 1;           // PCC_OPT_OVERLAP_PREP: a k = 1 search that follows setInputCloud directly packs and sorts its queries on a
                                     // second stream while the build's cell sort is still running (they share nothing but the grid parameters);
                                     // from 2M queries on, 2 = at every size

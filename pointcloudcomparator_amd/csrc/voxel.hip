@@ -104,6 +104,7 @@ int voxel_grid(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
         const int mn = (int)std::floor(lo[a] * inv), mx = (int)std::floor(hi[a] * inv);
         hd.g.org[a] = (float)mn;
         hd.g.dim[a] = mx - mn + 1;
+        hd.g.ax[a] = a;  // (PCL's voxel index is x fastest, z slowest: the output order depends on it)
         cells *= (double)hd.g.dim[a];
     }
     if (cells > (double)VOX_MAX_CELLS) {

@@ -1,0 +1,115 @@
+"""PCC_OPT_GRID_AXES: which coordinate of the cloud the grid's axes (along a row of cells, over the rows of a layer, over the
+layers) follow.  By default the index picks them from the cloud's extents (second shortest, shortest, longest); 0..5 force one
+of the six assignments, 0 being the x / y / z layout of rounds 1-5.  The layout decides where a cell's neighbours lie in memory
+and nothing else: every search must return the oracle's bits under all six -- the kd-tree it stands in for has no such notion
+(reference src/comparator.cpp:564-577, src/segmentation.cpp:120-131)."""
+import numpy as np
+import pytest
+
+import oracle
+from pointcloudcomparator_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+AXES = [-1, 0, 1, 2, 3, 4, 5]
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32)
+
+
+def _slab(n, seed, ext):
+    """uniform points in a box of the given extents, shifted off the origin"""
+    rng = np.random.default_rng(seed)
+    return (rng.random((n, 3)) * np.asarray(ext) + np.asarray([-3.0, 7.0, 0.5])).astype(np.float32)
+
+
+def _scenes():
+    out = [("corridor", synth.corridor_cloud(50000, synth.SEED_A), synth.corridor_cloud(15000, synth.SEED_B))]
+    # every ranking of the three extents, so that "by extent" lands on each of the six assignments once
+    for k, ext in enumerate([(8, 2, 0.5), (8, 0.5, 2), (2, 8, 0.5), (0.5, 8, 2), (2, 0.5, 8), (0.5, 2, 8)]):
+        q = _slab(9000, 200 + k, ext)
+        q[:1500] += np.float32([0.7, -0.9, 0.4])  # a part of the queries outside the cloud: open lanes, far walk
+        out.append((f"slab{k}", _slab(40000, 100 + k, ext), q))
+    flat = _slab(30000, 7, (3, 5, 0))            # a plane: one extent is zero (a grid of one layer)
+    out.append(("plane", flat, _slab(6000, 8, (3, 5, 0.2))))
+    line = _slab(20000, 9, (0, 0, 4))            # a line: two zero extents
+    out.append(("line", line, _slab(4000, 10, (0.1, 0.1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("axes", AXES)
+def test_nn1_is_exact_under_every_axis_assignment(gpu, axes):
+    for name, ref, qry in _scenes():
+        oi, od = oracle.nn1_exhaustive(ref, qry)
+        with capi.Index(ref, engine=capi.ENGINE_GRID) as ix:
+            ix.set_option(capi.OPT_GRID_AXES, axes)
+            assert ix.get_option(capi.OPT_GRID_AXES) == axes
+            ix.set_input(ref)  # (options that shape the index act at the next set_input)
+            for form in (1, 0, 2):
+                ix.set_option(capi.OPT_NN1_KERNEL, form)
+                for _ in range(2):  # (the second call takes the far route where the first had fallbacks)
+                    idx, d2 = ix.nn1(qry)
+                    assert (_bits(d2) == _bits(od)).all(), (name, axes, form, np.nonzero(_bits(d2) != _bits(od))[0][:5])
+                    assert (idx == oi).all(), (name, axes, form, np.nonzero(idx != oi)[0][:5])
+
+
+@pytest.mark.parametrize("axes", AXES)
+def test_knn_radius_clusters_under_every_axis_assignment(gpu, axes):
+    rng = np.random.default_rng(5)
+    ref = np.concatenate([synth.corridor_cloud(30000, synth.SEED_A, layer="objects"), _slab(6000, 3, (0.6, 4.0, 0.3))])
+    qry = ref[rng.permutation(len(ref))[:3000]] + rng.normal(0, 0.01, (3000, 3)).astype(np.float32)
+    qry[:200] += np.float32(2.5)
+    with capi.Index(ref, engine=capi.ENGINE_GRID) as ix:
+        ix.set_option(capi.OPT_GRID_AXES, axes)
+        ix.set_input(ref)
+        for k in (1, 7, 51, 130):
+            oi, od = oracle.knn_exhaustive(ref, qry, k)
+            idx, d2 = ix.knn(qry, k)
+            assert (_bits(d2) == _bits(od)).all(), (axes, k)
+            assert (idx == oi).all(), (axes, k)
+        tree = oracle.KdTree(ref)
+        for r in (0.03, 0.11):
+            off, idx, d2 = ix.radius_search(qry, r, sorted=True)
+            assert (np.diff(off) == oracle.radius_count_exhaustive(ref, qry, r)).all(), (axes, r)
+            for i in range(0, len(qry), 23):  # rows: PCL's sorted result of the restated kd-tree
+                oi, od = tree.radius(qry[i], r, sorted=True)
+                assert (idx[off[i]:off[i + 1]] == oi).all() and (_bits(d2[off[i]:off[i + 1]]) == _bits(od)).all(), (axes, r, i)
+        fw = ix.first_within(qry, 0.05)
+        assert (fw == oracle.first_within(ref, qry, 0.05)).all(), axes
+        for ec in (3, 1, 0):
+            ix.set_option(capi.OPT_EC_CELLS, ec)
+            labels, ncl, sizes = ix.euclidean_clusters(0.05, 20, 250000)
+            olabels, oncl, osizes = oracle.euclidean_clusters(ref, 0.05, 20, 250000)
+            assert ncl == oncl and list(sizes) == list(osizes), (axes, ec)
+            assert (labels == olabels).all(), (axes, ec)
+
+
+def test_axes_by_extent_is_a_pure_layout_choice_at_a_million(gpu):
+    """1M x 1M corridor (C2's clouds): the default assignment and the x / y / z layout of rounds 1-5 return the same arrays, for
+    k = 1, the ICP loop on one handle and SOR."""
+    torch = pytest.importorskip("torch")
+    n = 1_000_000
+    a = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_A)).cuda()
+    b = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_B)).cuda()
+    res = {}
+    for axes in (-1, 0, 3):
+        with capi.Index(a, engine=capi.ENGINE_GRID) as ix:
+            ix.set_option(capi.OPT_GRID_AXES, axes)
+            ix.set_input(a)
+            idx, d2 = ix.nn1(b)
+            # (the sums of a pass in the CALLER's order: with PCC_OPT_ICP_SORTED = 1 they are added up in cell order, which the
+            # layout changes -- same correspondences, the last bits of a 200k-term double sum may differ)
+            ix.set_option(capi.OPT_ICP_SORTED, 0)
+            T, fit, it, conv = ix.icp_align(b[:200000], max_iter=5, fixed=True)
+            ix.set_option(capi.OPT_ICP_SORTED, 1)
+            T1, fit1, _, _ = ix.icp_align(b[:200000], max_iter=5, fixed=True)
+            assert np.allclose(T1, T, atol=1e-6) and abs(fit1 - fit) <= 1e-9 * fit
+            md, inl, thr, kept = ix.sor(mean_k=20)
+            res[axes] = (idx.cpu().numpy(), d2.cpu().numpy(), np.asarray(T), fit, md, inl, thr, kept)
+    for axes in (0, 3):
+        assert (res[axes][0] == res[-1][0]).all() and (_bits(res[axes][1]) == _bits(res[-1][1])).all()
+        assert (np.asarray(res[axes][2]).view(np.uint32) == np.asarray(res[-1][2]).view(np.uint32)).all()
+        assert res[axes][3] == res[-1][3]
+        assert (_bits(res[axes][4]) == _bits(res[-1][4])).all() and (res[axes][5] == res[-1][5]).all()
+        assert res[axes][6] == res[-1][6] and res[axes][7] == res[-1][7]
