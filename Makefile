@@ -9,6 +9,7 @@ HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -s
 CSRC       := pointcloudcomparator_amd/csrc
 LIBDIR     := pointcloudcomparator_amd/lib
 HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/normals.hip $(CSRC)/region.hip $(CSRC)/sac.hip $(CSRC)/flann_order.hip $(CSRC)/cellsort_mp.hip $(CSRC)/comm.hip)
+HDRS       := $(wildcard $(CSRC)/*.hpp) include/pcc_nn.h
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 
 all: lib oracle hosttest cli prof
@@ -17,7 +18,7 @@ lib: $(LIBDIR)/libpcc_nn.so
 # the profiling build: same sources with the pair counter compiled in (pcc_index_stats[4]); never the timed library
 prof: $(LIBDIR)/libpcc_nn_prof.so
 PROF_OBJS  := $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(HIP_SRCS))
-build/prof/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/libm_f32.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
+build/prof/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) -DPCC_COUNT_PAIRS $(EXTRA_HIPFLAGS) -c $< -o $@
 $(LIBDIR)/libpcc_nn_prof.so: $(PROF_OBJS)
@@ -28,7 +29,7 @@ ubench: build/ubench_valu build/ubench_gather build/ubench_scatter
 hosttest: build/test_host_mirror build/test_lane_ops build/test_report build/test_libm
 cli: build/comparator build/ply_dump build/rgb_segments
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/pcc_internal.hpp $(CSRC)/grid_device.hpp $(CSRC)/uf_device.hpp $(CSRC)/lane_ops.hpp $(CSRC)/plane_fit.hpp $(CSRC)/libm_f32.hpp $(CSRC)/flann_tree.hpp include/pcc_nn.h
+build/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 

@@ -155,6 +155,23 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def pcl_present() -> bool:
+    """is a PCL kd-tree library installed on this box (pkg-config / ldconfig / the usual include directories)?  If it ever is,
+    a C++ harness against the real pcl::KdTreeFLANN is what can pin parity (DESIGN.md 2); until then cpu_baseline.kind = port."""
+    try:
+        for cmd in (["pkg-config", "--exists", "pcl_kdtree"], ["pkg-config", "--exists", "pcl_kdtree-1.7"]):
+            if subprocess.run(cmd, capture_output=True, timeout=10).returncode == 0:
+                return True
+    except Exception:
+        pass
+    try:
+        if "pcl_kdtree" in subprocess.run(["ldconfig", "-p"], capture_output=True, text=True, timeout=10).stdout:
+            return True
+    except Exception:
+        pass
+    return any(Path(d).glob("pcl*/pcl/kdtree/kdtree_flann.h") for d in ("/usr/include", "/usr/local/include", "/opt/include"))
+
+
 def load_pmc_traffic(kernel_key, workload_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json), and whether
     that profile was taken from the kernel sources in this tree."""
@@ -180,6 +197,74 @@ def compact(x):
     if isinstance(x, (list, tuple)):
         return [compact(v) for v in x]
     return x
+
+
+def short_line(out):
+    """the one JSON line: contract keys + roofline / cpu_baseline as flat scalars + every extra leg as {ms, value, ...}"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "query_only_queries_per_sec", "build_ms", "search_call_ms", "query_sort_ms", "fallback_queries",
+            "broadcast_ms", "broadcast_bytes", "per_rank_ms_per_step", "icp")
+    line = {k: out[k] for k in keep if k in out}
+    if "scaling_terms" in out:
+        line["scaling_terms"] = {k: v for k, v in out["scaling_terms"].items() if k != "note"}
+    rf = out.get("roofline")
+    if rf:
+        hbm = rf.get("hbm") or {}
+        flat = {"kernel": rf.get("kernel"), "bound": "hbm", "achieved": hbm.get("achieved", rf.get("achieved")), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": hbm.get("frac", rf.get("frac")), "traffic": rf.get("traffic"), "traffic_stale": rf.get("traffic_stale"),
+                "kernel_ms": rf.get("kernel_ms"), "algorithmic_bytes": hbm.get("algorithmic_bytes")}
+        if rf.get("bound") == "valu" and "hbm" in rf:   # pruned search: the pair arithmetic against the non-FMA fp32 roof beside it
+            flat.update({"pairs_per_launch": rf.get("pairs_per_launch"), "valu_achieved_tops": rf.get("achieved"), "valu_frac": rf.get("frac")})
+        elif rf.get("bound") == "valu":                 # exhaustive engine measured directly: VALU-bound by SURVEY 8d
+            flat.update({"bound": "valu", "achieved": rf.get("achieved"), "peak": VALU_NOFMA_PEAK_TOPS, "unit": "Top/s", "frac": rf.get("frac")})
+        ex = rf.get("exhaustive") or (out.get("exhaustive") or {}).get("roofline")
+        if ex:  # the kernel north_star names (k_nn1_brute), on C2's data or on the measured config
+            flat.update({"exhaustive_kernel": "k_nn1_brute", "exhaustive_kernel_ms": ex.get("kernel_ms"), "exhaustive_achieved_tops": ex.get("achieved"),
+                         "exhaustive_frac": ex.get("frac"), "exhaustive_bit_identical": ex.get("bit_identical_to_grid", (out.get("exhaustive") or {}).get("bit_identical_to_grid"))})
+        cnt = rf.get("counters") or {}
+        for k in ("valu_busy_fraction", "active_lanes_per_valu_instruction", "valu_instructions_per_wave"):
+            if cnt.get(k) is not None:
+                flat["pmc_" + k] = cnt[k]
+        line["roofline"] = flat
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = out["cpu_baseline"]
+    ex = out.get("extra")
+    if ex:
+        e = {}
+        for name in ("c2", "c5_shard", "c5", "c3_weak"):
+            if name in ex:
+                r = ex[name]
+                e[name] = {"ms": r["ms_per_step"], "value": r["value"], "build_ms": r["build_ms"], "kernel_ms": r["roofline"].get("kernel_ms"),
+                           "frac": (r["roofline"].get("hbm") or r["roofline"]).get("frac")}
+        if "c3_clusters" in ex:
+            r = ex["c3_clusters"]
+            e["c3_clusters"] = {"ms": r["ms"], "value": r["points_per_sec"], "clusters": r["clusters"], "ok": r["all_points_clustered"] and r["clusters"] == r["clusters_expected"]}
+        if "c4_icp" in ex:
+            r = ex["c4_icp"]
+            e["c4_icp"] = {"ms": r["ms"], "value": r["nn_queries_per_sec"], "ms_per_pass": r["ms_per_pass"], "nn_kernel_ms_per_pass": r["split_ms_per_pass"]["nn_kernel"],
+                           "frac": ((r.get("roofline") or {}).get("hbm") or {}).get("frac")}
+        if "room" in ex:
+            sc, big = ex["room"]["scan"], ex["room"]["10M"]
+            e["room_scan"] = {"points": sc["points"], "ms": sc["nn1_step_ms"], "value": sc["nn1_queries_per_sec"], "sor_k51_ms": sc.get("sor_k51_ms"),
+                              "clusters_ms": sc.get("clusters_ms"), "clusters_ok": sc.get("clusters") == sc.get("clusters_expected")}
+            e["room_10M"] = {"ms": big["nn1_step_ms"], "value": big["nn1_queries_per_sec"], "kernel_ms": big["nn1_kernel_ms"]}
+        sp = ex.get("scaling_projection")
+        if sp:
+            e["scaling_projection"] = {"kind": "PROJECTION from one GPU (this GPU doing one rank's share), not a multi-GPU measurement", "gpus": list(PROJECTION_G)}
+            for name in ("c3", "c5"):
+                if sp.get(name):
+                    e["scaling_projection"][name] = {"step": [r["projected_speedup_step"] for r in sp[name]["rows"]],
+                                                     "query_only": [r["projected_speedup_query_only"] for r in sp[name]["rows"]],
+                                                     "query_only_ms": [r["query_only_ms"] for r in sp[name]["rows"]]}
+        for name in ("small_calls", "host_path", "c_abi_comm"):
+            if name in ex:
+                e[name] = ex[name]
+        line["extra"] = e
+    line["note"] = ("pruned exact k = 1 search (k_grid_nn1_flat2 + k_nn1_open_flat): roofline = SURVEY 8d bytes (12 B per reference and query, 8 B "
+                    "per result) over the kernels' HIP-event time; `traffic` = FETCH_SIZE x 2 + WRITE_SIZE per call from the committed PMC pass; "
+                    "exhaustive_* = the tiled brute-force kernel north_star names, on C2, against the non-FMA fp32 roof.  Full record: "
+                    "gpurun_out/bench_full.json")
+    return line
 
 
 def main():
@@ -484,10 +569,12 @@ def main():
                 "value": cpu_rate, "unit": "queries/s", "cores": 1, "kind": "port",
                 "sample": f"kd-tree build over all {M} references ({tb_cpu:.3f} s) + first {sample} of {N} queries "
                           f"({tq_cpu:.3f} s), one thread, oracle/pcc_oracle.c (FLANN KDTreeSingleIndex restatement)",
-                "all_cores": {"cores": ncores, "query_only_queries_per_sec": sample / tq_mt},
                 "query_only_queries_per_sec": sample / tq_cpu,
-                "gpu_matches_cpu": {"d2_bits_equal": bool((cd.view(np.uint32) == res_d2[:sample].view(np.uint32)).all()),
-                                    "index_mismatches": int((ci != res_idx[:sample]).sum())}}
+                "all_cores": ncores, "all_cores_query_only_qps": sample / tq_mt,
+                "d2_bits_equal": bool((cd.view(np.uint32) == res_d2[:sample].view(np.uint32)).all()),
+                "index_mismatches": int((ci != res_idx[:sample]).sum()),
+                # real PCL on the GPU box would make this `reference`; probed, never assumed
+                "pcl_found": pcl_present()}
             del kd
         ix.close()
         del ref, qry, idx, d2
@@ -607,6 +694,116 @@ def main():
                 "split_ms_per_pass": {"nn_kernel": tm[0], "far_and_fallback": tm[1], "pass_total_events": tm[2],
                                       "sums_reduce_transform": max(tm[2] - tm[0] - tm[1], 0.0)}}
 
+    # ---- the small-call regime: matchRIFTFeaturesKnn, call site #1 (src/comparator.cpp:560-588) ----------------------------
+    def run_small_calls(sizes=(4, 100, 1000, 18381), c1=10_000):
+        """What the reference does up to 3 x ~100 times per comparison: a tree over `n` descriptors of 128-byte stride in HOST
+        memory, one k = 1 query per descriptor of a second cloud of the same size, matches below 0.05 returned -- through the
+        C-ABI exactly as include/pcc/comparator_nn.hpp calls it (one handle, re-pointed per call: pcc_index_set_input +
+        pcc_match_knn), in both tie modes, microseconds per call; the CPU oracle's per-call time beside it (tree build + queries,
+        one thread).  n = 18 381 is the largest descriptor cloud in the reference's own result file (build/results.txt:15).
+        C1 (10k x 10k XYZ from host memory, pcc_nn1) the same way."""
+        import oracle
+        rng = np.random.default_rng(0x51FF)
+        rows = []
+        ix = capi.Index(np.zeros((4, 32), np.float32), auto_sync=False)
+
+        def per_call(fn, budget_s=0.25, kmin=5, kmax=2000):
+            fn()
+            t0 = time.perf_counter()
+            fn()
+            one = time.perf_counter() - t0
+            k = int(max(kmin, min(kmax, budget_s / max(one, 1e-7))))
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            return (time.perf_counter() - t0) / k * 1e6
+
+        for n in sizes:
+            # descriptor clouds: normalised histograms (the searched first three bins lie in [0, 1], many of them equal)
+            d1 = np.round(rng.random((n, 32), dtype=np.float32) * 16) / np.float32(64)
+            d2_ = d1[rng.permutation(n)] + (rng.random((n, 32), dtype=np.float32) < 0.3) * np.float32(1.0 / 64)
+            d2_ = np.ascontiguousarray(d2_, dtype=np.float32)
+            row = {"n": n}
+            want = oracle.match_rift_knn(d1, d2_)
+            for mode, key in ((capi.TIES_LOWEST_INDEX, "gpu_us"), (capi.TIES_FLANN, "gpu_flann_ties_us")):
+                ix.set_tie_order(mode)
+
+                def call():
+                    ix.set_input(d1)
+                    return ix.match_knn(d2_)
+                got = call()
+                if mode == capi.TIES_FLANN:
+                    row["matches_equal_oracle"] = bool(len(got) == len(want) and (got == want).all())
+                row[key] = per_call(call)
+            row["cpu_oracle_us"] = per_call(lambda: oracle.match_rift_knn(d1, d2_))
+            row["gpu_over_cpu"] = row["gpu_flann_ties_us"] / row["cpu_oracle_us"]
+            rows.append(row)
+        ix.close()
+        # C1: 10k x 10k XYZ, k = 1, host memory in and out
+        a, b = make_cloud(c1, synth.SEED_A, 3), make_cloud(c1, synth.SEED_B, 3)
+        ix = capi.Index(a, auto_sync=False)
+
+        def c1_call():
+            ix.set_input(a)
+            return ix.nn1(b)
+        gi, gd = c1_call()
+        kd = oracle.KdTree(a)
+        ci, cd = kd.nn1_batch(b)
+        c1_row = {"n": c1, "gpu_us": per_call(c1_call),
+                  "cpu_oracle_us": per_call(lambda: oracle.KdTree(a).nn1_batch(b)),
+                  "d2_bits_equal": bool((gd.view(np.uint32) == cd.view(np.uint32)).all()), "index_mismatches": int((gi != ci).sum())}
+        ix.close()
+        return {"what": "us per call from HOST memory through the C-ABI, handle reused (set_input + match_knn / nn1); CPU = oracle "
+                        "kd-tree build + queries, 1 thread", "match_knn_128B": rows, "c1_nn1_10k": c1_row}
+
+    # ---- the path a ./comparator user takes: clouds in HOST memory, results back to HOST memory ---------------------------
+    def run_host_path(cfg="c3", reps=3):
+        """The step of `cfg` with PCC_MEM_HOST inputs and outputs (pageable numpy arrays, as the reference's std::vectors are:
+        src/comparator.cpp:1119,1130 load to host, :571-577 hand vectors over): wall clock per step, beside the device-resident
+        step and the PCIe time of the bytes that have to cross (measured with a pinned copy of the same size in this run)."""
+        M, N, floats, desc = CONFIGS[cfg]
+        ref_h, qry_h = make_cloud(M, synth.SEED_A, floats), make_cloud(N, synth.SEED_B, floats)
+        idx_h, d2_h = np.empty(N, np.int32), np.empty(N, np.float32)
+        ix = capi.Index(ref_h, auto_sync=False)
+
+        def step():
+            ix.set_input(ref_h)
+            ix.nn1(qry_h, idx_h, d2_h)
+        step()
+        best, build, query = 1e9, 1e9, 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ix.set_input(ref_h)
+            ix.sync()
+            t1 = time.perf_counter()
+            ix.nn1(qry_h, idx_h, d2_h)
+            ix.sync()
+            t2 = time.perf_counter()
+            build, query = min(build, t1 - t0), min(query, t2 - t1)
+            t0 = time.perf_counter()
+            step()
+            ix.sync()
+            best = min(best, time.perf_counter() - t0)
+        ix.close()
+        # PCIe: one pinned H2D of the raw cloud's size, one pinned D2H of the results' size
+        pin = torch.empty(M * floats, dtype=torch.float32).pin_memory()
+        dv = torch.empty(M * floats, dtype=torch.float32, device=dev)
+        dv.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dv.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+        h2d = time.perf_counter() - t0
+        pin2 = torch.empty(N * 2, dtype=torch.float32).pin_memory()
+        t0 = time.perf_counter()
+        pin2.copy_(dv[:N * 2], non_blocking=True); torch.cuda.synchronize()
+        d2h = time.perf_counter() - t0
+        raw = M * floats * 4
+        del pin, dv, pin2
+        torch.cuda.empty_cache()
+        return {"workload": f"{desc} from and to HOST memory (pageable)", "step_ms": best * 1e3, "set_input_ms": build * 1e3,
+                "nn1_ms": query * 1e3, "raw_bytes_per_cloud": raw, "pinned_h2d_GBps": raw / h2d / 1e9,
+                "pcie_floor_ms_raw": (2 * h2d + d2h) * 1e3,
+                "pcie_floor_ms_xyz_only": (2 * h2d * 12.0 / (floats * 4) + d2h) * 1e3}
+
     # ---- the measured workload ---------------------------------------------------------------------------------------
     # C3 / C5: a FIXED total of queries sharded over the ranks present (north_star's partition: strong scaling, N = 1 is the
     # whole configuration on one GPU); the other configurations keep their size on every rank (weak)
@@ -654,19 +851,8 @@ def main():
             extra["c3_clusters"] = run_clusters()
             extra["c4_icp"] = run_icp()
             extra["room"] = {"scan": run_room(synth.ROOM_SIZES[1]), "10M": run_room(synth.ROOM_SIZES[2], full=False)}
-            # the other operations of the hot path against the HBM roof on their algorithmic bytes: measured by
-            # tools/ops_roofline.py under rocprofv3, committed as profiles/*_ops_roofline.json (not re-measured here)
-            ops_files = sorted((ROOT / "profiles").glob("*_ops_roofline.json"))
-            if ops_files:
-                try:
-                    ops = json.loads(ops_files[-1].read_text())["operations"]
-                    extra["ops_roofline"] = {"source": "profiles/" + ops_files[-1].name,
-                                             "operations": [{"op": o["op"], "config": o["config"], "call_ms": round(o["call_ms"], 3),
-                                                             "frac_of_hbm": round(o["frac_of_hbm"], 4),
-                                                             "frac_of_valu": round(o["frac_of_valu"], 4) if "frac_of_valu" in o else None}
-                                                            for o in ops]}
-                except Exception:
-                    pass
+            extra["small_calls"] = run_small_calls()
+            extra["host_path"] = {"c3": run_host_path("c3")}
             # what ONE of eight GPUs does in BASELINE configs[4] (a 4M-query shard vs the 8M references)
             shard = run_nn("c5_shard", steps=min(K, 10), warmup=2)
             shard["scaling"] = "one shard of the 8-GPU configuration, measured on one GPU"
@@ -723,7 +909,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(compact(out), separators=(",", ":")))
+        # the full record goes to a file (whoever wants every leg's detail reads it there); the LINE is what the driver keeps --
+        # the contract's keys, flat scalars, one note: under 7 KB
+        full = compact(out)
+        for d in (ROOT / "gpurun_out", Path(os.environ.get("TMPDIR", "/tmp"))):
+            try:
+                d.mkdir(exist_ok=True)
+                (d / "bench_full.json").write_text(json.dumps(full, indent=1))
+                break
+            except Exception:
+                continue
+        print(json.dumps(compact(short_line(out)), separators=(",", ":")))
 
 
 if __name__ == "__main__":

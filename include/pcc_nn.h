@@ -175,8 +175,10 @@ enum pcc_option {
                                     shortest, longest: the rows and layers next to a query's row are then as close to it in memory as
                                     the cloud allows; default); 0 = x, y, z (rounds 1-5); 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx.  Takes
                                     effect at the next pcc_index_set_input.  No result bit depends on it. */
-    PCC_OPT_XCD_RUN = 19         /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
+    PCC_OPT_XCD_RUN = 19,        /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
                                     i.e. the stretch of the grid one L2 works on at a time (default 32) */
+    PCC_OPT_FUSE_PARAMS = 20     /* index build: 1 = the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
+                                    pack kernel to finish (default); 0 = by a kernel of its own behind it (rounds 1-5) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -49,6 +49,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_OVERLAP_PREP: return value >= 0 && value <= 2;
         case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
         case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
+        case PCC_OPT_FUSE_PARAMS: return value == 0 || value == 1;
         default: return value == 0 || value == 1;
     }
 }
@@ -74,6 +75,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_OVERLAP_PREP: *as_int = &o.overlap_prep; return nullptr;
         case PCC_OPT_GRID_AXES: *as_int = &o.grid_axes; return nullptr;
         case PCC_OPT_XCD_RUN: *as_int = &o.xcd_run; return nullptr;
+        case PCC_OPT_FUSE_PARAMS: *as_int = &o.fuse_params; return nullptr;
         default: return nullptr;
     }
 }
@@ -88,7 +90,8 @@ void Options::from_env() {
         {"PCC_FLANN_SPLIT", PCC_OPT_FLANN_SPLIT}, {"PCC_NN1_DENSE_MIN", PCC_OPT_NN1_DENSE_MIN}, {"PCC_KNN_KERNEL", PCC_OPT_KNN_KERNEL},
         {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1},
         {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}, {"PCC_OVERLAP_PREP", PCC_OPT_OVERLAP_PREP},
-        {"PCC_GRID_AXES", PCC_OPT_GRID_AXES}, {"PCC_XCD_RUN", PCC_OPT_XCD_RUN}};
+        {"PCC_GRID_AXES", PCC_OPT_GRID_AXES}, {"PCC_XCD_RUN", PCC_OPT_XCD_RUN},
+        {"PCC_FUSE_PARAMS", PCC_OPT_FUSE_PARAMS}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;
@@ -106,7 +109,10 @@ static std::atomic<int> g_fail_alloc{0};
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap && p) return PCC_OK;
-    if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1) == 1) {
+    // (one compare-exchange per armed growth: two threads can never both take the count through zero)
+    int armed = g_fail_alloc.load(std::memory_order_relaxed);
+    while (armed > 0 && !g_fail_alloc.compare_exchange_weak(armed, armed - 1)) {}
+    if (armed == 1) {
         set_error("hipMalloc(%zu) failed: injected by pcc_debug_fail_alloc", bytes);
         return PCC_ERR_NOMEM;  // (the buffer keeps what it had: exactly what a refused growth leaves behind)
     }
@@ -176,14 +182,14 @@ struct DeviceGuard {
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
                         DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr,
                         unsigned int* zero_word = nullptr, float4* seeds = nullptr, unsigned long long* invalid_keys = nullptr,
-                        unsigned int* cells = nullptr, const GridDev* gd = nullptr) {
+                        unsigned int* cells = nullptr, const GridDev* gd = nullptr, const PackGrid* grid = nullptr) {
     const void* src = pts;
     if (mem == PCC_MEM_HOST) {
         PCC_TRY(raw.reserve(n * stride));
         PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
         src = raw.p;
     }
-    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd);
+    return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd, grid);
 }
 
 int check_points(const void* pts, size_t n, size_t stride, int mem) {
@@ -262,9 +268,12 @@ static int set_input_impl(pcc_index* ix, const void* pts, size_t n, size_t strid
     PCC_TRY(ix->refs.reserve(n * sizeof(float4)));
     int nblk = 0;
     PCC_TRY(ix->seeds.reserve(((n + PCC_SEED_STRIDE - 1) / PCC_SEED_STRIDE) * sizeof(float4)));  // the pack kernel also emits the seed subset
+    PackGrid pg{};
+    const bool fused = ix->opt.fuse_params != 0;
+    if (fused) PCC_TRY(grid_params_fused(ix, &pg));
     PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk,
-                         nullptr, ix->seeds.as<float4>()));
-    PCC_TRY(grid_params(ix, ix->blk_stats.as<float>(), nblk));
+                         nullptr, ix->seeds.as<float4>(), nullptr, nullptr, nullptr, fused ? &pg : nullptr));
+    if (!fused) PCC_TRY(grid_params(ix, ix->blk_stats.as<float>(), nblk));
     ix->engine = resolve_engine(ix->engine_requested, n);
     // everything a query needs to be packed and sorted exists from here on (PrepOverlap below)
     if (ix->engine == PCC_ENGINE_GRID && ix->opt.overlap_prep) {
@@ -409,6 +418,7 @@ static int new_handle(int device, int engine, pcc_index** out) {
     ix->stream = ix->own_stream;
     if (hipHostMalloc(&ix->pinned, PACK_MAX_BLOCKS * 8 * sizeof(float) + 4096, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(PCC_ERR_DEVICE); }
     if ((st = ix->small.reserve(PCC_SMALL_BYTES)) != PCC_OK) return fail(st);
+    if (hipMemset(ix->small.p, 0, PCC_SMALL_BYTES) != hipSuccess) { set_error("hipMemset failed"); return fail(PCC_ERR_DEVICE); }  // (the pack kernel's ticket word starts at 0)
     if ((st = ix->blk_stats.reserve(PACK_MAX_BLOCKS * 8 * sizeof(float))) != PCC_OK) return fail(st);
     ix->engine_requested = engine;
     ix->engine = engine;
@@ -1353,7 +1363,12 @@ int pcc_icp_align(pcc_index* ix, const void* src, size_t n, size_t stride, int m
 // src/comparator.cpp:1089-1110).  With one rank the all-reduce is the identity and the result is pcc_icp_align's, bit for bit.
 int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* src, size_t n, size_t stride, int mem, int max_iter,
                         int fixed, float T[16], double* fitness, int* iterations, int* converged) {
-    PCC_ENTER(ix);
+    // (PCC_ENTER spelled out: a device that cannot be selected is a failure of this rank alone and has to reach the status
+    // exchange below like every other one -- an early return here would leave the peers waiting in it)
+    if (!ix) { set_error("null index"); return PCC_ERR_INVALID; }  // (the sharded entry point has checked this before its peers can wait)
+    std::lock_guard<std::mutex> _lock(ix->mu);
+    pcc::DeviceGuard _guard(ix->device);
+    pcc::entered(ix);
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int it = 0;
     bool conv = false;
@@ -1364,6 +1379,7 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
     // collective and ends in a status the ranks agree on (hooks->agree: all-reduce MIN of one word), so a rank that
     // cannot go on takes the others out with it instead of leaving them in the broadcast below (comm.hip).
     auto prepare = [&]() -> int {
+        if (!_guard.ok) { set_error("hipSetDevice(%d) failed", ix->device); return PCC_ERR_DEVICE; }
         PCC_TRY(check_points(src, n, stride, mem));
         if (!T) { set_error("null T"); return PCC_ERR_INVALID; }
         if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }

@@ -224,15 +224,18 @@ int pcc_index_create_broadcast(pcc_comm* c, int root, const void* pts, size_t n,
     // step 2: the size (a device word; the default stream orders the three steps)
     n64 = c->rank == root ? (unsigned long long)n : 0ull;
     unsigned long long* w = c->word.as<unsigned long long>();
-    PCC_HIP(hipMemcpy(w, &n64, sizeof(n64), hipMemcpyHostToDevice));
+    // (a copy that fails on one rank joins the status exchange like every other local failure: no rank enters the broadcast alone)
+    st = PCC_OK;
+    if (hipMemcpy(w, &n64, sizeof(n64), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed: %s", hipGetErrorString(hipGetLastError())); st = PCC_ERR_DEVICE; }
+    if ((st = agree_status(c, st)) != PCC_OK) return fail(st);
     {
         ncclResult_t r = rccl()->Broadcast(w, w, 1, ncclUint64, root, c->nccl, nullptr);
         if (r != ncclSuccess) { set_error("ncclBroadcast failed: %s", rccl()->GetErrorString(r)); return fail(PCC_ERR_DEVICE); }
     }
-    if (hipMemcpy(&n64, w, sizeof(n64), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return fail(PCC_ERR_DEVICE); }
-    // step 3: room for the copy on the other ranks; one agreed status BEFORE the data collective
+    // step 3: room for the copy on the other ranks; one agreed status BEFORE the data collective (the read-back of the size included)
     st = PCC_OK;
-    if (c->rank != root) {
+    if (hipMemcpy(&n64, w, sizeof(n64), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed: %s", hipGetErrorString(hipGetLastError())); st = PCC_ERR_DEVICE; }
+    if (st == PCC_OK && c->rank != root) {
         std::lock_guard<std::mutex> lock(ix->mu);
         pcc::entered(ix);
         st = n64 ? ix->icp_src.reserve((size_t)n64 * sizeof(float4)) : PCC_ERR_EMPTY;
@@ -361,15 +364,27 @@ int pcc_sor_sharded(pcc_index* ix, pcc_comm* c, size_t start, size_t count, int 
         const int st = agree_status(c, prepare());
         if (st != PCC_OK) return st;
     }
+    // (A collective RCCL refuses to enqueue -- PCC_NCCL -- is not a failure of this rank alone: the communicator is broken for
+    // every rank and the call returns PCC_ERR_DEVICE; what CAN fail locally between two collectives -- a launch, a copy, an
+    // allocation -- is folded into an agreed status before the next one.)
     PCC_NCCL(rccl()->AllReduce(out4, out4, 2, ncclDouble, ncclSum, c->nccl, s));
     PCC_NCCL(rccl()->AllReduce(out4 + 2, out4 + 2, 2, ncclDouble, ncclMin, c->nccl, s));
     struct { double sum, sq, thr; unsigned long long kept; unsigned int exact, pad; } hs{};
     void* st_dev = ix->small.as<char>() + 256;
-    PCC_TRY(launch_sor_threshold_mask(s, dmean, count, ix->d_grid.as<GridDev>(), K, stddev_mult, out4, st_dev, dmask));
+    {
+        const int st = agree_status(c, launch_sor_threshold_mask(s, dmean, count, ix->d_grid.as<GridDev>(), K, stddev_mult, out4, st_dev, dmask));
+        if (st != PCC_OK) return st;
+    }
     unsigned long long* kept_dev = reinterpret_cast<unsigned long long*>(static_cast<char*>(st_dev) + 24);
     PCC_NCCL(rccl()->AllReduce(kept_dev, kept_dev, 1, ncclUint64, ncclSum, c->nccl, s));
-    PCC_HIP(hipMemcpyAsync(&hs, st_dev, sizeof(hs), hipMemcpyDeviceToHost, s));
-    PCC_HIP(hipStreamSynchronize(s));
+    {   // (hs.exact decides whether the big all-reduce below happens: every rank must have read it)
+        int st = PCC_OK;
+        if (hipMemcpyAsync(&hs, st_dev, sizeof(hs), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            set_error("SOR statistics read-back failed: %s", hipGetErrorString(hipGetLastError()));
+            st = PCC_ERR_DEVICE;
+        }
+        if ((st = agree_status(c, st)) != PCC_OK) return st;
+    }
     double thr = hs.thr;
     size_t kept = (size_t)hs.kept;
     if (!hs.exact) {
@@ -380,11 +395,15 @@ int pcc_sor_sharded(pcc_index* ix, pcc_comm* c, size_t start, size_t count, int 
             int st = ix->scratch_c.reserve(no * sizeof(float) + 64);
             if (st == PCC_OK) st = ix->host_a.reserve(no * sizeof(float));
             if (st == PCC_OK) st = ix->host_b.reserve(count + 64);
+            float* all0 = ix->scratch_c.as<float>();
+            if (st == PCC_OK && (hipMemsetAsync(all0, 0, no * sizeof(float), s) != hipSuccess ||
+                                 (count && hipMemcpyAsync(all0 + start, dmean, count * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess))) {
+                set_error("SOR: staging the shard's mean distances failed: %s", hipGetErrorString(hipGetLastError()));
+                st = PCC_ERR_DEVICE;
+            }
             if ((st = agree_status(c, st)) != PCC_OK) return st;
         }
         float* all = ix->scratch_c.as<float>();
-        PCC_HIP(hipMemsetAsync(all, 0, no * sizeof(float), s));
-        if (count) PCC_HIP(hipMemcpyAsync(all + start, dmean, count * sizeof(float), hipMemcpyDeviceToDevice, s));
         PCC_NCCL(rccl()->AllReduce(all, all, no, ncclFloat, ncclSum, c->nccl, s));
         float* hm = ix->host_a.as<float>();
         PCC_HIP(hipMemcpyAsync(hm, all, no * sizeof(float), hipMemcpyDeviceToHost, s));

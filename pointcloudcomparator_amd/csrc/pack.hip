@@ -7,6 +7,7 @@
 #include "pcc_internal.hpp"
 #include "lane_ops.hpp"
 #include "grid_device.hpp"
+#include "grid_params_device.hpp"
 
 namespace pcc {
 
@@ -36,7 +37,8 @@ template <bool VEC16, bool STATS>
 __global__ void __launch_bounds__(256)
 k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict__ out,
        float* __restrict__ blk, unsigned int* __restrict__ zero_word, float4* __restrict__ seeds,
-       unsigned long long* __restrict__ invalid_keys, unsigned int* __restrict__ cells, const GridDev* __restrict__ gd) {
+       unsigned long long* __restrict__ invalid_keys, unsigned int* __restrict__ cells, const GridDev* __restrict__ gd,
+       PackGrid pg) {
     if (zero_word && blockIdx.x == 0 && threadIdx.x < 64) {  // counters of the search that follows: saves a 5 us memset node
         if (threadIdx.x < 2) zero_word[threadIdx.x] = 0u;                      // fallback list, far list
         zero_word[PCC_OPEN_CTR0 - 32 + threadIdx.x * PCC_OPEN_CTR_STRIDE] = 0u;  // the sharded open-lane counters (grid.hip)
@@ -104,12 +106,28 @@ k_pack(const char* __restrict__ aos, size_t n, size_t stride, float4* __restrict
             for (int a = 0; a < 3; ++a) { o[1 + a] = l[a]; o[4 + a] = h[a]; }
             o[7] = 0.f;
         }
+        // The grid of the index straight from here (PackGrid, set by the index build): every workgroup takes a ticket once its
+        // row is written (release: fence, then the agent-scope increment); the LAST one to arrive does what k_grid_params did in
+        // a launch of its own -- 10-12 us of every build, a twentieth of a 1M x 1M step -- reading the rows past the caches.
+        if (pg.out) {
+            __shared__ unsigned int last;
+            if (threadIdx.x == 0) {
+                __threadfence();
+                last = atomicAdd(pg.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+            }
+            __syncthreads();
+            if (last) {  // (block-uniform)
+                __threadfence();
+                if (threadIdx.x == 0) *pg.ticket = 0u;  // ready for the next build on this handle (stream order)
+                grid_params_block<true>(blk, (int)gridDim.x, (unsigned int)n, pg.ppc, pg.nc_cap, pg.trim_k, pg.axes, pg.out, pg.host_mirror);
+            }
+        }
     }
 }
 
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
                 float* blk_stats, int* n_blocks, unsigned int* zero_word, float4* seeds, unsigned long long* invalid_keys,
-                unsigned int* cells, const GridDev* gd) {
+                unsigned int* cells, const GridDev* gd, const PackGrid* grid) {
     if (n_blocks) *n_blocks = 0;
     if (n == 0) return PCC_OK;
     bool vec = (stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(aos) & 15) == 0);
@@ -118,10 +136,15 @@ int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4*
     if (n_blocks) *n_blocks = g;
     const char* a = (const char*)aos;
     bool st = blk_stats != nullptr;
-    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
-    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
-    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
-    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd);
+    PackGrid pg{};
+    if (grid && st) {
+        pg = *grid;
+        if (g < 128) pg.trim_k = 0;  // (trimming needs enough rows to tell an outlier from the scene: 128 pack workgroups = 64k points)
+    }
+    if (vec && st) hipLaunchKernelGGL((k_pack<true, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd, pg);
+    else if (vec) hipLaunchKernelGGL((k_pack<true, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd, pg);
+    else if (st) hipLaunchKernelGGL((k_pack<false, true>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd, pg);
+    else hipLaunchKernelGGL((k_pack<false, false>), dim3(g), dim3(256), 0, s, a, n, stride, out, blk_stats, zero_word, seeds, invalid_keys, cells, gd, pg);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -11,7 +11,7 @@
 // every PCC_SEED_STRIDE-th reference is a "seed": the exhaustive scan of the seeds bounds a far query's ball
 #define PCC_SEED_SHIFT 6
 #define PCC_SEED_STRIDE (1 << PCC_SEED_SHIFT)
-// pcc_index::small (uint32 words): [32] fallback count, [33] far-list count, [PCC_OPEN_CTR0 + s * PCC_OPEN_CTR_STRIDE] open-lane
+// pcc_index::small (uint32 words): [32] fallback count, [33] far-list count, [52] ticket of the build's pack kernel (grid.hip), [PCC_OPEN_CTR0 + s * PCC_OPEN_CTR_STRIDE] open-lane
 // count of shard s -- one 128-byte line each, PCC_OPEN_SHARDS of them (a single word takes ~88 atomics per microsecond)
 #define PCC_OPEN_SHARDS 64
 #define PCC_OPEN_CTR0 1024
@@ -131,6 +131,8 @@ struct Options {
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
                                     // shortest, shortest, longest); 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
+    int fuse_params = 1;            // PCC_OPT_FUSE_PARAMS: the grid parameters come out of the build's pack kernel (its last workgroup); 0 = k_grid_params,
+                                    // a launch of its own
     int xcd_run = 32;               // PCC_OPT_XCD_RUN: consecutive workgroups of the k = 1 search steered to the same XCD (its L2)
     int overlap_prep = 1;           // PCC_OPT_OVERLAP_PREP: a k = 1 search that follows setInputCloud directly packs and sorts its queries on a
                                     // second stream while the build's cell sort is still running (they share nothing but the grid parameters);
@@ -270,9 +272,20 @@ inline void ev_next(pcc_index* ix) {
 // written with w = -1.  With blk_stats != nullptr every workgroup b also writes 8 floats:
 // [0] bits(invalid count), [1..3] min xyz, [4..6] max xyz of its valid points; *n_blocks rows.
 constexpr int PACK_MAX_BLOCKS = 1024;
+// grid (index builds, with blk_stats): the pack kernel's last workgroup also derives the index's grid (what k_grid_params does in
+// a launch of its own): ticket = a zeroed device word, the rest are k_grid_params' arguments
+struct PackGrid {
+    unsigned int* ticket;
+    float ppc;
+    unsigned int nc_cap;
+    int trim_k, axes;
+    GridDev* out;
+    GridDev* host_mirror;
+};
 int launch_pack(hipStream_t s, const void* aos, size_t n, size_t stride, float4* out,
                 float* blk_stats = nullptr, int* n_blocks = nullptr, unsigned int* zero_word = nullptr, float4* seeds = nullptr,
-                unsigned long long* invalid_keys = nullptr, unsigned int* cells = nullptr, const GridDev* gd = nullptr);
+                unsigned long long* invalid_keys = nullptr, unsigned int* cells = nullptr, const GridDev* gd = nullptr,
+                const PackGrid* grid = nullptr);
 // exclusive scan of uint32 data[n] in place; data[n] receives the total when
 // write_total.  tmp is grown as needed.
 int launch_exclusive_scan(pcc_index* ix, hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp);
@@ -318,6 +331,7 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
 
 // ---- grid.hip --------------------------------------------------------------------------
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks);  // async: d_grid + pinned mirror
+int grid_params_fused(pcc_index* ix, PackGrid* pg);                        // the same from inside the pack kernel: fills *pg for launch_pack
 int grid_build(pcc_index* ix);                                             // async: cell sort of the references
 int sync_info(pcc_index* ix);                                              // wait for the pinned mirror, refresh host fields
 unsigned int grid_nc_cap(size_t n, double ppc);

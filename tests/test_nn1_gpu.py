@@ -334,3 +334,39 @@ def test_nn1_staged_beside_the_build_at_every_size(gpu, engine, m, n):
         ki, _ = ix.knn(b[:50], 2)                    # another call in between: one stream
         assert ok(ix.nn1(b), want[id(a2)])
         assert (ki[:, 0] == want[id(a2)][0][:50]).all()
+
+
+def test_nn1_on_a_caller_stream_waits_for_the_callers_producer(gpu):
+    """pcc_index_set_stream hands the caller's stream over: everything the caller enqueues on it between setInputCloud and the
+    search -- here the kernels that PRODUCE the queries -- is ordered before the search's first read, whatever
+    PCC_OPT_OVERLAP_PREP says (the staging on the library's second stream waits for the build's grid parameters only, so it
+    must not act on a stream it does not own).  The producer is made slow (a chain of passes over a large buffer) and the
+    query buffer holds far-away garbage until its last kernel writes it."""
+    torch = pytest.importorskip("torch")
+    m = n = 300_000
+    a = torch.from_numpy(synth.corridor_cloud(m, synth.SEED_A)).cuda()
+    b_host = synth.corridor_cloud(n, synth.SEED_B)
+    want = oracle.KdTree(synth.corridor_cloud(m, synth.SEED_A)).nn1_batch(b_host[:5000])
+    src = torch.from_numpy(b_host).cuda()
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with capi.Index(a, engine=capi.ENGINE_GRID, auto_sync=False) as ix:
+        ix.set_stream(stream.cuda_stream)
+        for prep in (2, 1, 0):
+            ix.set_option(capi.OPT_OVERLAP_PREP, prep)
+            q = torch.full((n, 3), 1.0e6, dtype=torch.float32, device="cuda")
+            idx = torch.empty(n, dtype=torch.int32, device="cuda")
+            d2 = torch.empty(n, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                ix.set_input(a)
+                junk = torch.zeros(64_000_000, dtype=torch.float32, device="cuda")
+                for _ in range(12):          # a few milliseconds of work ahead of the write
+                    junk.add_(1.0)
+                q.copy_(src + junk[:1] * 0)  # the queries exist only now
+                ix.nn1(q, idx, d2)
+            stream.synchronize()
+            ix.sync()
+            gi, gd = idx[:5000].cpu().numpy(), d2[:5000].cpu().numpy()
+            assert (_bits(gd) == _bits(want[1])).all(), prep
+            assert (gi == want[0]).all(), prep
