@@ -177,8 +177,14 @@ enum pcc_option {
                                     effect at the next pcc_index_set_input.  No result bit depends on it. */
     PCC_OPT_XCD_RUN = 19,        /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
                                     i.e. the stretch of the grid one L2 works on at a time (default 32) */
-    PCC_OPT_FUSE_PARAMS = 20     /* index build: 1 = the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
-                                    pack kernel to finish (default); 0 = by a kernel of its own behind it (rounds 1-5) */
+    PCC_OPT_FUSE_PARAMS = 20,    /* index build: 1 = the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
+                                    pack kernel to finish, and a pass of pcc_icp_align is solved by the last workgroup of its sums
+                                    kernel (default); 0 = by kernels of their own behind them (rounds 1-5) */
+    PCC_OPT_HOST_PIPE = 21       /* PCC_MEM_HOST clouds and results of 8 MB and more in PAGEABLE memory: 1 = staged by the library
+                                    through two pinned chunk buffers by a few host threads (PCC_HOST_THREADS, default half the
+                                    cores, at most 8), the DMA of a chunk running while the next is gathered; only x, y, z cross
+                                    the link when the stride is 24 bytes or more (default); 0 = one hipMemcpyAsync of the raw
+                                    array.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) is always copied directly */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -5,6 +5,7 @@
 #include "pcc_internal.hpp"
 #include <atomic>
 #include "rigid_solve.hpp"
+#include "host_pipe.hpp"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -49,7 +50,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_OVERLAP_PREP: return value >= 0 && value <= 2;
         case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
         case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
-        case PCC_OPT_FUSE_PARAMS: return value == 0 || value == 1;
+        case PCC_OPT_FUSE_PARAMS: case PCC_OPT_HOST_PIPE: return value == 0 || value == 1;
         default: return value == 0 || value == 1;
     }
 }
@@ -76,6 +77,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_GRID_AXES: *as_int = &o.grid_axes; return nullptr;
         case PCC_OPT_XCD_RUN: *as_int = &o.xcd_run; return nullptr;
         case PCC_OPT_FUSE_PARAMS: *as_int = &o.fuse_params; return nullptr;
+        case PCC_OPT_HOST_PIPE: *as_int = &o.host_pipe; return nullptr;
         default: return nullptr;
     }
 }
@@ -91,7 +93,7 @@ void Options::from_env() {
         {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1},
         {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}, {"PCC_OVERLAP_PREP", PCC_OPT_OVERLAP_PREP},
         {"PCC_GRID_AXES", PCC_OPT_GRID_AXES}, {"PCC_XCD_RUN", PCC_OPT_XCD_RUN},
-        {"PCC_FUSE_PARAMS", PCC_OPT_FUSE_PARAMS}};
+        {"PCC_FUSE_PARAMS", PCC_OPT_FUSE_PARAMS}, {"PCC_HOST_PIPE", PCC_OPT_HOST_PIPE}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;
@@ -178,15 +180,25 @@ struct DeviceGuard {
 #define PCC_NOTHING_ENQUEUED(ix) (ix)->build_fresh = (ix)->after_build
 
 // Stage a caller cloud (host or device AoS) as packed float4 on the device.
-// host: one H2D copy of the raw AoS, then the pack kernel.
+// host: the raw array (or, for large pageable clouds, its x / y / z alone: host_pipe.hpp) to the device, then the pack kernel.
 static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem,
                         DevBuf& raw, float4* packed, float* blk_stats = nullptr, int* n_blocks = nullptr,
                         unsigned int* zero_word = nullptr, float4* seeds = nullptr, unsigned long long* invalid_keys = nullptr,
                         unsigned int* cells = nullptr, const GridDev* gd = nullptr, const PackGrid* grid = nullptr) {
     const void* src = pts;
-    if (mem == PCC_MEM_HOST) {
-        PCC_TRY(raw.reserve(n * stride));
-        PCC_HIP(hipMemcpyAsync(raw.p, pts, (n - 1) * stride + 12, hipMemcpyHostToDevice, ix->stream));
+    if (mem == PCC_MEM_HOST && n > 0) {
+        const size_t bytes = (n - 1) * stride + 12;
+        if (ix->opt.host_pipe && bytes >= PIPE_MIN_BYTES && !host_pointer_is_pinned(pts)) {
+            // (everything enqueued so far may still be reading `raw`: the chunks are enqueued on the same stream, in order behind it)
+            const size_t dst_stride = stride >= 24 ? 12 : stride;
+            PCC_TRY(raw.reserve(n * dst_stride + 16));
+            if (!ix->pipe) ix->pipe = new HostPipe();
+            PCC_TRY(ix->pipe->upload(ix->stream, static_cast<const char*>(pts), n, stride, raw.as<char>(), dst_stride));
+            stride = dst_stride;
+        } else {
+            PCC_TRY(raw.reserve(n * stride));
+            PCC_HIP(hipMemcpyAsync(raw.p, pts, bytes, hipMemcpyHostToDevice, ix->stream));
+        }
         src = raw.p;
     }
     return launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd, grid);
@@ -226,6 +238,10 @@ template <class T>
 static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) {
     if (!user || count == 0) return PCC_OK;
     if (mem == PCC_MEM_HOST) {
+        if (ix->opt.host_pipe && count * sizeof(T) >= PIPE_MIN_BYTES && !host_pointer_is_pinned(user)) {
+            if (!ix->pipe) ix->pipe = new HostPipe();
+            PCC_TRY(ix->pipe->download(ix->stream, reinterpret_cast<const char*>(dev), reinterpret_cast<char*>(user), count * sizeof(T)));
+        } else
         PCC_HIP(hipMemcpyAsync(user, dev, count * sizeof(T), hipMemcpyDeviceToHost, ix->stream));
     } else if (user != dev) {
         PCC_HIP(hipMemcpyAsync(user, dev, count * sizeof(T), hipMemcpyDeviceToDevice, ix->stream));
@@ -394,6 +410,7 @@ int pcc_index_destroy(pcc_index* ix) {
             if (ix->ev[sl][k]) (void)hipEventDestroy(ix->ev[sl][k]);
     ix->host_a.release();
     ix->host_b.release();
+    if (ix->pipe) { ix->pipe->release(); delete ix->pipe; ix->pipe = nullptr; }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     if (ix->h_grid) (void)hipHostFree(ix->h_grid);
     if (ix->edge_ev) (void)hipEventDestroy(ix->edge_ev);
@@ -1466,10 +1483,15 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
                 ix->warm_start = warm_env != 0;  // from now on out_packed holds the last pass's keys of these same points
                 int nb = 0;
                 unsigned int* zw = ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr;
+                // (one GPU: the sums kernel's last workgroup solves the pass itself -- [53] of `small` is its ticket word;
+                // PCC_OPT_FUSE_PARAMS = 0 keeps the solver's own launch, as the sharded loop must: its sums pass through an all-reduce)
+                const bool fuse_solve = !hooks && ix->opt.fuse_params != 0;
+                const IcpFuse fuse{ix->small.as<unsigned int>() + 53, st, max_iter, fixed, fold ? zw : nullptr};
                 PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
                                         ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb, zw,
-                                        static_cast<unsigned int*>(ix->pinned) + 40, center_dev));
-                if (hooks) {  // rows -> 17 sums (workgroup order, as the solver adds them) -> sum over the ranks -> solve
+                                        static_cast<unsigned int*>(ix->pinned) + 40, center_dev, fuse_solve ? &fuse : nullptr));
+                if (fuse_solve) {
+                } else if (hooks) {  // rows -> 17 sums (workgroup order, as the solver adds them) -> sum over the ranks -> solve
                     PCC_TRY(launch_icp_rows_to_sums(ix->stream, ix->scratch_a.as<double>(), nb, sums_dev));
                     PCC_TRY(hooks->allreduce_sum_f64(hooks->ctx, sums_dev, 17, ix->stream));
                     PCC_TRY(launch_icp_solve(ix->stream, sums_dev, 1, st, max_iter, fixed, center_dev, fold ? zw : nullptr));

@@ -11,7 +11,7 @@
 // every PCC_SEED_STRIDE-th reference is a "seed": the exhaustive scan of the seeds bounds a far query's ball
 #define PCC_SEED_SHIFT 6
 #define PCC_SEED_STRIDE (1 << PCC_SEED_SHIFT)
-// pcc_index::small (uint32 words): [32] fallback count, [33] far-list count, [52] ticket of the build's pack kernel (grid.hip), [PCC_OPEN_CTR0 + s * PCC_OPEN_CTR_STRIDE] open-lane
+// pcc_index::small (uint32 words): [32] fallback count, [33] far-list count, [52] ticket of the build's pack kernel (grid.hip), [53] ticket of k_icp_sums (fused solve), [PCC_OPEN_CTR0 + s * PCC_OPEN_CTR_STRIDE] open-lane
 // count of shard s -- one 128-byte line each, PCC_OPEN_SHARDS of them (a single word takes ~88 atomics per microsecond)
 #define PCC_OPEN_SHARDS 64
 #define PCC_OPEN_CTR0 1024
@@ -131,6 +131,9 @@ struct Options {
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
                                     // shortest, shortest, longest); 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
+    int host_pipe = 1;              // PCC_OPT_HOST_PIPE: clouds / results of 8 MB and more in pageable HOST memory cross PCIe through the library's own pinned
+                                    // chunk buffers, staged by a few host threads (x, y, z only when the stride is 24 bytes or more); 0 = one
+                                    // hipMemcpyAsync of the raw array (rounds 1-5)
     int fuse_params = 1;            // PCC_OPT_FUSE_PARAMS: the grid parameters come out of the build's pack kernel (its last workgroup); 0 = k_grid_params,
                                     // a launch of its own
     int xcd_run = 32;               // PCC_OPT_XCD_RUN: consecutive workgroups of the k = 1 search steered to the same XCD (its L2)
@@ -142,6 +145,7 @@ struct Options {
 
 }  // namespace pcc
 
+namespace pcc { struct HostPipe; }  // host_pipe.hpp (api.hip): pipelined transfers between pageable host memory and the device
 #define PCC_EV_SLOTS 64
 #define PCC_EV_KINDS 10
 // The opaque handle of the C-ABI.
@@ -227,6 +231,7 @@ struct pcc_index {
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     pcc::HostBuf host_a, host_b;  // large pinned read-back buffers
+    pcc::HostPipe* pipe = nullptr;  // two pinned chunk buffers + events, made at the first large host transfer (api.hip)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
     // ring of PCC_EV_SLOTS calls so a timed region of many steps is covered without syncing
@@ -382,9 +387,19 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
 int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq);
 // ---- icp.hip -----------------------------------------------------------------------------
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
+struct IcpState;
+// fuse (device-resident loop on one GPU): the last workgroup of k_icp_sums to finish also solves the pass (k_icp_solve's work);
+// ticket = a zeroed device word; center_dev must be given
+struct IcpFuse {
+    unsigned int* ticket;
+    IcpState* st;
+    int max_iter, fixed;
+    unsigned int* zero_word;
+};
 int launch_icp_sums(hipStream_t s, const float4* src, size_t n, const unsigned long long* keys,
                     const float4* refs, double* partials, int* n_blocks, const unsigned int* mirror_dev = nullptr,
-                    unsigned int* mirror_host = nullptr, const double* center_dev = nullptr);  // sums of p - center, q - center (device pointer)
+                    unsigned int* mirror_host = nullptr, const double* center_dev = nullptr,  // sums of p - center, q - center (device pointer)
+                    const IcpFuse* fuse = nullptr);
 constexpr int ICP_MAX_BLOCKS = 480;  // (480 rows of 17 doubles fit the 64 KB of LDS k_icp_solve stages them in)
 // state of the device-resident ICP loop (pcc_icp_align): no host round trip per pass
 struct IcpState {

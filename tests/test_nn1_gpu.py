@@ -370,3 +370,31 @@ def test_nn1_on_a_caller_stream_waits_for_the_callers_producer(gpu):
             gi, gd = idx[:5000].cpu().numpy(), d2[:5000].cpu().numpy()
             assert (_bits(gd) == _bits(want[1])).all(), prep
             assert (gi == want[0]).all(), prep
+
+
+@pytest.mark.parametrize("floats", [3, 4, 8])
+def test_large_host_clouds_cross_pcie_through_the_pinned_pipe(gpu, floats):
+    """PCC_OPT_HOST_PIPE: pageable host clouds and results of 8 MB and more are staged by the library (chunks gathered by host
+    threads into pinned buffers, x / y / z only when the stride is 24 bytes or more); the plain hipMemcpyAsync path must return
+    the same arrays -- and both the oracle's bits on a sample.  Non-finite points, sizes that are no multiple of the chunk."""
+    m, n = 1_500_011, 2_100_003          # 2.1M x 4 B results = 8.4 MB: the download side acts too
+    a = synth.corridor_cloud(m, synth.SEED_A)
+    b = synth.corridor_cloud(n, synth.SEED_B)
+    if floats > 3:
+        pad = np.full((1, floats - 3), 7.0, np.float32)
+        a = np.ascontiguousarray(np.concatenate([a, np.broadcast_to(pad, (m, floats - 3))], axis=1))
+        b = np.ascontiguousarray(np.concatenate([b, np.broadcast_to(pad, (n, floats - 3))], axis=1))
+    a[5, 1] = np.nan
+    a[m - 1, 0] = np.inf
+    b[n - 1, 2] = np.nan
+    res = {}
+    for pipe in (1, 0):
+        with capi.Index(a[:4096], engine=capi.ENGINE_GRID) as ix:
+            ix.set_option(capi.OPT_HOST_PIPE, pipe)
+            ix.set_input(a)
+            res[pipe] = ix.nn1(b)
+    assert (res[1][0] == res[0][0]).all() and (_bits(res[1][1]) == _bits(res[0][1])).all()
+    sel = np.concatenate([np.arange(0, n, 997), [n - 2, n - 1]])
+    oi, od = oracle.KdTree(a[:, :3]).nn1_batch(np.ascontiguousarray(b[sel[:-1], :3]))
+    assert (_bits(res[1][1][sel[:-1]]) == _bits(od)).all() and (res[1][0][sel[:-1]] == oi).all()
+    assert res[1][0][n - 1] == -1 and np.isinf(res[1][1][n - 1])
