@@ -176,7 +176,7 @@ enum pcc_option {
                                     the cloud allows; default); 0 = x, y, z (rounds 1-5); 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx.  Takes
                                     effect at the next pcc_index_set_input.  No result bit depends on it. */
     PCC_OPT_XCD_RUN = 19,        /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
-                                    i.e. the stretch of the grid one L2 works on at a time (default 32) */
+                                    i.e. the stretch of the grid one L2 works on at a time (default 256) */
     PCC_OPT_FUSE_PARAMS = 20,    /* index build: 1 = the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
                                     pack kernel to finish, and a pass of pcc_icp_align is solved by the last workgroup of its sums
                                     kernel (default); 0 = by kernels of their own behind them (rounds 1-5) */

@@ -83,7 +83,7 @@ def run(out_path):
             "8d: 12 B per point read (16 B packed here) + 8 B per emitted (idx, d2)")
     t, r = timed(lambda: ix.euclidean_clusters(0.05, 100, 250000, device_out=obj), reps=2)
     add("Euclidean clustering r=0.05 (-e)", f"{m} object-layer points, {r[1]} clusters", t, 2 * (16.0 * m + 4.0 * m) + 16.0 * m,
-        ["k_uf_link_cells", "k_uf_"], "8d: 12 M' read + 4 M' label write per propagation round (two passes over the points here) + the cell sort")
+        ["k_ecc_", "k_uf_", "k_cs_", "k_mp_"], "8d: 12 M' read + 4 M' label write per propagation round (two passes over the points here) + the cell sort")
     ix.close()
     del obj, idx, d2, offs, cnt
     torch.cuda.empty_cache()
@@ -113,7 +113,7 @@ def merge(run_json, stats_csv, out_path, pairs_json=None):
         for r in rows:
             name = r["Name"]
             if any(k in name for k in op["kernels"]):
-                short = name.split("(")[0].replace("void ", "").replace("pcc::", "")
+                short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("pcc::", "")
                 ks[short] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
         op["rocprof_kernels"] = ks
         pc = pairs.get((op["op"], op["config"]))
