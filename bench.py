@@ -169,7 +169,7 @@ def pcl_present() -> bool:
             return True
     except Exception:
         pass
-    return any(Path(d).glob("pcl*/pcl/kdtree/kdtree_flann.h") for d in ("/usr/include", "/usr/local/include", "/opt/include"))
+    return any(any(Path(d).glob("pcl*/pcl/kdtree/kdtree_flann.h")) for d in ("/usr/include", "/usr/local/include", "/opt/include"))
 
 
 def load_pmc_traffic(kernel_key, workload_key):

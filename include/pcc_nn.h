@@ -138,9 +138,11 @@ enum pcc_option {
     PCC_OPT_FAR_MODE = 3,        /* queries the cell walk leaves: -1 auto, 0 exhaustive kernel, 1 seed scan + ball walk */
     PCC_OPT_ICP_WARM = 4,        /* pcc_icp_align: passes start from the previous pass's neighbours (default 1) */
     PCC_OPT_ICP_DEVICE_LOOP = 5, /* pcc_icp_align: loop resident on the device (default 1; 0 = host-driven, same bits) */
-    PCC_OPT_EC_CELLS = 6,        /* clustering over the clique-cell grid: 3 = union-find over the CELLS, face links first, the rest settled
-                                    against flat roots through the caches (default); 1 = one parent word per point, lanes over a cell's
-                                    neighbour cells; 2 = the same with lanes over points; 0 = per-point ball scan on the search grid */
+    PCC_OPT_EC_CELLS = 6,        /* clustering over the clique-cell grid: 3 = union-find over the CELLS -- the runs of touching cells along a
+                                    row joined by plain stores, one union per pair of neighbouring runs, the rest settled against flat
+                                    roots through the caches (default); 4 = the same with one union per occupied cell and face (round 5);
+                                    1 = one parent word per point, lanes over a cell's neighbour cells; 2 = the same with lanes over
+                                    points; 0 = per-point ball scan on the search grid */
     PCC_OPT_SORT_MP_MIN = 7,     /* reference clouds from this size take the three-level cell sort */
     PCC_OPT_SORT_MP_MIN_Q = 8,   /* the same for query clouds */
     PCC_OPT_NN1_KERNEL = 9,      /* pruned k = 1 kernel: 0 one lane per query; 1 rows drained with lanes over candidates (default);
@@ -177,9 +179,9 @@ enum pcc_option {
                                     effect at the next pcc_index_set_input.  No result bit depends on it. */
     PCC_OPT_XCD_RUN = 19,        /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
                                     i.e. the stretch of the grid one L2 works on at a time (default 256) */
-    PCC_OPT_FUSE_PARAMS = 20,    /* index build: 1 = the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
-                                    pack kernel to finish, and a pass of pcc_icp_align is solved by the last workgroup of its sums
-                                    kernel (default); 0 = by kernels of their own behind them (rounds 1-5) */
+    PCC_OPT_FUSE_PARAMS = 20,    /* bits: 1 = index build: the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
+                                    pack kernel to finish instead of a kernel of its own behind it; 2 = a pass of pcc_icp_align is solved
+                                    by the last workgroup of its sums kernel.  Default 0: see DESIGN.md 4.3 (both were measured) */
     PCC_OPT_HOST_PIPE = 21       /* PCC_MEM_HOST clouds and results of 8 MB and more in PAGEABLE memory: 1 = staged by the library
                                     through two pinned chunk buffers by a few host threads (PCC_HOST_THREADS, default half the
                                     cores, at most 8), the DMA of a chunk running while the next is gathered; only x, y, z cross

@@ -42,7 +42,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_FAR_MODE: return value >= -1 && value <= 1;
         case PCC_OPT_SORT_MP_MIN: case PCC_OPT_SORT_MP_MIN_Q: return value >= 0;
         case PCC_OPT_NN1_KERNEL: return value >= 0 && value <= 3;
-        case PCC_OPT_EC_CELLS: return value >= 0 && value <= 3;
+        case PCC_OPT_EC_CELLS: return value >= 0 && value <= 4;
         case PCC_OPT_KNN_CACHE_K: return value >= 0 && value <= 512;
         case PCC_OPT_NN1_DENSE_MIN: return value >= 1 && value <= 1000000;
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
@@ -50,7 +50,8 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_OVERLAP_PREP: return value >= 0 && value <= 2;
         case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
         case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
-        case PCC_OPT_FUSE_PARAMS: case PCC_OPT_HOST_PIPE: return value == 0 || value == 1;
+        case PCC_OPT_FUSE_PARAMS: return value >= 0 && value <= 3;
+        case PCC_OPT_HOST_PIPE: return value == 0 || value == 1;
         default: return value == 0 || value == 1;
     }
 }
@@ -195,6 +196,25 @@ static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride,
             if (!ix->pipe) ix->pipe = new HostPipe();
             PCC_TRY(ix->pipe->upload(ix->stream, static_cast<const char*>(pts), n, stride, raw.as<char>(), dst_stride));
             stride = dst_stride;
+        } else if (ix->opt.host_pipe && bytes <= PIPE_CHUNK_BYTES) {
+            // SMALL clouds -- the reference's descriptor clouds, 4 ... 18 381 records of 128 bytes, up to 300 calls per comparison
+            // (src/comparator.cpp:560-588): a hipMemcpyAsync from pageable memory makes the host wait for a staged copy (~15 us a
+            // piece).  The cloud is copied into the handle's pinned buffer instead (slot 0: indexed clouds, 1: query clouds) and,
+            // up to SMALL_DIRECT_BYTES, the pack kernel reads it from there across the link -- no copy command at all.
+            if (!ix->pipe) ix->pipe = new HostPipe();
+            PCC_TRY(ix->pipe->init());
+            const int slot = blk_stats ? 0 : 1;
+            PCC_HIP(hipEventSynchronize(ix->pipe->ev[slot]));  // (whoever read this buffer last has finished: nearly always true already)
+            memcpy(ix->pipe->buf[slot].p, pts, bytes);
+            src = ix->pipe->buf[slot].p;
+            if (bytes > SMALL_DIRECT_BYTES) {
+                PCC_TRY(raw.reserve(n * stride));
+                PCC_HIP(hipMemcpyAsync(raw.p, src, bytes, hipMemcpyHostToDevice, ix->stream));
+                src = raw.p;
+            }
+            PCC_TRY(launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd, grid));
+            PCC_HIP(hipEventRecord(ix->pipe->ev[slot], ix->stream));
+            return PCC_OK;
         } else {
             PCC_TRY(raw.reserve(n * stride));
             PCC_HIP(hipMemcpyAsync(raw.p, pts, bytes, hipMemcpyHostToDevice, ix->stream));
@@ -285,7 +305,7 @@ static int set_input_impl(pcc_index* ix, const void* pts, size_t n, size_t strid
     int nblk = 0;
     PCC_TRY(ix->seeds.reserve(((n + PCC_SEED_STRIDE - 1) / PCC_SEED_STRIDE) * sizeof(float4)));  // the pack kernel also emits the seed subset
     PackGrid pg{};
-    const bool fused = ix->opt.fuse_params != 0;
+    const bool fused = (ix->opt.fuse_params & 1) != 0;
     if (fused) PCC_TRY(grid_params_fused(ix, &pg));
     PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk,
                          nullptr, ix->seeds.as<float4>(), nullptr, nullptr, nullptr, fused ? &pg : nullptr));
@@ -750,7 +770,14 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq));
     int32_t* didx = idx;
     float* dd2 = d2;
-    if (mem == PCC_MEM_HOST) {
+    // small host results: the unpack kernel writes them into pinned host memory itself (no copy command, one wait)
+    const bool direct = mem == PCC_MEM_HOST && ix->opt.host_pipe && nq * sizeof(float) <= SMALL_RESULT_BYTES;
+    if (direct) {
+        PCC_TRY(ix->host_a.reserve(nq * sizeof(int32_t)));
+        PCC_TRY(ix->host_b.reserve(nq * sizeof(float)));
+        didx = idx ? ix->host_a.as<int32_t>() : nullptr;
+        dd2 = d2 ? ix->host_b.as<float>() : nullptr;
+    } else if (mem == PCC_MEM_HOST) {
         PCC_TRY(ix->out_idx.reserve(nq * sizeof(int32_t)));
         PCC_TRY(ix->out_d2.reserve(nq * sizeof(float)));
         didx = idx ? ix->out_idx.as<int32_t>() : nullptr;
@@ -759,7 +786,11 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, nq, didx, dd2,
                           ix->small.as<unsigned int>() + 32, static_cast<unsigned int*>(ix->pinned) + 40));
     ev_mark(ix, EV_CALL1);
-    if (mem == PCC_MEM_HOST) {
+    if (direct) {
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        if (idx) memcpy(idx, didx, nq * sizeof(int32_t));
+        if (d2) memcpy(d2, dd2, nq * sizeof(float));
+    } else if (mem == PCC_MEM_HOST) {
         PCC_TRY(deliver(ix, didx, idx, nq, mem));
         PCC_TRY(deliver(ix, dd2, d2, nq, mem));
         PCC_HIP(hipStreamSynchronize(ix->stream));
@@ -1484,8 +1515,8 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
                 int nb = 0;
                 unsigned int* zw = ix->engine == PCC_ENGINE_GRID ? ix->small.as<unsigned int>() + 32 : nullptr;
                 // (one GPU: the sums kernel's last workgroup solves the pass itself -- [53] of `small` is its ticket word;
-                // PCC_OPT_FUSE_PARAMS = 0 keeps the solver's own launch, as the sharded loop must: its sums pass through an all-reduce)
-                const bool fuse_solve = !hooks && ix->opt.fuse_params != 0;
+                // PCC_OPT_FUSE_PARAMS bit 1; the sharded loop keeps the solver's own launch: its sums pass through an all-reduce)
+                const bool fuse_solve = !hooks && (ix->opt.fuse_params & 2) != 0;
                 const IcpFuse fuse{ix->small.as<unsigned int>() + 53, st, max_iter, fixed, fold ? zw : nullptr};
                 PCC_TRY(launch_icp_sums(ix->stream, ix->q_packed.as<float4>(), n, ix->out_packed.as<unsigned long long>(),
                                         ix->refs.as<float4>(), ix->scratch_a.as<double>(), &nb, zw,
@@ -1579,14 +1610,13 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
     PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
     PCC_TRY(nn1_packed(ix, n2));
     if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), n2));
-    PCC_TRY(ix->out_idx.reserve(n2 * sizeof(int32_t)));
-    PCC_TRY(ix->out_d2.reserve(n2 * sizeof(float)));
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n2, ix->out_idx.as<int32_t>(), ix->out_d2.as<float>()));
+    // (the unpack kernel writes the result arrays into pinned host memory itself: no copy command, one wait)
+    PCC_TRY(ix->host_a.reserve(n2 * sizeof(int32_t)));
+    PCC_TRY(ix->host_b.reserve(n2 * sizeof(float)));
+    const int32_t* hi = ix->host_a.as<int32_t>();
+    const float* hd = ix->host_b.as<float>();
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n2, ix->host_a.as<int32_t>(), ix->host_b.as<float>()));
     ev_mark(ix, EV_CALL1);
-    std::vector<int32_t> hi(n2);
-    std::vector<float> hd(n2);
-    PCC_HIP(hipMemcpyAsync(hi.data(), ix->out_idx.p, n2 * sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
-    PCC_HIP(hipMemcpyAsync(hd.data(), ix->out_d2.p, n2 * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
     PCC_HIP(hipStreamSynchronize(ix->stream));
     int32_t c = 1;
     for (size_t i = 0; i < n2; ++i)  // neighborCount == 1 && squaredDistances[0] < threshold (:579)

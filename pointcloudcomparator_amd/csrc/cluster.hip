@@ -273,6 +273,126 @@ k_ecc_link_faces(const float4* __restrict__ cr2, const unsigned int* __restrict_
     }
 }
 
+// ---- phase 1 by x-RUNS (round 6; PCC_OPT_EC_CELLS = 3, the default; 4 = k_ecc_link_faces above) ---------------------------------
+// k_ecc_link_faces offers one agent-scope union per occupied cell and face -- 3.6M of them at 5M points, for components that need
+// one link per pair of neighbouring rows.  Inside an object the occupied cells of a row form RUNS of consecutive cells whose
+// points touch: a run is found by its wave with a segmented scan over the wave's cell heads, and its cells get the run's first
+// cell as their parent with a plain (agent-scope) STORE -- no compare-and-swap, no root walk: in this kernel nothing else writes a
+// cell that is not the first of its run, and compare-and-swaps only ever land on first cells (a run that continues into the next
+// wave is hooked there by the one union its last head makes).  runid[head] = first cell of the head's run within its wave.
+__global__ void __launch_bounds__(256)
+k_ecc_link_xruns(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2, float r2,
+                 unsigned int* __restrict__ cparent, unsigned int* __restrict__ runid) {
+    const GridParams g = gd2->g;
+    const unsigned int n_valid = gd2->n_valid;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= n_valid) return;  // wave-uniform
+    __shared__ unsigned int head_lane[4][64];
+    unsigned int* hl = head_lane[threadIdx.x >> 6];
+    int cx = 0;
+    unsigned int c = 0, a0 = 0xffffffffu, a1 = 0;
+    if (t < n_valid) {
+        const float4 me = cr2[t];
+        float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+        grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+        cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
+        c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+        a0 = cs2[c];
+        a1 = cs2[c + 1];
+    }
+    const bool head = t == a0;
+    const unsigned long long heads = __ballot(head);
+    const unsigned int nheads = (unsigned int)__popcll(heads);
+    if (nheads == 0) return;  // (a wave inside one big cell)
+    if (head) hl[__popcll(heads & ((1ull << lane) - 1ull))] = lane;
+    wave_lds_sync();
+    // lane k < nheads stands for the k-th head of the wave (cells in ascending order)
+    const bool mine = lane < nheads;
+    const int src = (int)hl[mine ? lane : 0u];
+    const int hx = __shfl(cx, src, 64);
+    const unsigned int hc = (unsigned int)__shfl((int)c, src, 64);
+    const unsigned int ha0 = (unsigned int)__shfl((int)a0, src, 64), ha1 = (unsigned int)__shfl((int)a1, src, 64);
+    // the next cell of the row: occupied when its range [ha1, b1) is not empty (CSR: it starts where this one ends)
+    bool touch = false;
+    unsigned int b1 = 0;
+    if (mine && hx + 1 < g.dim[0]) {
+        b1 = cs2[hc + 2];
+        touch = b1 != ha1 && ecc_cells_touch(cr2, ha0, ha1, ha1, b1, r2);
+    }
+    // a head starts a run unless the head before it (in the wave) is its left neighbour and touches it
+    const unsigned int prev_c = (unsigned int)__shfl_up((int)hc, 1, 64);
+    const bool prev_touch = __shfl_up((int)touch, 1, 64) != 0;
+    const bool start = mine && (lane == 0 || !(prev_touch && prev_c + 1u == hc));
+    // (head positions ascend with the lane: the latest start at or before a lane is a running maximum)
+    const unsigned int first = wave_incl_scan_max(start ? ha0 + 1u : 0u) - 1u;
+    if (mine) {
+        runid[ha0] = first;
+        if (!start) __hip_atomic_store(&cparent[ha0], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the run goes on in a later wave: its next cell is the first head there -- a run start, hooked with the one union
+        if (lane == nheads - 1u && touch) uf_union(cparent, first, ha1);
+    }
+}
+
+// the +y / +z face neighbours of every occupied cell, two lanes per head; of the cells of one run that touch the SAME run of the
+// neighbouring row only the first offers the union (both runs are connected in themselves)
+__global__ void __launch_bounds__(256)
+k_ecc_link_yz(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2, float r2,
+              unsigned int* __restrict__ cparent, const unsigned int* __restrict__ runid) {
+    const GridParams g = gd2->g;
+    const unsigned int n_valid = gd2->n_valid;
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= n_valid) return;  // wave-uniform
+    __shared__ unsigned int head_lane[4][64];
+    unsigned int* hl = head_lane[threadIdx.x >> 6];
+    int cy = 0, cz = 0;
+    unsigned int c = 0, a0 = 0xffffffffu, a1 = 0;
+    if (t < n_valid) {
+        const float4 me = cr2[t];
+        float ux, uy, uz;  // the point in the grid's frame (grid_device.hpp)
+        grid_frame(g, me.x, me.y, me.z, ux, uy, uz);
+        const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
+        cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
+        cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
+        c = ((unsigned int)cz * g.dim[1] + cy) * g.dim[0] + cx;
+        a0 = cs2[c];
+        a1 = cs2[c + 1];
+    }
+    const bool head = t == a0;
+    const unsigned long long heads = __ballot(head);
+    const unsigned int nheads = (unsigned int)__popcll(heads);
+    if (head) hl[__popcll(heads & ((1ull << lane) - 1ull))] = lane;
+    wave_lds_sync();
+    const unsigned int sub = lane >> 1, dir = lane & 1u;  // dir 0: one row on (+y), 1: one layer on (+z)
+    for (unsigned int h0 = 0; h0 < nheads; h0 += 32u) {  // wave-uniform
+        const unsigned int hi = h0 + sub;
+        const bool mine = hi < nheads;
+        const int src = (int)hl[mine ? hi : 0u];
+        const int hy = __shfl(cy, src, 64), hz = __shfl(cz, src, 64);
+        const unsigned int hc = (unsigned int)__shfl((int)c, src, 64);
+        const unsigned int ha0 = (unsigned int)__shfl((int)a0, src, 64), ha1 = (unsigned int)__shfl((int)a1, src, 64);
+        unsigned int my_run = 0xffffffffu, nrun = 0xffffffffu, b0 = 0;
+        bool touch = false;
+        if (mine && (dir == 0 ? hy + 1 < g.dim[1] : hz + 1 < g.dim[2])) {
+            const unsigned int cb = hc + (dir == 0 ? (unsigned int)g.dim[0] : (unsigned int)g.dim[0] * (unsigned int)g.dim[1]);
+            b0 = cs2[cb];
+            const unsigned int b1 = cs2[cb + 1];
+            if (b0 != b1 && ecc_cells_touch(cr2, ha0, ha1, b0, b1, r2)) {
+                touch = true;
+                my_run = runid[ha0];
+                nrun = runid[b0];
+            }
+        }
+        // the head before this one (same direction: two lanes back) linked the same two runs already
+        const unsigned int p_my = (unsigned int)__shfl_up((int)my_run, 2, 64), p_n = (unsigned int)__shfl_up((int)nrun, 2, 64);
+        const bool dup = lane >= 2u && p_my == my_run && p_n == nrun;
+        if (touch && !dup) uf_union(cparent, ha0, b0);
+    }
+}
+
 // parent[c] = root(c) for the heads of cells, when no union runs (plain loads: whatever a cache holds is an ancestor)
 __global__ void __launch_bounds__(256)
 k_ecc_flatten(const float4* __restrict__ cr2, const unsigned int* __restrict__ cs2, const GridDev* __restrict__ gd2,
@@ -494,7 +614,14 @@ static int grid_clusters_cells(pcc_index* ix, float r2, uint32_t min_size, uint3
     ev_mark(ix, EV_MAIN0);
     PCC_HIP(hipMemsetAsync(d_count, 0, 4, s));
     hipLaunchKernelGGL(k_ecc_init, dim3(g1(n)), blk, 0, s, cparent, size, minidx, id_of_root, n, labels_dev, n);
-    hipLaunchKernelGGL(k_ecc_link_faces, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent);
+    if (ix->opt.ec_cells == 4) {  // round 5: one union per occupied cell and face
+        hipLaunchKernelGGL(k_ecc_link_faces, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent);
+    } else {  // x-runs by store, then one union per pair of neighbouring runs
+        PCC_TRY(ix->scratch_g.reserve((size_t)n * 4 + 256));  // (the query sort's order buffer: no search is in flight on this handle)
+        unsigned int* runid = ix->scratch_g.as<unsigned int>();
+        hipLaunchKernelGGL(k_ecc_link_xruns, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent, runid);
+        hipLaunchKernelGGL(k_ecc_link_yz, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent, (const unsigned int*)runid);
+    }
     hipLaunchKernelGGL(k_ecc_flatten, gp, blk, 0, s, cr2, cs2, gd2, cparent);
     hipLaunchKernelGGL(k_ecc_link_rest, gp, blk, 0, s, cr2, cs2, gd2, r2, cparent);
     hipLaunchKernelGGL(k_ecc_sizes, gp, blk, 0, s, cr2, cs2, gd2, cparent, size, minidx);
@@ -579,7 +706,7 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
             cells_ok = true;
         }
     }
-    if (cells_ok && ix->opt.ec_cells == 3)
+    if (cells_ok && ix->opt.ec_cells >= 3)
         return grid_clusters_cells(ix, r2, min_size, max_size, labels_dev, n_clusters, sizes, max_sizes);
     // scratch: parent[n] | size[n] | id_of_root[n] | list[cap]
     const unsigned int cap = min_size > 0 ? n / min_size + 1 : n;

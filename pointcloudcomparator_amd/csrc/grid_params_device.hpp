@@ -150,7 +150,7 @@ __device__ __forceinline__ void grid_params_block(const float* __restrict__ blk,
         if (!(g.inv_h > 0.f) || !(g.inv_h < __builtin_inff()) || !(g.h > 0.f)) { g.h = 1.f; g.inv_h = 1.f; }
         double tot = 1.0;
         for (int a = 0; a < 3; ++a) {
-            double dd = floor((double)ext[g.ax[a]] * (double)g.inv_h) + 1.0;
+            double dd = floor((double)pick3(ext, g.ax[a]) * (double)g.inv_h) + 1.0;
             if (dd > 1048576.0) dd = 1048576.0;
             g.dim[a] = (int)dd;
             tot *= dd;
@@ -160,9 +160,9 @@ __device__ __forceinline__ void grid_params_block(const float* __restrict__ blk,
     }
     if ((double)g.dim[0] * g.dim[1] * g.dim[2] > (double)nc_cap) { g.dim[0] = g.dim[1] = g.dim[2] = 1; }  // cannot happen; stay in bounds
     for (int a = 0; a < 3; ++a) {
-        g.org[a] = lo[g.ax[a]];
-        d.glo[a] = d.lo[g.ax[a]];
-        d.ghi[a] = d.hi[g.ax[a]];
+        g.org[a] = pick3(lo, g.ax[a]);
+        d.glo[a] = pick3(d.lo, g.ax[a]);
+        d.ghi[a] = pick3(d.hi, g.ax[a]);
     }
     g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
     d.g = g;

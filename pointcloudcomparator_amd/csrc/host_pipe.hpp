@@ -21,6 +21,8 @@ namespace pcc {
 
 constexpr size_t PIPE_MIN_BYTES = 8u << 20;   // transfers from here on are pipelined
 constexpr size_t PIPE_CHUNK_BYTES = 8u << 20;  // pinned bytes per chunk (two buffers)
+constexpr size_t SMALL_DIRECT_BYTES = 1u << 20;  // a host cloud up to here is read by the pack kernel straight from its pinned copy
+constexpr size_t SMALL_RESULT_BYTES = 1u << 20;  // a host result array up to here is written by the unpack kernel straight into pinned memory
 
 inline bool host_pointer_is_pinned(const void* p) {
     hipPointerAttribute_t a;

@@ -79,17 +79,25 @@ struct GridParams {
 // with the second shortest extent runs along the rows, the shortest over the rows of a layer, the longest over the layers;
 // ties keep x, y, z order.  forced 0..5 = xyz, xzy, yxz, yzx, zxy, zyx (PCC_OPT_GRID_AXES), anything else: by extent.
 __host__ __device__ inline void grid_axes_for(const float ext[3], int forced, int ax[3]) {
-    int o[3] = {0, 1, 2};  // coordinates by ascending extent (stable)
-    for (int i = 1; i < 3; ++i)
-        for (int j = i; j > 0 && ext[o[j]] < ext[o[j - 1]]; --j) { const int t = o[j]; o[j] = o[j - 1]; o[j - 1] = t; }
-    ax[0] = o[1]; ax[1] = o[0]; ax[2] = o[2];
+    // (no array is indexed by a variable: on the device that would put it in scratch memory)
+    const float e0 = ext[0], e1 = ext[1], e2 = ext[2];
+    // rank of each coordinate by ascending extent, ties in x, y, z order (a stable sort of three)
+    const int r0 = (e1 < e0 ? 1 : 0) + (e2 < e0 ? 1 : 0);
+    const int r1 = (e0 <= e1 ? 1 : 0) + (e2 < e1 ? 1 : 0);
+    const int r2 = (e0 <= e2 ? 1 : 0) + (e1 <= e2 ? 1 : 0);
+    const int shortest = r0 == 0 ? 0 : (r1 == 0 ? 1 : 2), second = r0 == 1 ? 0 : (r1 == 1 ? 1 : 2), longest = r0 == 2 ? 0 : (r1 == 2 ? 1 : 2);
+    (void)r2;
+    ax[0] = second; ax[1] = shortest; ax[2] = longest;
     if (forced >= 0 && forced < 6) {
         ax[0] = forced >> 1;                          // 0 0 1 1 2 2
-        const int r0 = ax[0] == 0 ? 1 : 0, r1 = ax[0] == 2 ? 1 : 2;  // the other two, ascending
-        ax[1] = (forced & 1) ? r1 : r0;
-        ax[2] = (forced & 1) ? r0 : r1;
+        const int o0 = ax[0] == 0 ? 1 : 0, o1 = ax[0] == 2 ? 1 : 2;  // the other two, ascending
+        ax[1] = (forced & 1) ? o1 : o0;
+        ax[2] = (forced & 1) ? o0 : o1;
     }
 }
+// element `i` of a three-vector without indexing memory by a variable
+template <class T>
+__host__ __device__ inline T pick3(const T v[3], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
 
 // Device-resident description of the grid, written by k_grid_params from the pack kernel's
 // per-workgroup statistics.  The host never waits for it on the build path: launches are sized
@@ -134,8 +142,11 @@ struct Options {
     int host_pipe = 1;              // PCC_OPT_HOST_PIPE: clouds / results of 8 MB and more in pageable HOST memory cross PCIe through the library's own pinned
                                     // chunk buffers, staged by a few host threads (x, y, z only when the stride is 24 bytes or more); 0 = one
                                     // hipMemcpyAsync of the raw array (rounds 1-5)
-    int fuse_params = 1;            // PCC_OPT_FUSE_PARAMS: the grid parameters come out of the build's pack kernel (its last workgroup); 0 = k_grid_params,
-                                    // a launch of its own
+    int fuse_params = 0;            // PCC_OPT_FUSE_PARAMS (bits): 1 = the grid parameters come out of the build's pack kernel (its last workgroup to finish)
+                                    // instead of k_grid_params -- built in round 6 and a LOSS: the hand-over needs an agent-scope release fence in every
+                                    // workgroup, which on this chip writes the XCD's L2 back, in a kernel that has just dirtied 160 MB of it: build
+                                    // 0.437 -> 0.497 ms at C3, 0.089 -> 0.112 at C2 (EXPERIMENTS.md); 2 = a pass of pcc_icp_align is solved by the last
+                                    // workgroup of k_icp_sums (a kernel that writes 65 KB) instead of k_icp_solve
     int xcd_run = 256;              // PCC_OPT_XCD_RUN: consecutive workgroups of the k = 1 search steered to the same XCD (its L2).  32 until round 5;
                                     // with the layers of the grid a few rows apart (grid_axes) a run should hold several LAYERS, so that the rows of
                                     // the layer behind are re-read from the same L2: C3 fabric reads 2.18 -> 1.66 GB at 512, kernels 646 / 592 / 604 /

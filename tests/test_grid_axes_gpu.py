@@ -77,7 +77,7 @@ def test_knn_radius_clusters_under_every_axis_assignment(gpu, axes):
                 assert (idx[off[i]:off[i + 1]] == oi).all() and (_bits(d2[off[i]:off[i + 1]]) == _bits(od)).all(), (axes, r, i)
         fw = ix.first_within(qry, 0.05)
         assert (fw == oracle.first_within(ref, qry, 0.05)).all(), axes
-        for ec in (3, 1, 0):
+        for ec in (3, 4, 1, 0):
             ix.set_option(capi.OPT_EC_CELLS, ec)
             labels, ncl, sizes = ix.euclidean_clusters(0.05, 20, 250000)
             olabels, oncl, osizes = oracle.euclidean_clusters(ref, 0.05, 20, 250000)

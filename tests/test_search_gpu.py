@@ -107,10 +107,11 @@ def test_radius_boundary_is_strict(gpu):
     assert cnt[0] == 2
 
 
-@pytest.mark.parametrize("form", [3, 1, 2, 0])
+@pytest.mark.parametrize("form", [3, 4, 1, 2, 0])
 def test_euclidean_clusters_known_partition(gpu, form):
     """object layer only: the balls are the clusters by construction.  PCC_OPT_EC_CELLS: 3 = union-find over the cells
-    of the clique-cell grid (default), 1 = one parent per point with the lanes over a cell's neighbour cells, 2 = the same with
+    of the clique-cell grid, runs of touching cells along a row joined by stores (default), 4 = one union per cell and face
+    (round 5), 1 = one parent per point with the lanes over a cell's neighbour cells, 2 = the same with
     the lanes over points, 0 = per-point ball scan"""
     pts = synth.corridor_cloud(120000, synth.SEED_A, layer="objects")
     with capi.Index(pts) as ix:

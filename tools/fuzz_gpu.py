@@ -154,11 +154,17 @@ def main():
                 ix.set_option(capi.OPT_NN1_KERNEL, int(rng.integers(0, 4)))
                 ix.set_option(capi.OPT_NN1_OPEN_FLAT, int(rng.random() < 0.7))  # listed open lanes: drained flat / one lane each
                 ix.set_option(capi.OPT_KNN_KERNEL, int(rng.random() < 0.8))
-                ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([3, 3, 1, 2, 0])))
+                ix.set_option(capi.OPT_EC_CELLS, int(rng.choice([3, 3, 4, 1, 2, 0])))
                 if rng.random() < 0.2:
                     ix.set_option(capi.OPT_NN1_DENSE_MIN, int(rng.choice([1, 2, 1000000])))
                 # the staging of a search that follows the build directly: behind it / beside it on the second stream (2: at every size)
                 ix.set_option(capi.OPT_OVERLAP_PREP, int(rng.choice([0, 1, 2, 2])))
+                # round 6: the grid's axis assignment drawn per scene (-1: by extent), the XCD run, the fused grid parameters; the
+                # index is rebuilt under them (options that shape it act at the next set_input)
+                ix.set_option(capi.OPT_GRID_AXES, int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5])))
+                ix.set_option(capi.OPT_XCD_RUN, int(rng.choice([1, 32, 256, 4096])))
+                ix.set_option(capi.OPT_FUSE_PARAMS, int(rng.choice([0, 0, 1, 2, 3])))
+                ix.set_input(a)
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
                 check("nn1", (idx == oi).all() and (bits(d2) == bits(od)).all(), a=a, q=q, engine=engine)
