@@ -784,6 +784,14 @@ def main():
             step()
             ix.sync()
             best = min(best, time.perf_counter() - t0)
+        # the same step as rounds 1-5 took it: one hipMemcpyAsync of the raw pageable array each way (PCC_OPT_HOST_PIPE = 0)
+        ix.set_option(capi.OPT_HOST_PIPE, 0)
+        step()
+        ix.sync()
+        t0 = time.perf_counter()
+        step()
+        ix.sync()
+        plain = time.perf_counter() - t0
         ix.close()
         # PCIe: one pinned H2D of the raw cloud's size, one pinned D2H of the results' size
         pin = torch.empty(M * floats, dtype=torch.float32).pin_memory()
@@ -799,7 +807,8 @@ def main():
         raw = M * floats * 4
         del pin, dv, pin2
         torch.cuda.empty_cache()
-        return {"workload": f"{desc} from and to HOST memory (pageable)", "step_ms": best * 1e3, "set_input_ms": build * 1e3,
+        return {"workload": f"{desc} from and to HOST memory (pageable)", "step_ms": best * 1e3, "step_ms_plain_hipmemcpy": plain * 1e3,
+                "host_threads": int(os.environ.get("PCC_HOST_THREADS", min(8, max(2, (os.cpu_count() or 4) // 2)))), "set_input_ms": build * 1e3,
                 "nn1_ms": query * 1e3, "raw_bytes_per_cloud": raw, "pinned_h2d_GBps": raw / h2d / 1e9,
                 "pcie_floor_ms_raw": (2 * h2d + d2h) * 1e3,
                 "pcie_floor_ms_xyz_only": (2 * h2d * 12.0 / (floats * 4) + d2h) * 1e3}

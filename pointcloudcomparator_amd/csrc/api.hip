@@ -196,22 +196,18 @@ static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride,
             if (!ix->pipe) ix->pipe = new HostPipe();
             PCC_TRY(ix->pipe->upload(ix->stream, static_cast<const char*>(pts), n, stride, raw.as<char>(), dst_stride));
             stride = dst_stride;
-        } else if (ix->opt.host_pipe && bytes <= PIPE_CHUNK_BYTES) {
+        } else if (ix->opt.host_pipe && bytes <= SMALL_DIRECT_BYTES) {
             // SMALL clouds -- the reference's descriptor clouds, 4 ... 18 381 records of 128 bytes, up to 300 calls per comparison
             // (src/comparator.cpp:560-588): a hipMemcpyAsync from pageable memory makes the host wait for a staged copy (~15 us a
-            // piece).  The cloud is copied into the handle's pinned buffer instead (slot 0: indexed clouds, 1: query clouds) and,
-            // up to SMALL_DIRECT_BYTES, the pack kernel reads it from there across the link -- no copy command at all.
+            // piece).  Up to SMALL_DIRECT_BYTES the cloud is copied into the handle's pinned buffer instead (slot 0: indexed clouds,
+            // 1: query clouds) and the pack kernel reads it from there across the link -- no copy command at all.  (Between 1 and
+            // 8 MB the runtime's own staging is as good: 18 381 descriptors 244 us a call against 277 through the pinned buffer.)
             if (!ix->pipe) ix->pipe = new HostPipe();
             PCC_TRY(ix->pipe->init());
             const int slot = blk_stats ? 0 : 1;
             PCC_HIP(hipEventSynchronize(ix->pipe->ev[slot]));  // (whoever read this buffer last has finished: nearly always true already)
             memcpy(ix->pipe->buf[slot].p, pts, bytes);
             src = ix->pipe->buf[slot].p;
-            if (bytes > SMALL_DIRECT_BYTES) {
-                PCC_TRY(raw.reserve(n * stride));
-                PCC_HIP(hipMemcpyAsync(raw.p, src, bytes, hipMemcpyHostToDevice, ix->stream));
-                src = raw.p;
-            }
             PCC_TRY(launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd, grid));
             PCC_HIP(hipEventRecord(ix->pipe->ev[slot], ix->stream));
             return PCC_OK;

@@ -546,7 +546,6 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int k_prev = 1;  // half-width of the cube the wave's previous query ended with (wave-uniform)
     for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
@@ -560,13 +559,10 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             if (lane == 0) fb_list[atomicAdd(fb_count, 1u)] = qi;
         };
         // the smallest cube that holds at least 2 x `want` points (as k_grid_knn_wave).  A lane looks after rows `lane` and
-        // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1.
-        // The search starts ONE BELOW the cube the wave's previous query needed (the wave's queries follow each other in cell
-        // order, nwaves apart: the density around them changes slowly) instead of at 3 x 3 x 3 every time -- in the sparse
-        // half of the corridor scene every query went through 3, 5 and 7 cells a side, ~30 instructions and two dependent
-        // loads per step.  Any starting cube is exact: the passes below only need SOME cube with >= `want` points.
-        int k = k_prev > 1 ? k_prev - 1 : 1;
-        bool came_in_wide = k > 1;  // (a start above 1 that holds far more than needed -- sparse to dense -- goes back to 1)
+        // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1
+        // (round 6, measured and removed: starting one below the cube of the wave's previous query instead of at 3 x 3 x 3 --
+        // K = 51 at 1M 1154 / 1140 us against 1155 / 1156: the sizing rounds are not what the kernel waits for, EXPERIMENTS.md)
+        int k = 1;
         unsigned int cnt = 0, rs0[RL], rc[RL];
         for (;; ++k) {
             const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
@@ -589,13 +585,8 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 mine += rc[i];
             }
             cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(mine), 63);
-            if (came_in_wide) {
-                came_in_wide = false;
-                if (cnt > 4u * (unsigned int)want) { k = 0; continue; }  // (the loop's ++k makes it 1)
-            }
             if (cnt >= 2u * (unsigned int)want || k >= KSEL) break;  // (the table's rows)
         }
-        k_prev = k;
         if (cnt < (unsigned int)want || cnt > (STORE ? (unsigned int)CAP : SEL_FLAT_CAP)) { give_up(); continue; }
         int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
         int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);

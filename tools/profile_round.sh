@@ -4,7 +4,7 @@
 # One rocprofv3 pass per kind: --kernel-trace --stats for durations, --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
 # passes (MI355X_MICROARCH.md: they do not fit one pass), never combined with other trace domains.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 S=$O/summary
@@ -22,6 +22,16 @@ for c in c2 c3 c4 c5 c5_shard; do
   echo "pmc $c done"
 done
 cp profiles/${TAG}_pmc_traffic.json $S/
+# the C3 step on ONE stream (query staging behind the build): per-pass durations and bytes that can be ranked
+export PCC_OVERLAP_PREP=0
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3_serial -- python3 bench.py --config c3 --no-cpu --no-pairs --no-exhaustive > $O/trace_c3_serial.json 2> $O/trace_c3_serial.err
+cp $(find $O/trace_c3_serial -name "*kernel_stats.csv" | head -1) $S/${TAG}_c3_serial_kernel_stats.csv
+for k in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $k --kernel-trace --output-format csv -d $O/pmc_c3_serial_$k -- python3 bench.py --config c3 --steps 6 --warmup 2 --no-cpu --no-exhaustive --no-pairs > $O/pmc_c3_serial_$k.json 2> $O/pmc_c3_serial_$k.err
+done
+unset PCC_OVERLAP_PREP
+python3 tools/pass_table.py $S/${TAG}_c3_serial_kernel_stats.csv $O/pmc_c3_serial_FETCH_SIZE $O/pmc_c3_serial_WRITE_SIZE $S/${TAG}_c3_serial_pass_table.txt > $O/pass_table.log
+echo "serial trace done"
 # the unprofiled default run last: its roofline.traffic is read from the PMC file written just above
 python3 bench.py > $S/${TAG}_bench_default.json 2> $O/bench_default.err
 echo "default bench done"
@@ -40,4 +50,6 @@ bash tools/pmc_flat.sh 1 1e7 both 1 2 3 4 > $O/pmcf_c3.log 2>&1
 mv gpurun_out/pmcf_1_both $O/pmcf_c3
 bash tools/pmc_flat.sh 1 1e6 both 1 2 3 4 > $O/pmcf_c2.log 2>&1
 mv gpurun_out/pmcf_1_both $O/pmcf_c2
+bash tools/pmc_cmd.sh knn51 k_grid_knn_sel "1 2 3 4" python3 tools/exp_knn.py 1e6 51 > $O/pmc_knn.log 2>&1
+cp gpurun_out/pmc_knn51/derived.json $S/${TAG}_knn_counters.json
 python3 tools/nn1_counters.py $S/${TAG}_nn1_counters.json c3_flat2=$O/pmcf_c3:k_grid_nn1_flat2 c3_open=$O/pmcf_c3:k_nn1_open c2_flat2=$O/pmcf_c2:k_grid_nn1_flat2 > $O/nn1_counters.log
