@@ -41,15 +41,15 @@ oracle/_build/libpcc_oracle.so: oracle/pcc_oracle.c oracle/pcc_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread -o $@ oracle/pcc_oracle.c -lm
 
-build/ubench_gather: $(CSRC)/ubench_gather.hip
+build/ubench_gather: tools/ubench/ubench_gather.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
-build/ubench_scatter: $(CSRC)/ubench_scatter.hip
+build/ubench_scatter: tools/ubench/ubench_scatter.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
-build/ubench_valu: $(CSRC)/ubench_valu.hip
+build/ubench_valu: tools/ubench/ubench_valu.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 

@@ -1437,7 +1437,7 @@ int pcc::icp_align_impl(pcc_index* ix, const pcc::IcpHooks* hooks, const void* s
         PCC_TRY(ix->icp_src.reserve(n * sizeof(float4)));
         // Round 5: the loop's working set in the target grid's CELL order.  Nothing of the loop leaves per point -- T, fitness,
         // counts -- so the permutation that a search pays per call (queries gathered through the sort order, keys scattered
-        // back: ~60 us of a 215-us pass at 2M points, csrc/ubench_scatter.hip) is paid ONCE: the source is sorted by the
+        // back: ~60 us of a 215-us pass at 2M points, tools/ubench/ubench_scatter.hip) is paid ONCE: the source is sorted by the
         // cell it starts in, gathered into that order, and every pass reads it front to back with the identity as its order
         // (a rigid motion keeps neighbouring points neighbours; any order is correct, as before).  The sums are added up in
         // this order by every form of the loop -- device-resident, host-driven, sharded -- so they agree with each other to

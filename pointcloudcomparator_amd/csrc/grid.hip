@@ -413,13 +413,8 @@ k_grid_nn1(const float4* __restrict__ cell_refs, const unsigned int* __restrict_
 // ends of neighbouring spans, a few positions apart, go to different words (the atomic ORs that set them do not
 // collide: with one word per 64 positions half of the LDS cycles were conflicts), lane l's word serves 32 consecutive
 // windows, and a window's mask is a ballot of one bit test.
-// PCC_ABLATE (development builds only: tools/exp_ablate.sh; the results are WRONG, only the kernel time is read -- the table of
-// DESIGN.md 4.2, round 5): bit 0 drops pass 1, bit 1 pass 0, bit 2 every drain loop, bit 3 the open-lane listing (every lane counts
-// as resolved), bit 5 stores the key at out[t] instead of out[order[t]], bit 6 reads q[t] instead of q[order[t]], bit 7 drops the
-// row-bound gathers.  11 = the kernel's skeleton (order -> query gather -> own-row bounds -> key scatter), 235 = the same streamed.
-#ifndef PCC_ABLATE
-#define PCC_ABLATE 0
-#endif
+// (The ablation builds behind profiles/r05_nn1_ablation.txt -- parts of this kernel compiled out to price them -- are a patch
+// applied to a scratch copy of this file: tools/exp_ablate.sh + tools/exp_ablate.patch.  None of it lives here.)
 constexpr int FLAT_PLANES = 4;
 constexpr int FLAT_CAP = FLAT_PLANES * 2048;  // candidates one flat pass can hold; larger passes fall back to the lane walk
 
@@ -522,7 +517,6 @@ __device__ __forceinline__ void flat2_pass(FW& fw, const float4* __restrict__ ce
         }
     };
     const unsigned int nfull = (T >> 6) / B * B;
-    if (!(PCC_ABLATE & 4))
     for (unsigned int p0 = 0; p0 < nwin; p0 += 32) {
         word = fw.ends[p0 >> 5][lane];
         const unsigned int pend = min(p0 + 32u, nwin);
@@ -567,9 +561,8 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
     float4 qv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     if (t < ns) {
         qi = order ? order[t] : t;
-        qv = q[(PCC_ABLATE & 64) ? t : qi];
+        qv = q[qi];
     }
-    if (PCC_ABLATE & 32) qi = t;
     const bool active = __float_as_int(qv.w) >= 0;
     // ICP passes in cell order (pcc_index::pre_transform): the previous pass's rigid motion is applied HERE, to the query the lane
     // has just read, and written back for the kernels that follow (open lanes, far walk, sums) -- pcl::transformPointCloud's
@@ -611,7 +604,7 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
         // inside their predicate; the selects afterwards)
         auto row_load = [&](int i, bool wanted) -> uint4 {
             uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
-            if (wanted & active & ok_y[i % 3] & ok_z[i / 3] & !(PCC_ABLATE & 128)) {  // (one predicate, one branch)
+            if (wanted & active & ok_y[i % 3] & ok_z[i / 3]) {  // (one predicate, one branch)
                 const int delta = ((i / 3 - 1) * g.dim[1] + (i % 3 - 1)) * g.dim[0];
                 b4 = *reinterpret_cast<const uint4*>(cell_start + (rowc + (unsigned int)delta));
             }
@@ -639,11 +632,11 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
         // dense wave: >= dense_min references per own cell on average
         const unsigned int own_cells = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(oB - oA), 63);
         const bool dense = own_cells >= 64u * dense_min;
-        if (!(PCC_ABLATE & 2)) {
+        {
             unsigned int s1[1] = {dense ? oA : oL}, l1[1] = {dense ? oB - oA : oR - oL};
             flat2_pass<1, U, B, true>(fw, cell_refs, s1, l1, lane);
         }
-        if (!(PCC_ABLATE & 1)) {
+        {
             const float bd = __uint_as_float((unsigned int)(fw.best[lane] >> 32));  // (NaN while nothing is found: every test below keeps its span)
             fw.q[lane].w = bd;  // the flat drain's pre-filter (read with the query, no extra LDS access)
             unsigned int sp[F2_R], ln[F2_R];
@@ -673,7 +666,6 @@ k_grid_nn1_flat2(const float4* __restrict__ cell_refs, const unsigned int* __res
         if (active) {
             const float bd = __uint_as_float((unsigned int)(best >> 32));
             if (best != ~0ull && (bd < lb2 || lb2 == __builtin_inff())) resolved = true;
-            if (PCC_ABLATE & 8) resolved = true;
         }
     }
     if (OPENK) {
