@@ -102,8 +102,14 @@ struct HostPipe {
     // n points of `stride` bytes at `src` (pageable host memory) -> device `dst`, packed to `dst_stride` bytes per point
     // (dst_stride == stride: plain copy; dst_stride == 12: x, y, z only).  Enqueued on `s`; returns when the last chunk's DMA
     // has been enqueued and its source buffer is safe (the caller's memory is no longer read).
+    // whoever used the two buffers last -- a small cloud's pack kernel reads its buffer in place (api.hip) -- has finished
+    int buffers_free() {
+        for (int b = 0; b < 2; ++b) PCC_HIP(hipEventSynchronize(ev[b]));
+        return PCC_OK;
+    }
     int upload(hipStream_t s, const char* src, size_t n, size_t stride, char* dst, size_t dst_stride) {
         PCC_TRY(init());
+        PCC_TRY(buffers_free());
         const size_t per_chunk = PIPE_CHUNK_BYTES / dst_stride;
         const size_t nchunks = (n + per_chunk - 1) / per_chunk;
         const bool gather = dst_stride != stride;
@@ -144,6 +150,7 @@ struct HostPipe {
     // bytes at device `src` -> pageable host `dst`; everything enqueued on `s` before is waited for (the first DMA is behind it)
     int download(hipStream_t s, const char* src, char* dst, size_t bytes) {
         PCC_TRY(init());
+        PCC_TRY(buffers_free());
         const size_t nchunks = (bytes + PIPE_CHUNK_BYTES - 1) / PIPE_CHUNK_BYTES;
         auto drain = [=](size_t c, int tid, int nt) {
             const size_t o0 = c * PIPE_CHUNK_BYTES, cnt = (o0 + PIPE_CHUNK_BYTES <= bytes ? PIPE_CHUNK_BYTES : bytes - o0);
