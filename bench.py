@@ -808,7 +808,7 @@ def main():
         del pin, dv, pin2
         torch.cuda.empty_cache()
         return {"workload": f"{desc} from and to HOST memory (pageable)", "step_ms": best * 1e3, "step_ms_plain_hipmemcpy": plain * 1e3,
-                "host_threads": int(os.environ.get("PCC_HOST_THREADS", min(12, max(2, (os.cpu_count() or 4) // 2)))), "set_input_ms": build * 1e3,
+                "host_threads": int(os.environ.get("PCC_HOST_THREADS", min(8, max(2, (os.cpu_count() or 4) // 2)))), "set_input_ms": build * 1e3,
                 "nn1_ms": query * 1e3, "raw_bytes_per_cloud": raw, "pinned_h2d_GBps": raw / h2d / 1e9,
                 "pcie_floor_ms_raw": (2 * h2d + d2h) * 1e3,
                 "pcie_floor_ms_xyz_only": (2 * h2d * 12.0 / (floats * 4) + d2h) * 1e3}

@@ -20,7 +20,8 @@
 namespace pcc {
 
 constexpr size_t PIPE_MIN_BYTES = 8u << 20;   // transfers from here on are pipelined
-constexpr size_t PIPE_CHUNK_BYTES = 8u << 20;  // pinned bytes per chunk (two buffers)
+constexpr size_t PIPE_CHUNK_BYTES = 8u << 20;  // pinned bytes per chunk (two buffers), at least; transfers of 8 chunks and more use PIPE_CHUNK_BIG
+constexpr size_t PIPE_CHUNK_BIG = 32u << 20;
 constexpr size_t SMALL_DIRECT_BYTES = 1u << 20;  // a host cloud up to here is read by the pack kernel straight from its pinned copy
 constexpr size_t SMALL_RESULT_BYTES = 1u << 20;  // a host result array up to here is written by the unpack kernel straight into pinned memory
 
@@ -82,12 +83,22 @@ private:
     std::vector<std::thread> helpers_;
 };
 
+// chunk size of a transfer of `bytes`: large transfers take large chunks (every chunk costs a fork-join of the crew, a copy command and an
+// event: ~0.1 ms)
+inline size_t pipe_chunk_bytes(size_t bytes) {
+    if (const char* e = getenv("PCC_PIPE_CHUNK_MB")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 256) return (size_t)v << 20;
+    }
+    return bytes >= 8 * PIPE_CHUNK_BYTES ? PIPE_CHUNK_BIG : PIPE_CHUNK_BYTES;
+}
+
 struct HostPipe {
     HostBuf buf[2];
     hipEvent_t ev[2] = {nullptr, nullptr};
-    int init() {
+    int init(size_t chunk = PIPE_CHUNK_BYTES) {
         for (int b = 0; b < 2; ++b) {
-            PCC_TRY(buf[b].reserve(PIPE_CHUNK_BYTES));
+            PCC_TRY(buf[b].reserve(chunk));
             if (!ev[b]) PCC_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
         }
         return PCC_OK;
@@ -104,13 +115,15 @@ struct HostPipe {
     // has been enqueued and its source buffer is safe (the caller's memory is no longer read).
     // whoever used the two buffers last -- a small cloud's pack kernel reads its buffer in place (api.hip) -- has finished
     int buffers_free() {
-        for (int b = 0; b < 2; ++b) PCC_HIP(hipEventSynchronize(ev[b]));
+        for (int b = 0; b < 2; ++b)
+            if (ev[b]) PCC_HIP(hipEventSynchronize(ev[b]));
         return PCC_OK;
     }
     int upload(hipStream_t s, const char* src, size_t n, size_t stride, char* dst, size_t dst_stride) {
-        PCC_TRY(init());
-        PCC_TRY(buffers_free());
-        const size_t per_chunk = PIPE_CHUNK_BYTES / dst_stride;
+        const size_t CH = pipe_chunk_bytes(n * dst_stride);
+        PCC_TRY(buffers_free());  // (before a reserve that may free them)
+        PCC_TRY(init(CH));
+        const size_t per_chunk = CH / dst_stride;
         const size_t nchunks = (n + per_chunk - 1) / per_chunk;
         const bool gather = dst_stride != stride;
         auto fill = [=](size_t c, int tid, int nt) {
@@ -149,17 +162,18 @@ struct HostPipe {
 
     // bytes at device `src` -> pageable host `dst`; everything enqueued on `s` before is waited for (the first DMA is behind it)
     int download(hipStream_t s, const char* src, char* dst, size_t bytes) {
-        PCC_TRY(init());
+        const size_t CH = pipe_chunk_bytes(bytes);
         PCC_TRY(buffers_free());
-        const size_t nchunks = (bytes + PIPE_CHUNK_BYTES - 1) / PIPE_CHUNK_BYTES;
+        PCC_TRY(init(CH));
+        const size_t nchunks = (bytes + CH - 1) / CH;
         auto drain = [=](size_t c, int tid, int nt) {
-            const size_t o0 = c * PIPE_CHUNK_BYTES, cnt = (o0 + PIPE_CHUNK_BYTES <= bytes ? PIPE_CHUNK_BYTES : bytes - o0);
+            const size_t o0 = c * CH, cnt = (o0 + CH <= bytes ? CH : bytes - o0);
             const size_t a = (cnt * (size_t)tid / (size_t)nt) & ~(size_t)63, b = tid + 1 == nt ? cnt : (cnt * (size_t)(tid + 1) / (size_t)nt) & ~(size_t)63;
             if (b > a) memcpy(dst + o0 + a, buf[c & 1].as<char>() + a, b - a);
         };
         ChunkCrew crew(pipe_threads(), drain);
         auto enqueue = [&](size_t c) -> int {
-            const size_t o0 = c * PIPE_CHUNK_BYTES, cnt = (o0 + PIPE_CHUNK_BYTES <= bytes ? PIPE_CHUNK_BYTES : bytes - o0);
+            const size_t o0 = c * CH, cnt = (o0 + CH <= bytes ? CH : bytes - o0);
             PCC_HIP(hipMemcpyAsync(buf[c & 1].p, src + o0, cnt, hipMemcpyDeviceToHost, s));
             PCC_HIP(hipEventRecord(ev[c & 1], s));
             return PCC_OK;
