@@ -1,9 +1,9 @@
 // host_pipe.hpp -- clouds and results between PAGEABLE host memory and the device, for api.hip (host code only).
 //
 // Every drop-in call site of the reference starts from host vectors (src/comparator.cpp:1119,1130 load the clouds to
-// host memory; :571-577 hand std::vectors over).  A hipMemcpyAsync from pageable memory is staged by the runtime through
-// one pinned bounce buffer by ONE thread: ~10 GB/s, a fifth of what the PCIe link carries -- 10M XYZRGB points (320 MB)
-// took 30 ms to arrive for a 1.3-ms step.  Here the staging is done by the library:
+// host memory; :571-577 hand std::vectors over).  A hipMemcpyAsync from pageable memory moves the RAW array: 10M XYZRGB
+// points are 320 MB for 120 MB of coordinates, 6.2 ms per cloud at the ~52 GB/s the runtime's staging reaches (a C3 step from and
+// to host memory: 14.4 ms for 1.3 ms of device work).  Here the staging is done by the library:
 //   upload   : a few host threads gather the cloud chunk by chunk into two pinned buffers -- only the 12 bytes of x, y, z
 //              of every point when the stride is 24 bytes or more (PointXYZRGB: 12 of 32) -- and each chunk's DMA runs while
 //              the next one is being gathered; the pack kernel then reads a 12-byte-stride cloud.
@@ -20,8 +20,7 @@
 namespace pcc {
 
 constexpr size_t PIPE_MIN_BYTES = 8u << 20;   // transfers from here on are pipelined
-constexpr size_t PIPE_CHUNK_BYTES = 8u << 20;  // pinned bytes per chunk (two buffers), at least; transfers of 8 chunks and more use PIPE_CHUNK_BIG
-constexpr size_t PIPE_CHUNK_BIG = 32u << 20;
+constexpr size_t PIPE_CHUNK_BYTES = 8u << 20;  // pinned bytes per chunk (two buffers)
 constexpr size_t SMALL_DIRECT_BYTES = 1u << 20;  // a host cloud up to here is read by the pack kernel straight from its pinned copy
 constexpr size_t SMALL_RESULT_BYTES = 1u << 20;  // a host result array up to here is written by the unpack kernel straight into pinned memory
 
@@ -36,7 +35,7 @@ inline int pipe_threads() {
     if (hw == 0) hw = 4;
     unsigned int t = hw / 2;
     if (t < 2) t = 2;
-    if (t > 12) t = 12;  // (a GPU's share of the host is 16 cores on the boxes this runs on; 8 threads gather 82 GB/s, see exp_host.py)
+    if (t > 8) t = 8;  // (4 threads already gather at the host's memory bandwidth, ~80 GB/s: tools/exp_host.py)
     if (const char* e = getenv("PCC_HOST_THREADS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) t = (unsigned int)v;
@@ -83,14 +82,15 @@ private:
     std::vector<std::thread> helpers_;
 };
 
-// chunk size of a transfer of `bytes`: large transfers take large chunks (every chunk costs a fork-join of the crew, a copy command and an
-// event: ~0.1 ms)
-inline size_t pipe_chunk_bytes(size_t bytes) {
+// chunk size of a transfer (PCC_PIPE_CHUNK_MB: measurements only).  C3 from host memory, 10M XYZRGB points, step ms at 8 / 16 / 32 / 64 MB:
+// 9.4-10.0 / 9.6-9.8 / 10.6-11.1 / 11.6-12.0 -- larger chunks overlap less at both ends; 4 / 8 / 12 / 16 / 24 threads: 10.1 / 10.2 / 10.7 /
+// 10.9 / 11.8: the gather is bound by the host's memory bandwidth (320 MB read in ~4 ms), not by the number of threads.
+inline size_t pipe_chunk_bytes(size_t) {
     if (const char* e = getenv("PCC_PIPE_CHUNK_MB")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 256) return (size_t)v << 20;
     }
-    return bytes >= 8 * PIPE_CHUNK_BYTES ? PIPE_CHUNK_BIG : PIPE_CHUNK_BYTES;
+    return PIPE_CHUNK_BYTES;
 }
 
 struct HostPipe {
