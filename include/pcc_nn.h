@@ -182,11 +182,14 @@ enum pcc_option {
     PCC_OPT_FUSE_PARAMS = 20,    /* bits: 1 = index build: the grid (cell edge, dimensions, axes) is derived by the last workgroup of the
                                     pack kernel to finish instead of a kernel of its own behind it; 2 = a pass of pcc_icp_align is solved
                                     by the last workgroup of its sums kernel.  Default 0: see DESIGN.md 4.3 (both were measured) */
-    PCC_OPT_HOST_PIPE = 21       /* PCC_MEM_HOST clouds and results of 8 MB and more in PAGEABLE memory: 1 = staged by the library
+    PCC_OPT_HOST_PIPE = 21,      /* PCC_MEM_HOST clouds and results of 8 MB and more in PAGEABLE memory: 1 = staged by the library
                                     through two pinned chunk buffers by a few host threads (PCC_HOST_THREADS, default half the
                                     cores, at most 8), the DMA of a chunk running while the next is gathered; only x, y, z cross
                                     the link when the stride is 24 bytes or more (default); 0 = one hipMemcpyAsync of the raw
                                     array.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) is always copied directly */
+    PCC_OPT_SCAN_CHAINED = 22    /* exclusive scans inside the sorts: 1 = one launch, workgroups hand their totals forward through tagged
+                                    64-bit atomics (default); 0 = two launches (totals, then apply) that wait for nothing -- for
+                                    environments where workgroups are not dispatched in order (preemption, shared devices) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

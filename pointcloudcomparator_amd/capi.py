@@ -19,7 +19,7 @@ KNN_MAX_K = 65536
 # enum pcc_option
 (OPT_GRID_PPC, OPT_GRID_TRIM, OPT_FAR_MODE, OPT_ICP_WARM, OPT_ICP_DEVICE_LOOP, OPT_EC_CELLS, OPT_SORT_MP_MIN,
  OPT_SORT_MP_MIN_Q, OPT_NN1_KERNEL, OPT_FLANN_SPLIT, OPT_NN1_DENSE_MIN, OPT_KNN_KERNEL, OPT_KNN_CACHE_K, OPT_NN1_OPEN_FLAT, OPT_SORT_STAGE1,
- OPT_ICP_SORTED, OPT_OVERLAP_PREP, OPT_GRID_AXES, OPT_XCD_RUN, OPT_FUSE_PARAMS, OPT_HOST_PIPE) = range(1, 22)
+ OPT_ICP_SORTED, OPT_OVERLAP_PREP, OPT_GRID_AXES, OPT_XCD_RUN, OPT_FUSE_PARAMS, OPT_HOST_PIPE, OPT_SCAN_CHAINED) = range(1, 23)
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PCC_LIB", _HERE / "lib" / "libpcc_nn.so"))
@@ -248,7 +248,14 @@ def sor_threshold(sums, n_valid: int, mean_k: int = 50, stddev_mult: float = 1.5
 
 
 class Index:
-    """Owner of one pcc_index handle (the role pcl::KdTreeFLANN plays in the reference)."""
+    """Owner of one pcc_index handle (the role pcl::KdTreeFLANN plays in the reference).
+
+    auto_sync (default on): every call on torch CUDA tensors is bracketed with pcc_index_wait_stream / pcc_stream_wait_index
+    against torch's current stream, so `ix.nn1(x * s)` reads finished data and `idx.cpu()` sees the result.  The bracket AFTER
+    set_input makes torch's stream wait for the whole build, and the next call's bracket makes the library wait for torch's
+    stream again: with auto_sync on, the query staging beside the build (PCC_OPT_OVERLAP_PREP) therefore hides nothing -- correct,
+    only serial.  Callers that time or pipeline (bench.py) pass auto_sync=False and order the streams themselves (sync(),
+    wait_stream(), stream_wait())."""
 
     @classmethod
     def broadcast(cls, comm: "Comm", root: int, points=None, engine: int = ENGINE_AUTO, auto_sync: bool = True):

@@ -51,7 +51,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
         case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
         case PCC_OPT_FUSE_PARAMS: return value >= 0 && value <= 3;
-        case PCC_OPT_HOST_PIPE: return value == 0 || value == 1;
+        case PCC_OPT_HOST_PIPE: case PCC_OPT_SCAN_CHAINED: return value == 0 || value == 1;
         default: return value == 0 || value == 1;
     }
 }
@@ -79,6 +79,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_XCD_RUN: *as_int = &o.xcd_run; return nullptr;
         case PCC_OPT_FUSE_PARAMS: *as_int = &o.fuse_params; return nullptr;
         case PCC_OPT_HOST_PIPE: *as_int = &o.host_pipe; return nullptr;
+        case PCC_OPT_SCAN_CHAINED: *as_int = &o.scan_chained; return nullptr;
         default: return nullptr;
     }
 }
@@ -94,7 +95,8 @@ void Options::from_env() {
         {"PCC_KNN_CACHE_K", PCC_OPT_KNN_CACHE_K}, {"PCC_NN1_OPEN_FLAT", PCC_OPT_NN1_OPEN_FLAT}, {"PCC_SORT_STAGE1", PCC_OPT_SORT_STAGE1},
         {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}, {"PCC_OVERLAP_PREP", PCC_OPT_OVERLAP_PREP},
         {"PCC_GRID_AXES", PCC_OPT_GRID_AXES}, {"PCC_XCD_RUN", PCC_OPT_XCD_RUN},
-        {"PCC_FUSE_PARAMS", PCC_OPT_FUSE_PARAMS}, {"PCC_HOST_PIPE", PCC_OPT_HOST_PIPE}};
+        {"PCC_FUSE_PARAMS", PCC_OPT_FUSE_PARAMS}, {"PCC_HOST_PIPE", PCC_OPT_HOST_PIPE},
+        {"PCC_SCAN_CHAINED", PCC_OPT_SCAN_CHAINED}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;

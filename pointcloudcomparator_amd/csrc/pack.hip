@@ -332,7 +332,7 @@ static int scan_rec(hipStream_t s, unsigned int* data, size_t n, unsigned int* t
 int launch_exclusive_scan(pcc_index* ix, hipStream_t s, unsigned int* data, size_t n, DevBuf& tmp) {
     if (n == 0) return PCC_OK;
     const size_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (ix && nb > 1 && nb <= SCAN_CHAIN_MAX) {
+    if (ix && ix->opt.scan_chained && nb > 1 && nb <= SCAN_CHAIN_MAX) {
         if (!ix->scan_flags.p) {  // (zeroed once: epochs start at 1)
             PCC_TRY(ix->scan_flags.reserve(SCAN_CHAIN_MAX * sizeof(unsigned long long)));
             PCC_HIP(hipMemsetAsync(ix->scan_flags.p, 0, SCAN_CHAIN_MAX * sizeof(unsigned long long), s));

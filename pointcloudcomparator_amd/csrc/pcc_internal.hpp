@@ -139,6 +139,9 @@ struct Options {
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
                                     // shortest, shortest, longest); 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
+    int scan_chained = 1;           // PCC_OPT_SCAN_CHAINED: exclusive scans of up to 512 x 2048 counters in ONE launch (workgroups pass their totals on as
+                                    // tagged 64-bit atomics and wait for the workgroups in front of them: relies on in-order dispatch); 0 = the two-launch
+                                    // form (block totals, then apply), which waits for nothing
     int host_pipe = 1;              // PCC_OPT_HOST_PIPE: clouds / results of 8 MB and more in pageable HOST memory cross PCIe through the library's own pinned
                                     // chunk buffers, staged by a few host threads (x, y, z only when the stride is 24 bytes or more); 0 = one
                                     // hipMemcpyAsync of the raw array (rounds 1-5)

@@ -493,9 +493,12 @@ def test_voxel_grid_sizes_around_the_scan_forms(gpu, n):
     with capi.Index(pts[:64]) as ctx:
         out = ctx.voxel_grid(pts, 0.05)
         again = ctx.voxel_grid(pts, 0.05)          # (a second scan on the handle: the next epoch over the same flag words)
+        ctx.set_option(capi.OPT_SCAN_CHAINED, 0)   # the two-launch scan kept reachable (round 6): same voxels
+        plain = ctx.voxel_grid(pts, 0.05)
     ref, nv = oracle.voxel_grid(pts, 0.05)
-    assert len(out) == nv == len(again)
+    assert len(out) == nv == len(again) == len(plain)
     assert np.allclose(out[:, :3], ref[:, :3], rtol=0, atol=1e-4) and (out.view(np.uint32) == again.view(np.uint32)).all()
+    assert (out.view(np.uint32) == plain.view(np.uint32)).all()
 
 
 def test_voxel_grid_refuses_absurd_leaf(gpu):
