@@ -187,9 +187,13 @@ enum pcc_option {
                                     cores, at most 8), the DMA of a chunk running while the next is gathered; only x, y, z cross
                                     the link when the stride is 24 bytes or more (default); 0 = one hipMemcpyAsync of the raw
                                     array.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) is always copied directly */
-    PCC_OPT_SCAN_CHAINED = 22    /* exclusive scans inside the sorts: 1 = one launch, workgroups hand their totals forward through tagged
+    PCC_OPT_SCAN_CHAINED = 22,   /* exclusive scans inside the sorts: 1 = one launch, workgroups hand their totals forward through tagged
                                     64-bit atomics (default); 0 = two launches (totals, then apply) that wait for nothing -- for
                                     environments where workgroups are not dispatched in order (preemption, shared devices) */
+    PCC_OPT_KNN_RUN = 23         /* k-NN selection (k <= 512): a wave takes this many consecutive queries of the cell-sorted order in a
+                                    row; every query after the first of its run starts from a bound -- its predecessor's K-th distance
+                                    plus their separation (the K-th neighbour distance is 1-Lipschitz) -- and skips the cube sizing,
+                                    the bucket histogram and the compaction (default 8; 1 = every query on its own, round 5) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -19,7 +19,7 @@ KNN_MAX_K = 65536
 # enum pcc_option
 (OPT_GRID_PPC, OPT_GRID_TRIM, OPT_FAR_MODE, OPT_ICP_WARM, OPT_ICP_DEVICE_LOOP, OPT_EC_CELLS, OPT_SORT_MP_MIN,
  OPT_SORT_MP_MIN_Q, OPT_NN1_KERNEL, OPT_FLANN_SPLIT, OPT_NN1_DENSE_MIN, OPT_KNN_KERNEL, OPT_KNN_CACHE_K, OPT_NN1_OPEN_FLAT, OPT_SORT_STAGE1,
- OPT_ICP_SORTED, OPT_OVERLAP_PREP, OPT_GRID_AXES, OPT_XCD_RUN, OPT_FUSE_PARAMS, OPT_HOST_PIPE, OPT_SCAN_CHAINED) = range(1, 23)
+ OPT_ICP_SORTED, OPT_OVERLAP_PREP, OPT_GRID_AXES, OPT_XCD_RUN, OPT_FUSE_PARAMS, OPT_HOST_PIPE, OPT_SCAN_CHAINED, OPT_KNN_RUN) = range(1, 24)
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PCC_LIB", _HERE / "lib" / "libpcc_nn.so"))

@@ -51,6 +51,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
         case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
         case PCC_OPT_FUSE_PARAMS: return value >= 0 && value <= 3;
+        case PCC_OPT_KNN_RUN: return value >= 1 && value <= 64;
         case PCC_OPT_HOST_PIPE: case PCC_OPT_SCAN_CHAINED: return value == 0 || value == 1;
         default: return value == 0 || value == 1;
     }
@@ -80,6 +81,7 @@ static double* option_slot(Options& o, int option, int** as_int) {
         case PCC_OPT_FUSE_PARAMS: *as_int = &o.fuse_params; return nullptr;
         case PCC_OPT_HOST_PIPE: *as_int = &o.host_pipe; return nullptr;
         case PCC_OPT_SCAN_CHAINED: *as_int = &o.scan_chained; return nullptr;
+        case PCC_OPT_KNN_RUN: *as_int = &o.knn_run; return nullptr;
         default: return nullptr;
     }
 }
@@ -96,7 +98,7 @@ void Options::from_env() {
         {"PCC_ICP_SORTED", PCC_OPT_ICP_SORTED}, {"PCC_OVERLAP_PREP", PCC_OPT_OVERLAP_PREP},
         {"PCC_GRID_AXES", PCC_OPT_GRID_AXES}, {"PCC_XCD_RUN", PCC_OPT_XCD_RUN},
         {"PCC_FUSE_PARAMS", PCC_OPT_FUSE_PARAMS}, {"PCC_HOST_PIPE", PCC_OPT_HOST_PIPE},
-        {"PCC_SCAN_CHAINED", PCC_OPT_SCAN_CHAINED}};
+        {"PCC_SCAN_CHAINED", PCC_OPT_SCAN_CHAINED}, {"PCC_KNN_RUN", PCC_OPT_KNN_RUN}};
     for (const auto& v : vars) {
         const char* txt = getenv(v.name);
         if (!txt || !*txt) continue;

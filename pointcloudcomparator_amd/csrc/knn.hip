@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256)
 k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restrict__ cell_start,
                const GridDev* __restrict__ gd, const float4* __restrict__ q, const unsigned int* __restrict__ order,
                const unsigned int* __restrict__ n_sorted_ptr, int K, KnnOut out,
-               unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+               unsigned int* __restrict__ fb_list, unsigned int* __restrict__ fb_count, unsigned int KNN_RUN) {
     constexpr unsigned int SCAP = SCAP_;
     constexpr int CAP = 2 * SCAP_;
     constexpr bool BIG = SCAP_ > 256;
@@ -546,7 +546,19 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
+    // Round 6: a wave takes RUNS of KNN_RUN consecutive queries of the cell-sorted order (runs dealt out strided over the waves, as
+    // single queries were).  The K-th neighbour distance is 1-Lipschitz in the query: r_K(q) <= r_K(p) + |q - p|.  So every query
+    // after the first of its run starts from a BOUND -- its predecessor's K-th distance plus their separation -- and needs neither the
+    // sizing rounds, nor the bucket histogram that finds a bound, nor the compaction behind it: one table over the box of that ball,
+    // one walk that keeps what lies inside, the sort.  Exact whatever the bound: the walk collects EVERY reference with d2 <= bound
+    // inside a box that covers the ball; with at least `want` of them their `want` smallest are the answer, with fewer (the bound
+    // came from rounded arithmetic, or the predecessor gave up) the query takes the full path below.
+    // (KNN_RUN: PCC_OPT_KNN_RUN, default 8; 1 = every query takes the full path, round 5's kernel)
+    constexpr float sep_max_ratio = 0.45f;
+    const unsigned int nruns = (ns + KNN_RUN - 1) / KNN_RUN;
+    for (unsigned int run = wave; run < nruns; run += nwaves) {  // wave-uniform
+    float prev_r = -1.f, pqx = 0.f, pqy = 0.f, pqz = 0.f;  // K-th distance (not squared) and position of the run's previous query; < 0: none
+    for (unsigned int t = run * KNN_RUN; t < min(ns, (run + 1u) * KNN_RUN); ++t) {
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
         const float qx = qv.x, qy = qv.y, qz = qv.z;
@@ -555,42 +567,12 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         const int cx = cell_coord(ux, g.org[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(uy, g.org[1], g.inv_h, g.dim[1]);
         const int cz = cell_coord(uz, g.org[2], g.inv_h, g.dim[2]);
+        const float run_r = prev_r;  // (the predecessor's bound, if any; whatever happens to this query, the next one needs ITS result)
+        prev_r = -1.f;
         auto give_up = [&]() {
             if (lane == 0) fb_list[atomicAdd(fb_count, 1u)] = qi;
         };
-        // the smallest cube that holds at least 2 x `want` points (as k_grid_knn_wave).  A lane looks after rows `lane` and
-        // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1
-        // (round 6, measured and removed: starting one below the cube of the wave's previous query instead of at 3 x 3 x 3 --
-        // K = 51 at 1M 1154 / 1140 us against 1155 / 1156: the sizing rounds are not what the kernel waits for, EXPERIMENTS.md)
-        int k = 1;
-        unsigned int cnt = 0, rs0[RL], rc[RL];
-        for (;; ++k) {
-            const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
-            const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
-            const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
-            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-            const float inv_ny = 1.0f / (float)ny;
-            unsigned int mine = 0;
-#pragma unroll
-            for (int i = 0; i < RL; ++i) {
-                const int r = (int)lane + 64 * i;
-                rs0[i] = 0;
-                rc[i] = 0;
-                if (r < nrow) {
-                    const int zi = (int)(((float)r + 0.5f) * inv_ny);  // r / ny (exact: r < 192, ny <= 13)
-                    const unsigned int row = ((unsigned int)(z0 + zi) * g.dim[1] + (y0 + (r - zi * ny))) * g.dim[0];
-                    rs0[i] = cell_start[row + x0];
-                    rc[i] = cell_start[row + x1 + 1] - rs0[i];
-                }
-                mine += rc[i];
-            }
-            cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(mine), 63);
-            if (cnt >= 2u * (unsigned int)want || k >= KSEL) break;  // (the table's rows)
-        }
-        if (cnt < (unsigned int)want || cnt > (STORE ? (unsigned int)CAP : SEL_FLAT_CAP)) { give_up(); continue; }
-        int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
-        int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
-        int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+        int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;       // box of the pass in hand (cells)
         int ix0 = 1, ix1 = 0, iy0 = 1, iy1 = 0, iz0 = 1, iz1 = 0;  // box already scanned (none yet)
         // span table: (start in cell_refs, flat offset) per non-empty span, and one bit per span END over the flat candidate
         // positions, transposed as in k_grid_radius_fill_wave
@@ -644,6 +626,42 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             }
             wave_lds_sync();
         };
+        // the rows of the box x0..z1 clipped to the BALL of squared radius tau around the query (the bound path): a row whose y / z
+        // gaps leave nothing of tau is dropped, the others are cut to the chord -- the same gaps, factors and slack as the radius
+        // search's rows (k_grid_radius_fill_wave): conservative, every reference with d2 <= tau lies in a listed span.  A ball
+        // fills 52 % of its box: half the candidates of the plain box
+        auto build_table_ball = [&](float tau) {
+            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+            const float inv_ny = 1.0f / (float)ny;
+            auto gap_of = [&](float v, int c, int dim, float org) {  // (boundary cells of the grid are open-ended)
+                return fmaxf(fmaxf((c == 0 ? -__builtin_inff() : org + c * g.h) - v,
+                                   v - (c == dim - 1 ? __builtin_inff() : org + (c + 1) * g.h)) - slack, 0.f);
+            };
+            table_reset();
+            for (int base = 0; base < nrow; base += 64) {
+                const int r = base + (int)lane;
+                unsigned int s0 = 0, c0 = 0;
+                if (r < nrow) {
+                    const int zi = (int)(((float)r + 0.5f) * inv_ny);
+                    const int z = z0 + zi, y = y0 + (r - zi * ny);
+                    const float gy = gap_of(uy, y, g.dim[1], g.org[1]), gz = gap_of(uz, z, g.dim[2], g.org[2]);
+                    const float rem = tau - (gy * gy + gz * gz) * 0.9999f;
+                    if (rem >= 0.f) {
+                        int xa, xb;
+                        cell_range(ux, __builtin_amdgcn_sqrtf(rem) * 1.00001f + slack, g.org[0], g.inv_h, g.dim[0], xa, xb);
+                        xa = max(xa, x0);
+                        xb = min(xb, x1);
+                        if (xa <= xb) {
+                            const unsigned int row = ((unsigned int)z * g.dim[1] + y) * g.dim[0];
+                            s0 = cell_start[row + xa];
+                            c0 = cell_start[row + xb + 1] - s0;
+                        }
+                    }
+                }
+                table_add(s0, c0);
+            }
+            wave_lds_sync();
+        };
         // the table's candidates 64 at a time: fn(flat position, key, in range)
         auto walk = [&](auto&& fn) {
             unsigned int before = 0, word = 0;
@@ -673,6 +691,84 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 }
             }
         };
+        // what both paths hand to the sort below: the survivors L.cand[0 .. scnt), every one of them within `bound`
+        unsigned int scnt = 0;
+        float bound = 0.f;
+        bool by_bound = false;
+        // a window's keys below `tkey` appended to the survivors
+        unsigned long long tkey = 0ull;
+        auto keep_below = [&](unsigned int, unsigned long long key, bool in) {
+            const bool pass = in && key < tkey;
+            const unsigned long long mask = __ballot(pass);
+            const unsigned int slot = scnt + (unsigned int)__popcll(mask & lt_mask);
+            if (pass && slot < SCAP) L.cand[slot] = key;
+            scnt += (unsigned int)__popcll(mask);
+        };
+        // ---- the bound path (every query of a run but the first)
+        if (run_r >= 0.f) {
+            const float sx = qx - pqx, sy = qy - pqy, sz = qz - pqz;
+            const float sep = sqrtf((sx * sx + sy * sy) + sz * sz);
+            const float rb = (run_r + sep) * 1.00001f + slack;  // radius that holds `want` references
+            const float tau = rb * rb;
+            const float rbox = rb * 1.00001f + slack;  // (cells that can hold a reference with d2 <= tau: as the ball pass below)
+            // Only where the bound is TIGHT: the ball of r + sep holds (1 + sep / r)^3 times the K references wanted.  Inside a
+            // dense object the K-th neighbour is a cell away and so is the next query of the cell order (sep / r ~ 0.7: five times
+            // the references, more than the survivor buffer takes -- the walk is wasted and the full path follows); in sparse
+            // regions and on surfaces sep / r is 0.1-0.5.  Measured on one box, K = 51 at 1M, search kernels us, ratio 0.15 / 0.3 / 0.45 /
+            // 0.6 against every query on its own: corridor 1210 / 1216 / 1212 / 1238 (1200), room scan 1068 / 1001 / 991 / 976 (1075);
+            // K = 100 corridor 1838 / 1804 / 1811 / 1883 (1932).  Without the test (every query of a run on the bound path): corridor
+            // 1442, room 968.
+            if (tau < 3.0e38f && sep <= sep_max_ratio * run_r) {
+                cell_range(ux, rbox, g.org[0], g.inv_h, g.dim[0], x0, x1);
+                cell_range(uy, rbox, g.org[1], g.inv_h, g.dim[1], y0, y1);
+                cell_range(uz, rbox, g.org[2], g.inv_h, g.dim[2], z0, z1);
+                if ((y1 - y0 + 1) * (z1 - z0 + 1) <= ROWCAP) {
+                    build_table_ball(tau);
+                    if (total >= (unsigned int)want && total <= SEL_FLAT_CAP) {
+                        tkey = ((unsigned long long)__float_as_uint(tau) + 1ull) << 32;  // every key with d2 <= tau
+                        walk(keep_below);
+                        wave_lds_sync();
+                        if (scnt >= (unsigned int)want && scnt <= SCAP) { bound = tau; by_bound = true; }
+                    }
+                }
+            }
+            scnt = by_bound ? scnt : 0u;
+        }
+        if (!by_bound) {
+        // the smallest cube that holds at least 2 x `want` points (as k_grid_knn_wave).  A lane looks after rows `lane` and
+        // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1
+        // (round 6, measured and removed: starting one below the cube of the wave's previous query instead of at 3 x 3 x 3 --
+        // K = 51 at 1M 1154 / 1140 us against 1155 / 1156: the sizing rounds are not what the kernel waits for, EXPERIMENTS.md)
+        int k = 1;
+        unsigned int cnt = 0, rs0[RL], rc[RL];
+        for (;; ++k) {
+            const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
+            const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
+            const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
+            const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
+            const float inv_ny = 1.0f / (float)ny;
+            unsigned int mine = 0;
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                const int r = (int)lane + 64 * i;
+                rs0[i] = 0;
+                rc[i] = 0;
+                if (r < nrow) {
+                    const int zi = (int)(((float)r + 0.5f) * inv_ny);  // r / ny (exact: r < 192, ny <= 13)
+                    const unsigned int row = ((unsigned int)(z0 + zi) * g.dim[1] + (y0 + (r - zi * ny))) * g.dim[0];
+                    rs0[i] = cell_start[row + x0];
+                    rc[i] = cell_start[row + x1 + 1] - rs0[i];
+                }
+                mine += rc[i];
+            }
+            cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(mine), 63);
+            if (cnt >= 2u * (unsigned int)want || k >= KSEL) break;  // (the table's rows)
+        }
+        if (cnt < (unsigned int)want || cnt > (STORE ? (unsigned int)CAP : SEL_FLAT_CAP)) { give_up(); continue; }
+        x0 = max(cx - k, 0); x1 = min(cx + k, g.dim[0] - 1);
+        y0 = max(cy - k, 0); y1 = min(cy + k, g.dim[1] - 1);
+        z0 = max(cz - k, 0); z1 = min(cz + k, g.dim[2] - 1);
+        ix0 = iy0 = iz0 = 1; ix1 = iy1 = iz1 = 0;
         // ---- pass 1: every candidate of the cube kept, d2 counted into buckets over the cube's d2 range
         {
             const float reach = (float)(k + 1) * g.h;
@@ -707,10 +803,10 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             const unsigned int s1 = first_half ? i_fl - c1_fl : i_fl;  // cube candidates with bucket <= b*
             (void)c0_fl;
             if (bstar >= BUCKET_N - 1 || s1 > SCAP) { give_up(); continue; }
-            const float bound = (float)(bstar + 1) / scale1 * 1.00001f;  // every d2 >= bound has a bucket > b*
+            bound = (float)(bstar + 1) / scale1 * 1.00001f;  // every d2 >= bound has a bucket > b*
             // the kept keys with bucket <= b*, compacted to the front of the buffer (in place: a window is read whole
             // before its survivors are written, and they land at or before their own position)
-            unsigned int scnt = 0;
+            scnt = 0;
             // a window's keys with bucket <= b* appended to the survivors
             auto keep = [&](unsigned int, unsigned long long key, bool in) {
                 const bool pass = in && bucket_of(key, scale1) <= bstar;
@@ -757,6 +853,9 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 }
             }
             if (!fits) { give_up(); continue; }
+        }
+        }  // (the full path)
+        {
             // ---- the survivors in order: finer buckets over [0, bound]; a crowded bucket (equal distances) -> the network
             const float scale2 = (float)BUCKET_N / bound;
             unsigned long long* tmp = L.cand + SCAP;
@@ -769,8 +868,10 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             }
             // (entries past `want` -- K beyond the number of valid references -- are "nothing found")
             const size_t row0 = (size_t)qi * K;
+            unsigned long long kth = ~0ull;  // the `want`-th key of the finished row (wave-uniform)
             if (in_order) {
                 for (unsigned int e = lane; e < (unsigned int)K; e += 64) knn_emit(out, row0 + e, e < (unsigned int)want ? L.cand[e] : ~0ull);
+                kth = L.cand[want - 1];
             } else if constexpr (BIG) {
                 give_up();  // (a crowded bucket among more keys than four registers per lane hold: the merge kernel's)
                 continue;
@@ -783,10 +884,17 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 for (int r = 0; r < 4; ++r) {
                     const unsigned int e = (unsigned int)(r * 64) + lane;
                     if (e < (unsigned int)K) knn_emit(out, row0 + e, e < (unsigned int)want ? v[r] : ~0ull);
+                    if (r == ((want - 1) >> 6)) kth = shfl_u64(v[r], (want - 1) & 63);
                 }
+            }
+            // the next query of the run starts from this one's K-th distance (a full row only: `want` == K real neighbours)
+            if (want == K && !key_none(kth)) {
+                prev_r = sqrtf(__uint_as_float((unsigned int)(kth >> 32)));
+                pqx = qx; pqy = qy; pqz = qz;
             }
         }
     }
+    }  // (runs)
 }
 
 // keys: the rows as search keys; or keys == nullptr and idx_out / d2_out (either may be null): the rows delivered as
@@ -821,7 +929,8 @@ int grid_knn(pcc_index* ix, const float4* q, size_t nq, int K, unsigned long lon
             PCC_HIP(hipMemsetAsync(fb + nq, 0, sizeof(unsigned int), s));
 #define PCC_LAUNCH_SEL(SCAP_, STORE_)                                                                                     \
     hipLaunchKernelGGL((k_grid_knn_sel<SCAP_, STORE_>), dim3(gw), dim3(256), 0, s, ix->cell_refs.as<float4>(),            \
-                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq)
+                       ix->cell_start.as<unsigned int>(), ix->d_grid.as<GridDev>(), q, order, n_sorted, K, out, fb, fb + nq, \
+                       (unsigned int)ix->opt.knn_run)
             if (K <= 64) PCC_LAUNCH_SEL(256, true);
             else if (K <= 128) PCC_LAUNCH_SEL(256, false);
             else if (K <= 256) PCC_LAUNCH_SEL(384, false);

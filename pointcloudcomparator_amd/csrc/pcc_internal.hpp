@@ -139,6 +139,8 @@ struct Options {
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
                                     // shortest, shortest, longest); 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
+    int knn_run = 8;                // PCC_OPT_KNN_RUN: k-NN selection kernel: consecutive cell-sorted queries a wave takes in a row, every one after the
+                                    // first starting from its predecessor's K-th distance + their separation (knn.hip); 1 = every query on its own
     int scan_chained = 1;           // PCC_OPT_SCAN_CHAINED: exclusive scans of up to 512 x 2048 counters in ONE launch (workgroups pass their totals on as
                                     // tagged 64-bit atomics and wait for the workgroups in front of them: relies on in-order dispatch); 0 = the two-launch
                                     // form (block totals, then apply), which waits for nothing

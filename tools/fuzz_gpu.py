@@ -165,6 +165,7 @@ def main():
                 ix.set_option(capi.OPT_XCD_RUN, int(rng.choice([1, 32, 256, 4096])))
                 ix.set_option(capi.OPT_FUSE_PARAMS, int(rng.choice([0, 0, 1, 2, 3])))
                 ix.set_option(capi.OPT_SCAN_CHAINED, int(rng.random() < 0.8))
+                ix.set_option(capi.OPT_KNN_RUN, int(rng.choice([1, 2, 8, 8, 64])))
                 ix.set_input(a)
                 idx, d2 = ix.nn1(q)
                 oi, od = oracle.nn1_exhaustive(a, q)
