@@ -9,6 +9,10 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 S=$O/summary
 mkdir -p $S
+# PART=A: traces, PMC traffic, the one-stream pass table, the default bench; PART=B: operations, rooflines, counters (a gpurun call is
+# limited to 20 minutes: the two halves are separate calls; default: both)
+PART=${PART:-AB}
+if [ "$PART" != B ]; then
 for c in c2 c3 c4 c5 c5_shard; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -- python3 bench.py --config $c --no-cpu --no-pairs > $S/${TAG}_${c}_trace_bench.json 2> $O/trace_$c.err
   cp $(find $O/trace_$c -name "*kernel_stats.csv" | head -1) $S/${TAG}_${c}_kernel_stats.csv
@@ -35,6 +39,8 @@ echo "serial trace done"
 # the unprofiled default run last: its roofline.traffic is read from the PMC file written just above
 python3 bench.py > $S/${TAG}_bench_default.json 2> $O/bench_default.err
 echo "default bench done"
+fi
+[ "$PART" = A ] && exit 0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ops -- python3 tools/profile_ops.py > $S/${TAG}_ops_wallclock.txt 2> $O/ops.err
 cp $(find $O/ops -name "*kernel_stats.csv" | head -1) $S/${TAG}_ops_kernel_stats.csv
 python3 tools/exp_ties.py 1e6 2>/dev/null | tail -1 >> $S/${TAG}_ops_wallclock.txt
