@@ -1024,7 +1024,10 @@ int grid_nn1(pcc_index* ix, const float4* q, size_t nq, unsigned long long* out)
     }
     ev_mark(ix, EV_MAIN0);
     const int BS = 256;  // 128 and 512 measured 9-12 % slower (fewer lanes to pack / longer wait at the barrier)
-    const unsigned int xcd_run = (unsigned int)ix->opt.xcd_run;  // consecutive workgroups per XCD (see k_grid_nn1; PCC_OPT_XCD_RUN)
+    // consecutive workgroups per XCD (see k_grid_nn1; PCC_OPT_XCD_RUN) -- at most a sixteenth of the launch, so that every XCD gets
+    // at least two runs (the kernels leave the last, partial round of runs unmapped: a launch smaller than 8 runs would lose the
+    // steering altogether)
+    const unsigned int xcd_run = std::max(1u, std::min((unsigned int)ix->opt.xcd_run, ((n + 127u) / 128u) / 16u));
     // 4 candidate loads in flight per lane: 2 and 8 measured 153 and 151 us against 142 at 1M x 1M
     // phase 2 as the ball outside the finished cube, except in ICP passes: while the source is still misaligned the
     // balls are several cells wide and the per-row chord arithmetic costs more than the rows it drops
