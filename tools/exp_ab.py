@@ -25,18 +25,23 @@ def cloud(seed):
 a, b = cloud(synth.SEED_A), cloud(synth.SEED_B)
 idx = torch.empty(n, dtype=torch.int32, device="cuda")
 d2 = torch.empty(n, dtype=torch.float32, device="cuda")
-handles = []
-for st in sets:
-    ix = capi.Index(a, engine=capi.ENGINE_GRID, auto_sync=False)
-    for k, v in st.items():
-        ix.set_option(getattr(capi, "OPT_" + k.upper()), v)
-    ix.set_input(a)
-    ix.nn1(b, idx, d2)
+# ONE handle for every option set: its buffers only grow, so every set runs in the same memory (a handle per set puts each set's
+# index at other addresses, and that alone moved steps by several percent -- round 6)
+ix = capi.Index(a, engine=capi.ENGINE_GRID, auto_sync=False)
+keys = sorted({k for st in sets for k in st})
+defaults = {k: ix.get_option(getattr(capi, "OPT_" + k.upper())) for k in keys}
+
+
+def apply(st):
+    for k in keys:
+        ix.set_option(getattr(capi, "OPT_" + k.upper()), st.get(k, defaults[k]))
+    for _ in range(2):
+        ix.set_input(a)
+        ix.nn1(b, idx, d2)
     ix.sync()
-    handles.append(ix)
 
 
-def wall(ix, fn, k=20):
+def wall(fn, k=20):
     fn(); ix.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(k):
@@ -45,14 +50,17 @@ def wall(ix, fn, k=20):
     return (time.perf_counter() - t0) / k * 1e3
 
 
+def step():
+    ix.set_input(a)
+    ix.nn1(b, idx, d2)
+
+
 res = [([], [], []) for _ in sets]
 for r in range(rounds):
-    for i, ix in enumerate(handles):
-        def step():
-            ix.set_input(a)
-            ix.nn1(b, idx, d2)
-        res[i][0].append(wall(ix, step))
-        res[i][1].append(wall(ix, lambda: ix.set_input(a)))
-        res[i][2].append(wall(ix, lambda: ix.nn1(b, idx, d2)))
+    for i, st in enumerate(sets):
+        apply(st)
+        res[i][0].append(wall(step))
+        res[i][1].append(wall(lambda: ix.set_input(a)))
+        res[i][2].append(wall(lambda: ix.nn1(b, idx, d2)))
 for st, (s_, b_, q_) in zip(sets, res):
     print(f"{cfg} {str(st):60s} step {statistics.median(s_):7.4f} ms (min {min(s_):7.4f})  build {statistics.median(b_):7.4f}  query-only {statistics.median(q_):7.4f}", flush=True)
