@@ -48,7 +48,7 @@ static bool option_in_range(int option, double value) {
         case PCC_OPT_FLANN_SPLIT: return value >= 0 && value <= 2;
         case PCC_OPT_SORT_STAGE1: return value >= 0 && value <= 2;
         case PCC_OPT_OVERLAP_PREP: return value >= 0 && value <= 2;
-        case PCC_OPT_GRID_AXES: return value >= -1 && value <= 5;
+        case PCC_OPT_GRID_AXES: return value >= -2 && value <= 5;
         case PCC_OPT_XCD_RUN: return value >= 1 && value <= 4096;
         case PCC_OPT_FUSE_PARAMS: return value >= 0 && value <= 3;
         case PCC_OPT_KNN_RUN: return value >= 1 && value <= 64;

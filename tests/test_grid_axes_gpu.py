@@ -1,6 +1,6 @@
 """PCC_OPT_GRID_AXES: which coordinate of the cloud the grid's axes (along a row of cells, over the rows of a layer, over the
-layers) follow.  By default the index picks them from the cloud's extents (second shortest, shortest, longest); 0..5 force one
-of the six assignments, 0 being the x / y / z layout of rounds 1-5.  The layout decides where a cell's neighbours lie in memory
+layers) follow.  From 3M points on the index picks them from the cloud's extents (second shortest, shortest, longest; -2: at every
+size); 0..5 force one of the six assignments, 0 being the x / y / z layout of rounds 1-5.  The layout decides where a cell's neighbours lie in memory
 and nothing else: every search must return the oracle's bits under all six -- the kd-tree it stands in for has no such notion
 (reference src/comparator.cpp:564-577, src/segmentation.cpp:120-131)."""
 import numpy as np
@@ -11,7 +11,7 @@ from pointcloudcomparator_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
-AXES = [-1, 0, 1, 2, 3, 4, 5]
+AXES = [-2, -1, 0, 1, 2, 3, 4, 5]  # -2: by extent at every size (the default, -1, does so from 3M points on)
 
 
 def _bits(x):
@@ -60,7 +60,7 @@ def test_nn1_is_exact_under_every_axis_assignment(gpu, axes):
             ix.set_option(capi.OPT_GRID_AXES, axes)
             assert ix.get_option(capi.OPT_GRID_AXES) == axes
             ix.set_input(ref)  # (options that shape the index act at the next set_input)
-            for form in ((1, 0, 2) if axes in (-1, 0, 3) else (1,)):
+            for form in ((1, 0, 2) if axes in (-2, 0, 3) else (1,)):
                 ix.set_option(capi.OPT_NN1_KERNEL, form)
                 for _ in range(2):  # (the second call takes the far route where the first had fallbacks)
                     idx, d2 = ix.nn1(qry)
@@ -107,7 +107,7 @@ def test_axes_by_extent_is_a_pure_layout_choice_at_a_million(gpu):
     a = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_A)).cuda()
     b = torch.from_numpy(synth.corridor_cloud(n, synth.SEED_B)).cuda()
     res = {}
-    for axes in (-1, 0, 3):
+    for axes in (-1, -2, 0, 3):
         with capi.Index(a, engine=capi.ENGINE_GRID) as ix:
             ix.set_option(capi.OPT_GRID_AXES, axes)
             ix.set_input(a)
@@ -121,7 +121,7 @@ def test_axes_by_extent_is_a_pure_layout_choice_at_a_million(gpu):
             assert np.allclose(T1, T, atol=1e-6) and abs(fit1 - fit) <= 1e-9 * fit
             md, inl, thr, kept = ix.sor(mean_k=20)
             res[axes] = (idx.cpu().numpy(), d2.cpu().numpy(), np.asarray(T), fit, md, inl, thr, kept)
-    for axes in (0, 3):
+    for axes in (-2, 0, 3):
         assert (res[axes][0] == res[-1][0]).all() and (_bits(res[axes][1]) == _bits(res[-1][1])).all()
         assert (np.asarray(res[axes][2]).view(np.uint32) == np.asarray(res[-1][2]).view(np.uint32)).all()
         assert res[axes][3] == res[-1][3]

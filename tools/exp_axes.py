@@ -11,7 +11,7 @@ from pointcloudcomparator_amd import capi, synth
 legs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c3", "c2", "room", "c4", "knn", "radius", "clusters"]
 AXES = [int(x) for x in os.environ.get("AXES", "0,-1").split(",")]
 RUNS = [int(x) for x in os.environ.get("XCD_RUNS", "32").split(",")]
-NAMES = {-1: "by extent", 0: "xyz (r5)", 1: "xzy", 2: "yxz", 3: "yzx", 4: "zxy", 5: "zyx"}
+NAMES = {-2: "by extent!", -1: "by extent", 0: "xyz (r5)", 1: "xzy", 2: "yxz", 3: "yzx", 4: "zxy", 5: "zyx"}
 
 
 def cloud(kind, n, seed, rgb=False):

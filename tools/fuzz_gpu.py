@@ -161,7 +161,7 @@ def main():
                 ix.set_option(capi.OPT_OVERLAP_PREP, int(rng.choice([0, 1, 2, 2])))
                 # round 6: the grid's axis assignment drawn per scene (-1: by extent), the XCD run, the fused grid parameters; the
                 # index is rebuilt under them (options that shape it act at the next set_input)
-                ix.set_option(capi.OPT_GRID_AXES, int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5])))
+                ix.set_option(capi.OPT_GRID_AXES, int(rng.choice([-2, -2, -1, 0, 1, 2, 3, 4, 5])))
                 ix.set_option(capi.OPT_XCD_RUN, int(rng.choice([1, 32, 256, 4096])))
                 ix.set_option(capi.OPT_FUSE_PARAMS, int(rng.choice([0, 0, 1, 2, 3])))
                 ix.set_option(capi.OPT_SCAN_CHAINED, int(rng.random() < 0.8))
