@@ -159,8 +159,8 @@ struct Options {
                                     // workgroup of k_icp_sums (a kernel that writes 65 KB) instead of k_icp_solve
     int xcd_run = 256;              // PCC_OPT_XCD_RUN: consecutive workgroups of the k = 1 search steered to the same XCD (its L2).  32 until round 5;
                                     // with the layers of the grid a few rows apart (grid_axes) a run should hold several LAYERS, so that the rows of
-                                    // the layer behind are re-read from the same L2: C3 fabric reads 2.18 -> 1.66 GB at 512, kernels 646 / 592 / 604 /
-                                    // 592 / 624 / 629 us at 32 / 128 / 256 / 512 / 1024 / 2048 (x / y / z layout: 624-637 whatever the run)
+                                    // the layer behind are re-read from the same L2: C3 fabric traffic of the search 2.95 -> 2.42 GB per call.  Time,
+                                    // on one handle: C3 step 1.3517 (by extent, 32) -> 1.3334 (by extent, 256); x / y / z layout 1.3333 / 1.3316
     int overlap_prep = 1;           // PCC_OPT_OVERLAP_PREP: a k = 1 search that follows setInputCloud directly packs and sorts its queries on a
                                     // second stream while the build's cell sort is still running (they share nothing but the grid parameters);
                                     // from 2M queries on, 2 = at every size
