@@ -48,9 +48,13 @@ inline int pipe_threads() {
 class ChunkCrew {
 public:
     template <class F>
-    ChunkCrew(int nthreads, F work) : n_(nthreads) {
-        for (int t = 1; t < n_; ++t)
-            helpers_.emplace_back([this, t, work]() {
+    ChunkCrew(int nthreads, F work) : n_(1) {
+        // (a helper that cannot be started -- thread limits of the process -- is done without: the owner alone is a crew of one.  n_ is
+        // final before any helper reads it: they wait for the first release, which run() makes after this constructor)
+        int started = 1;
+        for (int t = 1; t < nthreads; ++t) {
+            try {
+                helpers_.emplace_back([this, t, work]() {
                 for (long next = 0;; ++next) {
                     long rel;
                     while ((rel = released_.load(std::memory_order_acquire)) <= next) {
@@ -61,7 +65,13 @@ public:
                     work((size_t)next, t, n_);
                     done_.fetch_add(1, std::memory_order_release);
                 }
-            });
+                });
+                ++started;
+            } catch (...) {
+                break;
+            }
+        }
+        n_ = started;
     }
     // run chunk `c` on every thread and wait for all of them (chunks are released in order 0, 1, 2, ...)
     template <class F>
