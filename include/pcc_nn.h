@@ -173,9 +173,9 @@ enum pcc_option {
                                     It acts from 2M queries on (below that it hides nothing); 2 = at every size (tests).  Only on the
                                     library's own stream: after pcc_index_set_stream the caller's stream is the one order there is. */
     PCC_OPT_GRID_AXES = 18,      /* which coordinate of the cloud the grid's three axes -- along a row of cells, over the rows of a
-                                    layer, over the layers -- follow: -1 = chosen per index (default): from 3M points on by the cloud's
-                                    extents (second shortest, shortest, longest: the rows and layers next to a query's row are then as
-                                    close to it in memory as the cloud allows), below that x, y, z; -2 = by extent at every size; 0 = x, y, z (rounds 1-5); 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx.  Takes
+                                    layer, over the layers -- follow: -1 = chosen per index from the cloud's extents (default: second
+                                    shortest, shortest, longest: the rows and layers next to a query's row are then as close to it in
+                                    memory as the cloud allows); -2 = the same whatever GRID_AXES_MIN_POINTS says; 0 = x, y, z (rounds 1-5); 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx.  Takes
                                     effect at the next pcc_index_set_input.  No result bit depends on it. */
     PCC_OPT_XCD_RUN = 19,        /* k = 1 search: consecutive workgroups (128 cell-sorted queries each) steered to the same XCD,
                                     i.e. the stretch of the grid one L2 works on at a time (default 256) */

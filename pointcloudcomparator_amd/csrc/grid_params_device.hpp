@@ -143,7 +143,7 @@ __device__ __forceinline__ void grid_params_block(const float* __restrict__ blk,
     // re-reading from the L2 -- is as small as the cloud allows.  A room scan is long and wide and 2.7 m high: with z on axis 2
     // (rounds 1-5) the rows of the layer above were a whole floor plan away.  Ties keep x, y, z order.
     GridParams g;
-    // (by extent only for clouds large enough to gain from it; smaller ones keep x, y, z: pcc_internal.hpp)
+    // (GRID_AXES_MIN_POINTS, pcc_internal.hpp: measured both ways, set to 0)
     // (axes = -2: by extent whatever the size -- tests)
     grid_axes_for(ext, axes == -1 && d.n_valid < GRID_AXES_MIN_POINTS ? 0 : axes, g.ax);
     for (int iter = 0; iter < 200; ++iter) {  // grow the cell until the grid fits nc_cap

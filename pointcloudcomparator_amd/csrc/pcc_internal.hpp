@@ -78,10 +78,13 @@ struct GridParams {
 // The rule behind GridParams::ax (one place: k_grid_params on the device, the clustering grid on the host): the coordinate
 // with the second shortest extent runs along the rows, the shortest over the rows of a layer, the longest over the layers;
 // ties keep x, y, z order.  forced 0..5 = xyz, xzy, yxz, yzx, zxy, zyx (PCC_OPT_GRID_AXES), anything else: by extent.
-// GRID_AXES_MIN_POINTS: clouds below it keep x, y, z -- measured on ONE handle (same memory for every setting, tools/exp_ab.py): the
-// layout by extent costs 3-5 % of a k = 1 step at 1M-1.4M points (C2 0.2263 -> 0.2327 ms, room scan 0.3601 -> 0.3787), gains 1.4-3 % at
-// 4M, is time-neutral at 10M (1.3333 / 1.3334 ms) where it takes a sixth of the search's fabric traffic away.
-constexpr unsigned int GRID_AXES_MIN_POINTS = 3000000u;
+// GRID_AXES_MIN_POINTS: clouds below it would keep x, y, z.  Measured on ONE handle (same memory for every setting, tools/exp_ab.py,
+// exp_knn_ab.py): for k = 1 the layout by extent costs 3-5 % of a step at 1M-1.4M points (C2 0.2263 -> 0.2327 ms, room scan 0.3601 ->
+// 0.3787), gains 1.4-3 % at 4M and is time-neutral at 10M (1.3333 / 1.3334 ms), where it takes a sixth of the search's fabric traffic away;
+// for k-NN at 1M it is worth 7 % at K = 51 and 17 % at K = 100 on the corridor scene (1.229 -> 1.143, 2.196 -> 1.814 ms: the ball boxes of the
+// bound path span rows of several layers) and nothing on the room scan.  A cloud of the reference's sizes spends 5-20x longer in its k-NN
+// consumers (SOR, normals, region growing) than in a k = 1 step: 0 -- by extent at every size.
+constexpr unsigned int GRID_AXES_MIN_POINTS = 0u;
 __host__ __device__ inline void grid_axes_for(const float ext[3], int forced, int ax[3]) {
     // (no array is indexed by a variable: on the device that would put it in scratch memory)
     const float e0 = ext[0], e1 = ext[1], e2 = ext[2];
@@ -142,7 +145,7 @@ struct Options {
     int nn1_open_flat = 1;          // PCC_OPT_NN1_OPEN_FLAT: the listed open lanes drained flat (k_nn1_open_flat); 0 = one lane per query
     int flann_split = 0;            // PCC_OPT_FLANN_SPLIT: 0 middleSplit_, 1 middleSplit (which rule FLANN's divideTree is replayed with)
     int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
-                                    // shortest, shortest, longest) from GRID_AXES_MIN_POINTS points on, xyz below; -2 by extent at every size;
+                                    // shortest, shortest, longest; clouds below GRID_AXES_MIN_POINTS -- 0 -- would keep xyz); -2 by extent whatever that says;
                                     // 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
     int knn_run = 8;                // PCC_OPT_KNN_RUN: k-NN selection kernel: consecutive cell-sorted queries a wave takes in a row, every one after the
                                     // first starting from its predecessor's K-th distance + their separation (knn.hip); 1 = every query on its own

@@ -1,6 +1,6 @@
 """PCC_OPT_GRID_AXES: which coordinate of the cloud the grid's axes (along a row of cells, over the rows of a layer, over the
-layers) follow.  From 3M points on the index picks them from the cloud's extents (second shortest, shortest, longest; -2: at every
-size); 0..5 force one of the six assignments, 0 being the x / y / z layout of rounds 1-5.  The layout decides where a cell's neighbours lie in memory
+layers) follow.  The index picks them from the cloud's extents (second shortest, shortest, longest; -2: the same whatever the size
+threshold of pcc_internal.hpp says -- 0 today); 0..5 force one of the six assignments, 0 being the x / y / z layout of rounds 1-5.  The layout decides where a cell's neighbours lie in memory
 and nothing else: every search must return the oracle's bits under all six -- the kd-tree it stands in for has no such notion
 (reference src/comparator.cpp:564-577, src/segmentation.cpp:120-131)."""
 import numpy as np
@@ -11,7 +11,7 @@ from pointcloudcomparator_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
-AXES = [-2, -1, 0, 1, 2, 3, 4, 5]  # -2: by extent at every size (the default, -1, does so from 3M points on)
+AXES = [-2, -1, 0, 1, 2, 3, 4, 5]  # -1: by extent (the default), -2: the same regardless of GRID_AXES_MIN_POINTS
 
 
 def _bits(x):
