@@ -193,7 +193,7 @@ enum pcc_option {
     PCC_OPT_KNN_RUN = 23         /* k-NN selection (k <= 512): a wave takes this many consecutive queries of the cell-sorted order in a
                                     row; every query after the first of its run starts from a bound -- its predecessor's K-th distance
                                     plus their separation (the K-th neighbour distance is 1-Lipschitz) -- and skips the cube sizing,
-                                    the bucket histogram and the compaction (default 8; 1 = every query on its own, round 5) */
+                                    the bucket histogram and the compaction (default 16; 1 = every query on its own, round 5) */
 };
 int pcc_index_set_option(pcc_index *index, int option, double value);
 int pcc_index_get_option(pcc_index *index, int option, double *value);

@@ -553,7 +553,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     // one walk that keeps what lies inside, the sort.  Exact whatever the bound: the walk collects EVERY reference with d2 <= bound
     // inside a box that covers the ball; with at least `want` of them their `want` smallest are the answer, with fewer (the bound
     // came from rounded arithmetic, or the predecessor gave up) the query takes the full path below.
-    // (KNN_RUN: PCC_OPT_KNN_RUN, default 8; 1 = every query takes the full path, round 5's kernel)
+    // (KNN_RUN: PCC_OPT_KNN_RUN, default 16; 1 = every query takes the full path, round 5's kernel)
     constexpr float sep_max_ratio = 0.45f;
     const unsigned int nruns = (ns + KNN_RUN - 1) / KNN_RUN;
     for (unsigned int run = wave; run < nruns; run += nwaves) {  // wave-uniform

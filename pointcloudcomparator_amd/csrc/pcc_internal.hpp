@@ -147,8 +147,10 @@ struct Options {
     int grid_axes = -1;             // PCC_OPT_GRID_AXES: which coordinate the grid's axes (row, rows of a layer, layers) follow: -1 by extent (second
                                     // shortest, shortest, longest; clouds below GRID_AXES_MIN_POINTS -- 0 -- would keep xyz); -2 by extent whatever that says;
                                     // 0 xyz (the layout of rounds 1-5), 1 xzy, 2 yxz, 3 yzx, 4 zxy, 5 zyx
-    int knn_run = 8;                // PCC_OPT_KNN_RUN: k-NN selection kernel: consecutive cell-sorted queries a wave takes in a row, every one after the
-                                    // first starting from its predecessor's K-th distance + their separation (knn.hip); 1 = every query on its own
+    int knn_run = 16;               // PCC_OPT_KNN_RUN: k-NN selection kernel: consecutive cell-sorted queries a wave takes in a row, every one after the
+                                    // first starting from its predecessor's K-th distance + their separation (knn.hip); 1 = every query on its own.
+                                    // One handle, 1M self query, runs of 4 / 8 / 16 / 32, ms: corridor K = 51 1.167 / 1.146 / 1.119 / 1.215, K = 100
+                                    // 1.910 / 1.816 / 1.775 / 2.013; room scan K = 51 0.976 / 0.971 / 0.946 / 0.991, K = 100 1.210 / 1.179 / 1.148 / 1.212
     int scan_chained = 1;           // PCC_OPT_SCAN_CHAINED: exclusive scans of up to 512 x 2048 counters in ONE launch (workgroups pass their totals on as
                                     // tagged 64-bit atomics and wait for the workgroups in front of them: relies on in-order dispatch); 0 = the two-launch
                                     // form (block totals, then apply), which waits for nothing
