@@ -554,9 +554,9 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     // inside a box that covers the ball; with at least `want` of them their `want` smallest are the answer, with fewer (the bound
     // came from rounded arithmetic, or the predecessor gave up) the query takes the full path below.
     // (KNN_RUN: PCC_OPT_KNN_RUN, default 16; 1 = every query takes the full path, round 5's kernel)
-    // (and never so loose that the ball would hold more than the survivor buffer takes: (1 + ratio)^3 x want <= SCAP / 1.15 -- K = 100
-    // with its 256 slots: 0.31)
-    const float sep_max_ratio = fminf(0.45f, cbrtf((float)SCAP / (1.15f * (float)want)) - 1.f);
+    // (a cap by the survivor buffer -- (1 + ratio)^3 x want <= SCAP / 1.15, i.e. 0.31 for K = 100 -- was measured too: corridor K = 100
+    // 1.823 -> 1.796 ms, room scan 1.199 -> 1.229: on surfaces a ball holds fewer points than its volume says.  Not kept.)
+    constexpr float sep_max_ratio = 0.45f;
     const unsigned int nruns = (ns + KNN_RUN - 1) / KNN_RUN;
     for (unsigned int run = wave; run < nruns; run += nwaves) {  // wave-uniform
     float prev_r = -1.f, pqx = 0.f, pqy = 0.f, pqz = 0.f;  // K-th distance (not squared) and position of the run's previous query; < 0: none
