@@ -556,6 +556,9 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     // (KNN_RUN: PCC_OPT_KNN_RUN, default 16; 1 = every query takes the full path, round 5's kernel)
     // (a cap by the survivor buffer -- (1 + ratio)^3 x want <= SCAP / 1.15, i.e. 0.31 for K = 100 -- was measured too: corridor K = 100
     // 1.823 -> 1.796 ms, room scan 1.199 -> 1.229: on surfaces a ball holds fewer points than its volume says.  Not kept.)
+    // (with the second stage on the stored keys -- survivors beyond SCAP cut at the K-th's bucket instead of handed to the full path --
+    // the ratio was measured again, one handle, run 16 against run 1 per process: 0.45 / 0.7 / 1.0 -> corridor K = 51 0.931 / 0.975 /
+    // 1.027, K = 100 0.862 / 0.859 / 0.887; room scan K = 51 0.892 / 0.864 / 0.871, K = 100 0.838 / 0.825 / 0.823.  0.45 stays.)
     constexpr float sep_max_ratio = 0.45f;
     const unsigned int nruns = (ns + KNN_RUN - 1) / KNN_RUN;
     for (unsigned int run = wave; run < nruns; run += nwaves) {  // wave-uniform
@@ -703,8 +706,36 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             const bool pass = in && key < tkey;
             const unsigned long long mask = __ballot(pass);
             const unsigned int slot = scnt + (unsigned int)__popcll(mask & lt_mask);
-            if (pass && slot < SCAP) L.cand[slot] = key;
+            if (pass && slot < (unsigned int)CAP) L.cand[slot] = key;
             scnt += (unsigned int)__popcll(mask);
+        };
+        // the bucket that holds the `want`-th of the keys counted into L.bk: first one whose running count reaches it; s1 = keys
+        // with a bucket <= b* (at least `want` keys were counted, so some lane reaches it)
+        auto find_bstar = [&](unsigned int& bstar, unsigned int& s1) {
+            const unsigned int c0 = L.bk[1 + 2 * lane], c1 = L.bk[2 + 2 * lane];
+            const unsigned int incl = wave_incl_scan_add(c0 + c1);
+            const unsigned long long reached = __ballot(incl >= (unsigned int)want);
+            const int fl = __builtin_ctzll(reached);
+            const unsigned int i_fl = (unsigned int)__builtin_amdgcn_readlane((int)incl, fl);
+            const unsigned int c1_fl = (unsigned int)__builtin_amdgcn_readlane((int)c1, fl);
+            const bool first_half = i_fl - c1_fl >= (unsigned int)want;
+            bstar = 2u * (unsigned int)fl + (first_half ? 0u : 1u);
+            s1 = first_half ? i_fl - c1_fl : i_fl;
+        };
+        // the keys L.cand[0 .. count) with bucket <= b*, compacted to the front of the buffer (in place: a window is read whole
+        // before its survivors are written, and they land at or before their own position); scnt = how many
+        auto compact_stored = [&](unsigned int count, float scale1, unsigned int bstar) {
+            scnt = 0;
+            for (unsigned int B = 0; B < count; B += 64) {
+                const unsigned int c = B + lane;
+                const unsigned long long key = c < count ? L.cand[c] : ~0ull;
+                const bool pass = c < count && bucket_of(key, scale1) <= bstar;
+                const unsigned long long mask = __ballot(pass);
+                wave_lds_sync();
+                if (pass) L.cand[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+                scnt += (unsigned int)__popcll(mask);
+                wave_lds_sync();
+            }
         };
         // ---- the bound path (every query of a run but the first)
         if (run_r >= 0.f) {
@@ -730,7 +761,26 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                         tkey = ((unsigned long long)__float_as_uint(tau) + 1ull) << 32;  // every key with d2 <= tau
                         walk(keep_below);
                         wave_lds_sync();
-                        if (scnt >= (unsigned int)want && scnt <= SCAP) { bound = tau; by_bound = true; }
+                        if (scnt >= (unsigned int)want && scnt <= SCAP) {
+                            bound = tau;
+                            by_bound = true;
+                        } else if (scnt > SCAP && scnt <= (unsigned int)CAP) {
+                            // more than the sort takes, all of them kept (the buffer's second half is free until the sort): the
+                            // buckets of the full path's pass 1 over [0, tau] on the stored keys cut them at the `want`-th's bucket
+                            const float sc = (float)BUCKET_N / tau;
+                            L.bk[1 + 2 * lane] = 0u;
+                            L.bk[2 + 2 * lane] = 0u;
+                            wave_lds_sync();
+                            for (unsigned int c = lane; c < scnt; c += 64) atomicAdd(&L.bk[1 + bucket_of(L.cand[c], sc)], 1u);
+                            wave_lds_sync();
+                            unsigned int bstar, s1;
+                            find_bstar(bstar, s1);
+                            if (s1 <= SCAP) {
+                                compact_stored(scnt, sc, bstar);
+                                bound = fminf(tau, (float)(bstar + 1) / sc * 1.00001f);
+                                by_bound = true;
+                            }
+                        }
                     }
                 }
             }
@@ -791,23 +841,11 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 }
             });
             wave_lds_sync();
-            // the bucket that holds the `want`-th: first one whose running count reaches it
-            const unsigned int c0 = L.bk[1 + 2 * lane], c1 = L.bk[2 + 2 * lane];
-            const unsigned int incl = wave_incl_scan_add(c0 + c1);
-            const unsigned long long reached = __ballot(incl >= (unsigned int)want);
-            // (total >= want, so some lane has reached it)
-            const int fl = __builtin_ctzll(reached);
-            const unsigned int i_fl = (unsigned int)__builtin_amdgcn_readlane((int)incl, fl);
-            const unsigned int c0_fl = (unsigned int)__builtin_amdgcn_readlane((int)c0, fl);
-            const unsigned int c1_fl = (unsigned int)__builtin_amdgcn_readlane((int)c1, fl);
-            const bool first_half = i_fl - c1_fl >= (unsigned int)want;
-            const unsigned int bstar = 2u * (unsigned int)fl + (first_half ? 0u : 1u);
-            const unsigned int s1 = first_half ? i_fl - c1_fl : i_fl;  // cube candidates with bucket <= b*
-            (void)c0_fl;
+            unsigned int bstar, s1;  // the bucket that holds the `want`-th; cube candidates with bucket <= b*
+            find_bstar(bstar, s1);
             if (bstar >= BUCKET_N - 1 || s1 > SCAP) { give_up(); continue; }
             bound = (float)(bstar + 1) / scale1 * 1.00001f;  // every d2 >= bound has a bucket > b*
-            // the kept keys with bucket <= b*, compacted to the front of the buffer (in place: a window is read whole
-            // before its survivors are written, and they land at or before their own position)
+            // the kept keys with bucket <= b* to the front of the buffer
             scnt = 0;
             // a window's keys with bucket <= b* appended to the survivors
             auto keep = [&](unsigned int, unsigned long long key, bool in) {
@@ -818,16 +856,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 scnt += (unsigned int)__popcll(mask);
             };
             if constexpr (STORE) {
-                for (unsigned int B = 0; B < total; B += 64) {
-                    const unsigned int c = B + lane;
-                    const unsigned long long key = c < total ? L.cand[c] : ~0ull;
-                    const bool pass = c < total && bucket_of(key, scale1) <= bstar;
-                    const unsigned long long mask = __ballot(pass);
-                    wave_lds_sync();
-                    if (pass) L.cand[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
-                    scnt += (unsigned int)__popcll(mask);
-                    wave_lds_sync();
-                }
+                compact_stored(total, scale1, bstar);
             } else {
                 walk(keep);  // (s1 <= SCAP: they all fit)
                 wave_lds_sync();
