@@ -19,6 +19,10 @@
 #include <cstring>
 
 namespace pcc {
+// base + the number of lanes below this one whose bit is set in `mask` (v_mbcnt: two instructions, the base folded in)
+__device__ __forceinline__ unsigned int lanes_below(unsigned long long mask, unsigned int base) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, base));
+}
 
 __device__ __forceinline__ unsigned long long make_key(float d, const float4& r) {
     return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(r.w);
@@ -207,7 +211,6 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));  // (uniform: scalar header loads)
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (unsigned int t = wave; t < ns; t += nwaves) {  // wave-uniform
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
@@ -246,7 +249,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
             const bool pass = key < tau;
             const unsigned long long mask = __ballot(pass);
             if (mask == 0) return;
-            if (pass) stage[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+            if (pass) stage[lanes_below(mask, scnt)] = key;
             scnt += (unsigned int)__popcll(mask);
             wave_lds_sync();
             if (scnt >= 64) {
@@ -304,7 +307,7 @@ k_grid_knn_wave(const float4* __restrict__ cell_refs, const unsigned int* __rest
                     const unsigned int incl = wave_incl_scan_add(cnt);
                     const unsigned long long occ = __ballot(cnt != 0);
                     if (cnt) {
-                        const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
+                        const unsigned int slot = lanes_below(occ, nspans);
                         tab_s[slot] = s0;
                         tab_o[slot] = total + incl - cnt;
                     }
@@ -545,7 +548,6 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));  // (uniform: scalar header loads)
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int want = (unsigned int)K < n_valid ? K : (int)n_valid;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // Round 6: a wave takes RUNS of KNN_RUN consecutive queries of the cell-sorted order (runs dealt out strided over the waves, as
     // single queries were).  The K-th neighbour distance is 1-Lipschitz in the query: r_K(q) <= r_K(p) + |q - p|.  So every query
     // after the first of its run starts from a BOUND -- its predecessor's K-th distance plus their separation -- and needs neither the
@@ -594,7 +596,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             const unsigned int incl = wave_incl_scan_add(c);
             const unsigned long long occ = __ballot(c != 0);
             if (c) {
-                const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
+                const unsigned int slot = lanes_below(occ, nspans);
                 const unsigned int off = total + incl - c;
                 L.tab_s[slot] = s0;
                 const unsigned int e = off + c - 1;
@@ -609,7 +611,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         // the box minus the box already scanned: a row crossing it gives its left and its right part
         auto build_table = [&]() {
             const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-            const float inv_ny = 1.0f / (float)ny;
+            const float inv_ny = __builtin_amdgcn_rcpf((float)ny);  // (1 ulp; (r + 0.5) / ny stays 0.5 / ny away from an integer)
             table_reset();
             for (int base = 0; base < nrow; base += 64) {
                 const int r = base + (int)lane;
@@ -637,7 +639,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         // fills 52 % of its box: half the candidates of the plain box
         auto build_table_ball = [&](float tau) {
             const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-            const float inv_ny = 1.0f / (float)ny;
+            const float inv_ny = __builtin_amdgcn_rcpf((float)ny);  // (1 ulp; (r + 0.5) / ny stays 0.5 / ny away from an integer)
             auto gap_of = [&](float v, int c, int dim, float org) {  // (boundary cells of the grid are open-ended)
                 return fmaxf(fmaxf((c == 0 ? -__builtin_inff() : org + c * g.h) - v,
                                    v - (c == dim - 1 ? __builtin_inff() : org + (c + 1) * g.h)) - slack, 0.f);
@@ -705,7 +707,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         auto keep_below = [&](unsigned int, unsigned long long key, bool in) {
             const bool pass = in && key < tkey;
             const unsigned long long mask = __ballot(pass);
-            const unsigned int slot = scnt + (unsigned int)__popcll(mask & lt_mask);
+            const unsigned int slot = lanes_below(mask, scnt);
             if (pass && slot < (unsigned int)CAP) L.cand[slot] = key;
             scnt += (unsigned int)__popcll(mask);
         };
@@ -732,7 +734,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 const bool pass = c < count && bucket_of(key, scale1) <= bstar;
                 const unsigned long long mask = __ballot(pass);
                 wave_lds_sync();
-                if (pass) L.cand[scnt + (unsigned int)__popcll(mask & lt_mask)] = key;
+                if (pass) L.cand[lanes_below(mask, scnt)] = key;
                 scnt += (unsigned int)__popcll(mask);
                 wave_lds_sync();
             }
@@ -740,7 +742,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         // ---- the bound path (every query of a run but the first)
         if (run_r >= 0.f) {
             const float sx = qx - pqx, sy = qy - pqy, sz = qz - pqz;
-            const float sep = sqrtf((sx * sx + sy * sy) + sz * sz);
+            const float sep = __builtin_amdgcn_sqrtf((sx * sx + sy * sy) + sz * sz);  // (1 ulp: the factor below covers it)
             const float rb = (run_r + sep) * 1.00001f + slack;  // radius that holds `want` references
             const float tau = rb * rb;
             const float rbox = rb * 1.00001f + slack;  // (cells that can hold a reference with d2 <= tau: as the ball pass below)
@@ -767,7 +769,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                         } else if (scnt > SCAP && scnt <= (unsigned int)CAP) {
                             // more than the sort takes, all of them kept (the buffer's second half is free until the sort): the
                             // buckets of the full path's pass 1 over [0, tau] on the stored keys cut them at the `want`-th's bucket
-                            const float sc = (float)BUCKET_N / tau;
+                            const float sc = (float)BUCKET_N * __builtin_amdgcn_rcpf(tau);  // (any scale serves, the bound below takes the same one)
                             L.bk[1 + 2 * lane] = 0u;
                             L.bk[2 + 2 * lane] = 0u;
                             wave_lds_sync();
@@ -798,7 +800,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
             const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
             const int ny = y1 - y0 + 1, nrow = ny * (z1 - z0 + 1);
-            const float inv_ny = 1.0f / (float)ny;
+            const float inv_ny = __builtin_amdgcn_rcpf((float)ny);  // (1 ulp; (r + 0.5) / ny stays 0.5 / ny away from an integer)
             unsigned int mine = 0;
 #pragma unroll
             for (int i = 0; i < RL; ++i) {
@@ -851,7 +853,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             auto keep = [&](unsigned int, unsigned long long key, bool in) {
                 const bool pass = in && bucket_of(key, scale1) <= bstar;
                 const unsigned long long mask = __ballot(pass);
-                const unsigned int slot = scnt + (unsigned int)__popcll(mask & lt_mask);
+                const unsigned int slot = lanes_below(mask, scnt);
                 if (pass && slot < SCAP) L.cand[slot] = key;
                 scnt += (unsigned int)__popcll(mask);
             };
@@ -888,7 +890,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         }  // (the full path)
         {
             // ---- the survivors in order: finer buckets over [0, bound]; a crowded bucket (equal distances) -> the network
-            const float scale2 = (float)BUCKET_N / bound;
+            const float scale2 = (float)BUCKET_N * __builtin_amdgcn_rcpf(bound);  // (an ordering only: any scale serves)
             unsigned long long* tmp = L.cand + SCAP;
             bool in_order = scnt < 2;
             if (!in_order) {
@@ -920,7 +922,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             }
             // the next query of the run starts from this one's K-th distance (a full row only: `want` == K real neighbours)
             if (want == K && !key_none(kth)) {
-                prev_r = sqrtf(__uint_as_float((unsigned int)(kth >> 32)));
+                prev_r = __builtin_amdgcn_sqrtf(__uint_as_float((unsigned int)(kth >> 32)));
                 pqx = qx; pqy = qy; pqz = qz;
             }
         }
@@ -1221,7 +1223,6 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
     // scalar loads and scalar address arithmetic)
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const unsigned int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float bscale = (float)BUCKET_N / r2;
     // The per-query header (query index, packed query, two row offsets) is a chain of two dependent loads at the head of a
     // chain of five more (bounds, windows) -- and the kernel waits most of its time.  It is fetched one query ahead instead:
@@ -1295,7 +1296,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 const unsigned int incl = wave_incl_scan_add(cnt);
                 const unsigned long long occ = __ballot(cnt != 0);
                 if (cnt) {
-                    const unsigned int slot = nspans + (unsigned int)__popcll(occ & lt_mask);
+                    const unsigned int slot = lanes_below(occ, nspans);
                     const unsigned int off = total + incl - cnt;
                     tab_s[slot] = s0;
                     tab_o[slot] = off;
@@ -1365,7 +1366,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                         const bool hit = c[u] < total && d < r2;
                         const unsigned long long key = make_key(d, r4[u]);
                         const unsigned long long mask = __ballot(hit);
-                        const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
+                        const unsigned int slot = lanes_below(mask, written);
                         if (!COUNT && hit) {
                             if (in_lds) { if (slot < ROW_LDS_MAX) stage[slot] = key; }
                             else if (slot < row_len) keys[row_beg + slot] = key;
@@ -1399,7 +1400,7 @@ k_grid_radius_fill_wave(const float4* __restrict__ cell_refs, const unsigned int
                 }
                 const unsigned long long mask = __ballot(hit);
                 // (a fill can only find what the count found -- same arithmetic --; the bound is belt and braces)
-                const unsigned int slot = written + (unsigned int)__popcll(mask & lt_mask);
+                const unsigned int slot = lanes_below(mask, written);
                 if (!COUNT && hit && slot < (in_lds ? ROW_LDS_MAX : row_len)) row_out[slot] = key;
                 written += (unsigned int)__popcll(mask);
             }
