@@ -565,6 +565,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
     const unsigned int nruns = (ns + KNN_RUN - 1) / KNN_RUN;
     for (unsigned int run = wave; run < nruns; run += nwaves) {  // wave-uniform
     float prev_r = -1.f, pqx = 0.f, pqy = 0.f, pqz = 0.f;  // K-th distance (not squared) and position of the run's previous query; < 0: none
+    int prev_k = 1;  // half-width the sizing rounds start from: where the run's previous full-path query ended
     for (unsigned int t = run * KNN_RUN; t < min(ns, (run + 1u) * KNN_RUN); ++t) {
         const unsigned int qi = order[t];
         const float4 qv = q[qi];
@@ -791,11 +792,12 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         if (!by_bound) {
         // the smallest cube that holds at least 2 x `want` points (as k_grid_knn_wave).  A lane looks after rows `lane` and
         // `lane + 64` of the cube (11 x 11 rows at most): the bounds it reads for the count ARE the spans of pass 1
-        // (round 6, measured and removed: starting one below the cube of the wave's previous query instead of at 3 x 3 x 3 --
-        // K = 51 at 1M 1154 / 1140 us against 1155 / 1156: the sizing rounds are not what the kernel waits for, EXPERIMENTS.md)
-        int k = 1;
+        // The rounds start from the half-width the run's previous full-path query ended with (one round instead of two or three; a
+        // cube that came out too large for the buffers starts over from 3 x 3 x 3)
+        constexpr unsigned int CUBE_MAX = STORE ? (unsigned int)CAP : SEL_FLAT_CAP;
+        int k = prev_k;
         unsigned int cnt = 0, rs0[RL], rc[RL];
-        for (;; ++k) {
+        for (bool from_prev = k > 1;; ++k) {
             const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dim[0] - 1);
             const int y0 = max(cy - k, 0), y1 = min(cy + k, g.dim[1] - 1);
             const int z0 = max(cz - k, 0), z1 = min(cz + k, g.dim[2] - 1);
@@ -816,9 +818,17 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
                 mine += rc[i];
             }
             cnt = (unsigned int)__builtin_amdgcn_readlane((int)wave_incl_scan_add(mine), 63);
+            if (from_prev && cnt > CUBE_MAX) {
+                from_prev = false;
+                k = 0;
+                continue;
+            }
+            from_prev = false;
             if (cnt >= 2u * (unsigned int)want || k >= KSEL) break;  // (the table's rows)
         }
-        if (cnt < (unsigned int)want || cnt > (STORE ? (unsigned int)CAP : SEL_FLAT_CAP)) { give_up(); continue; }
+        // (a cube with several times the points it needs: the next query tries one smaller)
+        prev_k = cnt >= 6u * (unsigned int)want && k > 1 ? k - 1 : k;
+        if (cnt < (unsigned int)want || cnt > CUBE_MAX) { give_up(); continue; }
         x0 = max(cx - k, 0); x1 = min(cx + k, g.dim[0] - 1);
         y0 = max(cy - k, 0); y1 = min(cy + k, g.dim[1] - 1);
         z0 = max(cz - k, 0); z1 = min(cz + k, g.dim[2] - 1);
@@ -826,7 +836,7 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
         // ---- pass 1: every candidate of the cube kept, d2 counted into buckets over the cube's d2 range
         {
             const float reach = (float)(k + 1) * g.h;
-            const float scale1 = (float)BUCKET_N / (3.03f * reach * reach);
+            const float span1 = 3.03f * reach * reach, scale1 = (float)BUCKET_N / span1;
             table_reset();
 #pragma unroll
             for (int i = 0; i < RL; ++i)
@@ -846,7 +856,8 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             unsigned int bstar, s1;  // the bucket that holds the `want`-th; cube candidates with bucket <= b*
             find_bstar(bstar, s1);
             if (bstar >= BUCKET_N - 1 || s1 > SCAP) { give_up(); continue; }
-            bound = (float)(bstar + 1) / scale1 * 1.00001f;  // every d2 >= bound has a bucket > b*
+            // every d2 >= bound has a bucket > b* (span1 / BUCKET_N is 1 / scale1 to an ulp: the factor covers it, no division)
+            bound = (float)(bstar + 1) * (span1 * (1.0f / (float)BUCKET_N)) * 1.00001f;
             // the kept keys with bucket <= b* to the front of the buffer
             scnt = 0;
             // a window's keys with bucket <= b* appended to the survivors
@@ -867,7 +878,8 @@ k_grid_knn_sel(const float4* __restrict__ cell_refs, const unsigned int* __restr
             const float lb2 = outside_bound2(ux, uy, uz, x0, x1, y0, y1, z0, z1, g, slack);
             bool fits = true;
             if (!(bound < lb2)) {
-                const float rb = sqrtf(bound) * 1.00001f + slack;
+                // (hardware sqrt, 1 ulp, no denormals: a bound below 1e-30 is taken as 1e-30 -- larger, so still covering)
+                const float rb = __builtin_amdgcn_sqrtf(fmaxf(bound, 1.0e-30f)) * 1.00001f + slack;
                 int a0, a1, b0, b1, e0, e1;
                 cell_range(ux, rb, g.org[0], g.inv_h, g.dim[0], a0, a1);
                 cell_range(uy, rb, g.org[1], g.inv_h, g.dim[1], b0, b1);
