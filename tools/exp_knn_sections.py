@@ -28,3 +28,5 @@ print(f"{scene} {n} K={K}: wave time by section (one call; {cnt[0]} queries)")
 for i in (0, 10, 1, 2, 3, 4, 5, 6, 7, 8, 9):
     if cnt[i]:
         print(f"  {NAMES[i]:36s} {100.0 * cyc[i] / tot:5.1f} %   entered {cnt[i]:8d} times ({100.0 * cnt[i] / max(cnt[0], 1):5.1f} % of queries)   {cyc[i] / cnt[i]:8.0f} ticks each")
+if cnt[4]:
+    print(f"  full path: cube candidates {cyc[11] / cnt[4]:6.1f} per query, final half-width {cnt[11] / cnt[4]:4.2f} on average")
