@@ -8,7 +8,7 @@ ARCH       ?= gfx950
 HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -Iinclude -Ipointcloudcomparator_amd/csrc
 CSRC       := pointcloudcomparator_amd/csrc
 LIBDIR     := pointcloudcomparator_amd/lib
-HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/normals.hip $(CSRC)/region.hip $(CSRC)/sac.hip $(CSRC)/flann_order.hip $(CSRC)/cellsort_mp.hip $(CSRC)/comm.hip)
+HIP_SRCS   := $(CSRC)/api.hip $(CSRC)/pack.hip $(CSRC)/nn1_brute.hip $(CSRC)/grid.hip $(CSRC)/cellsort.hip $(wildcard $(CSRC)/knn.hip $(CSRC)/cluster.hip $(CSRC)/icp.hip $(CSRC)/voxel.hip $(CSRC)/normals.hip $(CSRC)/region.hip $(CSRC)/sac.hip $(CSRC)/flann_order.hip $(CSRC)/cellsort_mp.hip $(CSRC)/comm.hip $(CSRC)/small.hip)
 HDRS       := $(wildcard $(CSRC)/*.hpp) include/pcc_nn.h
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 

@@ -186,7 +186,10 @@ enum pcc_option {
                                     through two pinned chunk buffers by a few host threads (PCC_HOST_THREADS, default half the
                                     cores, at most 8), the DMA of a chunk running while the next is gathered; only x, y, z cross
                                     the link when the stride is 24 bytes or more (default); 0 = one hipMemcpyAsync of the raw
-                                    array.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) is always copied directly */
+                                    array.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) is always copied directly.
+                                    Also the SMALL host calls (clouds and results up to 1 MB): 1 = kernels read the cloud from, and write
+                                    the results into, the handle's pinned buffers, and a k = 1 query call against up to 4096
+                                    exhaustively searched points is one launch; 0 = copies and the separate launches */
     PCC_OPT_SCAN_CHAINED = 22,   /* exclusive scans inside the sorts: 1 = one launch, workgroups hand their totals forward through tagged
                                     64-bit atomics (default); 0 = two launches (totals, then apply) that wait for nothing -- for
                                     environments where workgroups are not dispatched in order (preemption, shared devices) */

@@ -271,6 +271,54 @@ static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) 
 
 
 // k = 1 search of ix->q_packed[0..nq) into ix->out_packed (u64 per query)
+// The small-call form (small.hip): host queries against a small exhaustively searched cloud -- the reference's descriptor
+// matching.  PCC_OPT_HOST_PIPE = 0 keeps the separate launches (pack, preset, search, unpack).
+static bool small_call(const pcc_index* ix, size_t nq, size_t stride, int mem) {
+    return mem == PCC_MEM_HOST && ix->opt.host_pipe && ix->engine == PCC_ENGINE_BRUTE && ix->n_orig <= SMALL_FUSED_REFS && nq > 0 &&
+           (nq - 1) * stride + 12 <= SMALL_DIRECT_BYTES && nq * sizeof(float) <= SMALL_RESULT_BYTES;
+}
+// queries to the pinned buffer, one launch, one wait; the results are in host_a (indices) and host_b (squared distances).
+// PCC_TIES_FLANN: the kernel also counts the queries whose minimum is shared by a second reference; only if there are any does the
+// tie replay (a kd-tree of FLANN's shape over the indexed cloud, flann_order.hip) run, on the q_packed / out_packed the kernel left
+static int small_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, bool want_idx, bool want_d2) {
+    const bool flann = ix->tie_mode == PCC_TIES_FLANN;
+    const size_t nblk = (nq + 63) / 64;
+    PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
+    PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
+    PCC_TRY(ix->host_a.reserve((nq + nblk) * sizeof(int32_t)));  // (+ the tie count of every workgroup)
+    PCC_TRY(ix->host_b.reserve(nq * sizeof(float)));
+    if (!ix->pipe) ix->pipe = new HostPipe();
+    PCC_TRY(ix->pipe->init());
+    PCC_HIP(hipEventSynchronize(ix->pipe->ev[1]));  // (whoever read the query buffer last has finished)
+    memcpy(ix->pipe->buf[1].p, q, (nq - 1) * stride + 12);
+    ix->fb_zeroed = false;
+    ix->q_cells_n = 0;
+    ix->stats[0] = 0;
+    ix->stats[1] = nq;
+    ix->stats_pending = false;
+    unsigned int* tie_blocks = flann ? reinterpret_cast<unsigned int*>(ix->host_a.as<int32_t>() + nq) : nullptr;
+    ev_mark(ix, EV_MAIN0);
+    PCC_TRY(launch_small_nn1(ix->stream, ix->pipe->buf[1].p, nq, stride, ix->refs.as<float4>(), ix->n_orig, ix->q_packed.as<float4>(),
+                             ix->out_packed.as<unsigned long long>(), want_idx || flann ? ix->host_a.as<int32_t>() : nullptr,
+                             want_d2 ? ix->host_b.as<float>() : nullptr, tie_blocks));
+    ev_mark(ix, EV_MAIN1);
+    ev_mark(ix, EV_CALL1);
+    // (the wait below is also what lets the next call overwrite the pinned query buffer: no event is recorded for it)
+    PCC_HIP(hipStreamSynchronize(ix->stream));
+    if (flann) {
+        unsigned int tied = 0;
+        for (size_t b = 0; b < nblk; ++b) tied += tie_blocks[b];
+        ix->ties_pending = false;
+        ix->ties_flagged = ix->ties_changed = 0;
+        if (tied) {
+            PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq));
+            PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, nq, ix->host_a.as<int32_t>(), nullptr));
+            PCC_HIP(hipStreamSynchronize(ix->stream));
+        }
+    }
+    return PCC_OK;
+}
+
 int nn1_packed(pcc_index* ix, size_t nq) {
     PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
     auto* out = ix->out_packed.as<unsigned long long>();
@@ -305,7 +353,8 @@ static int set_input_impl(pcc_index* ix, const void* pts, size_t n, size_t strid
     int nblk = 0;
     PCC_TRY(ix->seeds.reserve(((n + PCC_SEED_STRIDE - 1) / PCC_SEED_STRIDE) * sizeof(float4)));  // the pack kernel also emits the seed subset
     PackGrid pg{};
-    const bool fused = (ix->opt.fuse_params & 1) != 0;
+    // (small clouds: a launch is what a call costs there, and the fence the fused form pays is nothing over a handful of rows)
+    const bool fused = (ix->opt.fuse_params & 1) != 0 || (ix->opt.host_pipe && n <= SMALL_FUSED_POINTS);
     if (fused) PCC_TRY(grid_params_fused(ix, &pg));
     PCC_TRY(stage_points(ix, pts, n, stride, mem, ix->q_raw, ix->refs.as<float4>(), ix->blk_stats.as<float>(), &nblk,
                          nullptr, ix->seeds.as<float4>(), nullptr, nullptr, nullptr, fused ? &pg : nullptr));
@@ -756,6 +805,12 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
     if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
+    if (small_call(ix, nq, stride, mem)) {
+        PCC_TRY(small_nn1(ix, q, nq, stride, idx != nullptr, d2 != nullptr));
+        if (idx) memcpy(idx, ix->host_a.p, nq * sizeof(int32_t));
+        if (d2) memcpy(d2, ix->host_b.p, nq * sizeof(float));
+        return PCC_OK;
+    }
     {
         PrepOverlap beside(ix);
         if (PrepOverlap::wanted(ix, nq)) PCC_TRY(beside.begin());
@@ -1607,17 +1662,21 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
     if (ix->n_orig == 0) { set_error("index is empty"); return PCC_ERR_EMPTY; }
     ev_next(ix);
     ev_mark(ix, EV_CALL0);
-    PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
-    PCC_TRY(nn1_packed(ix, n2));
-    if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), n2));
-    // (the unpack kernel writes the result arrays into pinned host memory itself: no copy command, one wait)
-    PCC_TRY(ix->host_a.reserve(n2 * sizeof(int32_t)));
-    PCC_TRY(ix->host_b.reserve(n2 * sizeof(float)));
+    if (small_call(ix, n2, stride, mem)) {
+        PCC_TRY(small_nn1(ix, des2, n2, stride, true, true));
+    } else {
+        PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
+        PCC_TRY(nn1_packed(ix, n2));
+        if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), n2));
+        // (the unpack kernel writes the result arrays into pinned host memory itself: no copy command, one wait)
+        PCC_TRY(ix->host_a.reserve(n2 * sizeof(int32_t)));
+        PCC_TRY(ix->host_b.reserve(n2 * sizeof(float)));
+        PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n2, ix->host_a.as<int32_t>(), ix->host_b.as<float>()));
+        ev_mark(ix, EV_CALL1);
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+    }
     const int32_t* hi = ix->host_a.as<int32_t>();
     const float* hd = ix->host_b.as<float>();
-    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, n2, ix->host_a.as<int32_t>(), ix->host_b.as<float>()));
-    ev_mark(ix, EV_CALL1);
-    PCC_HIP(hipStreamSynchronize(ix->stream));
     int32_t c = 1;
     for (size_t i = 0; i < n2; ++i)  // neighborCount == 1 && squaredDistances[0] < threshold (:579)
         if (hi[i] >= 0 && hd[i] < threshold) out[c++] = hi[i];

@@ -363,6 +363,13 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
                      size_t n, unsigned long long* out, const unsigned int* qlist,
                      const unsigned int* qcount_dev, size_t qcount_max, bool idx_from_w = false);
 
+// ---- small-call form (small.hip): the query side of a k = 1 call in one launch -- raw host-pinned queries in, (idx, d2) out into
+// pinned host memory, q_packed / out_packed written as the separate launches would
+int launch_small_nn1(hipStream_t s, const void* raw_q, size_t nq, size_t stride, const float4* refs, size_t n, float4* q_packed,
+                     unsigned long long* out_packed, int32_t* idx, float* d2, unsigned int* tie_blocks);  // tie_blocks: PCC_TIES_FLANN, one word per 64 queries
+constexpr size_t SMALL_FUSED_REFS = 4096;    // indexed clouds up to here take it (PCC_ENGINE_AUTO's exhaustive range)
+constexpr size_t SMALL_FUSED_POINTS = 8192;  // indexed clouds up to here: the grid parameters come from the pack kernel's last workgroup
+
 // ---- grid.hip --------------------------------------------------------------------------
 int grid_params(pcc_index* ix, const float* blk_stats_dev, int n_blocks);  // async: d_grid + pinned mirror
 int grid_params_fused(pcc_index* ix, PackGrid* pg);                        // the same from inside the pack kernel: fills *pg for launch_pack

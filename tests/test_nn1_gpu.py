@@ -398,3 +398,89 @@ def test_large_host_clouds_cross_pcie_through_the_pinned_pipe(gpu, floats):
     oi, od = oracle.KdTree(a[:, :3]).nn1_batch(np.ascontiguousarray(b[sel[:-1], :3]))
     assert (_bits(res[1][1][sel[:-1]]) == _bits(od)).all() and (res[1][0][sel[:-1]] == oi).all()
     assert res[1][0][n - 1] == -1 and np.isinf(res[1][1][n - 1])
+
+
+def _records(pts, floats):
+    """the points as records of `floats` floats (the first three are x, y, z; the rest is payload that must never be read)"""
+    rec = np.full((len(pts), floats), np.nan, dtype=np.float32)
+    rec[:, :3] = pts
+    return rec
+
+
+@pytest.mark.parametrize("floats", [3, 4, 32])
+@pytest.mark.parametrize("m,n", [(1, 1), (4, 4), (100, 100), (63, 65), (1000, 777), (4096, 2500), (4095, 64), (17, 8000)])
+def test_small_calls_take_one_launch_and_the_same_bits(gpu, floats, m, n):
+    """The reference's descriptor matching (src/comparator.cpp:560-588): small host clouds, 128-byte records.  Up to 4096 indexed
+    points the query side of a host call is ONE launch (small.hip) -- against the oracle, and against the separate launches
+    (PCC_OPT_HOST_PIPE = 0) bit for bit; non-finite queries and references, either output alone, and pcc_match_knn on top."""
+    if floats == 32 and (n - 1) * 128 + 12 > (1 << 20):
+        pytest.skip("beyond the pinned small-call buffer: the staged path, covered elsewhere")
+    rng = np.random.default_rng(m * 131 + n)
+    a = synth.corridor_cloud(m, synth.SEED_A)
+    b = synth.corridor_cloud(n, synth.SEED_B)
+    if m >= 100:
+        a[rng.integers(0, m, 5)] = np.nan
+        a[m - 1, 1] = np.inf
+        a[7] = a[3]  # an exact tie: the lower index wins
+    if n >= 64:
+        b[0, 0] = np.nan
+        b[63, 2] = -np.inf
+        b[n - 1, 1] = np.nan
+        b[5] = a[3]
+    ra, rb = _records(a, floats), _records(b, floats)
+    oi, od = oracle.nn1_exhaustive(a, b)
+    with capi.Index(ra) as ix:  # PCC_ENGINE_AUTO: exhaustive below 4096 points
+        idx, d2 = ix.nn1(rb)
+        assert (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+        only_i = np.full(n, 12345, dtype=np.int32)
+        capi._check(capi.LIB.pcc_nn1(ix._h, rb.ctypes.data, n, rb.strides[0], capi.MEM_HOST, only_i.ctypes.data, None))
+        assert (only_i == oi).all()
+        only_d = np.full(n, 7.0, dtype=np.float32)
+        capi._check(capi.LIB.pcc_nn1(ix._h, rb.ctypes.data, n, rb.strides[0], capi.MEM_HOST, None, only_d.ctypes.data))
+        assert (_bits(only_d) == _bits(od)).all()
+        got = ix.match_knn(rb, 0.05)
+        want = [0] + [int(i) for i, d in zip(oi, od) if i >= 0 and d < np.float32(0.05)]
+        assert list(got) == want
+        # FLANN's tie order: the kernel counts the tied queries; none -> the call is complete, some -> the replay on what it left
+        fi, fd = oracle.KdTree(a).nn1_batch(b)
+        ix.set_tie_order(capi.TIES_FLANN)
+        ix.set_input(ra)
+        idx_f, d2_f = ix.nn1(rb)
+        st = ix.stats()
+        assert (idx_f == fi).all() and (_bits(d2_f) == _bits(fd)).all()
+        assert st[6] == (fi != oi).sum() and st[5] >= st[6]
+        ix.set_tie_order(capi.TIES_LOWEST_INDEX)
+        ix.set_option(capi.OPT_HOST_PIPE, 0)
+        ix.set_input(ra)
+        idx0, d20 = ix.nn1(rb)
+        assert (idx0 == idx).all() and (_bits(d20) == _bits(d2)).all()
+        assert list(ix.match_knn(rb, 0.05)) == want
+        # the handle is left as the separate launches leave it: a device-side consumer of the same index goes on working
+        ix.set_option(capi.OPT_HOST_PIPE, 1)
+        ix.set_input(ra)
+        ix.nn1(rb)
+        if m >= 100:
+            ki, kd = ix.knn(rb[:50], 3)
+            oki, okd = oracle.knn_exhaustive(a, b[:50], 3)
+            assert (ki == oki).all() and (_bits(kd) == _bits(okd)).all()
+
+
+def test_small_calls_with_one_valid_reference_and_overflow(gpu):
+    """all references but one non-finite: that one answers every query; distances that overflow: nothing found (as the
+    exhaustive kernel); a cloud without any finite point is refused at creation, as PCL refuses an empty tree"""
+    a = np.full((50, 3), np.nan, dtype=np.float32)
+    b = synth.corridor_cloud(70, synth.SEED_B)
+    with pytest.raises(capi.PccError):
+        capi.Index(a)
+    a[31] = [1.0, 1.0, 1.0]
+    with capi.Index(a) as ix:
+        idx, d2 = ix.nn1(b)
+        oi, od = oracle.nn1_exhaustive(a, b)
+        assert (idx == 31).all() and (idx == oi).all() and (_bits(d2) == _bits(od)).all()
+        a2 = np.zeros((10, 3), dtype=np.float32)
+        ix.set_input(a2)
+        far = np.full((70, 3), 3e20, dtype=np.float32)
+        far[1] = [1.0, 2.0, 3.0]
+        idx, d2 = ix.nn1(far)
+        oi, od = oracle.nn1_exhaustive(a2, far)
+        assert (idx == oi).all() and (_bits(d2) == _bits(od)).all() and idx[0] == -1 and idx[1] == 0

@@ -39,6 +39,19 @@ for n in sizes:
             got = call()
             ok = mode != capi.TIES_FLANN or (len(got) == len(want) and (got == want).all())
             row.append(f"pipe {pipe} ties {'flann ' if mode else 'lowest'} {per_call(call):8.1f} us{'' if ok else ' MISMATCH'}")
+    # descriptors without exact ties (continuous values): PCC_TIES_FLANN then needs no replay -- the kernel counts no tied query
+    c1 = rng.random((n, 32), dtype=np.float32)
+    c2 = np.ascontiguousarray(c1[rng.permutation(n)] + rng.random((n, 32), dtype=np.float32) * np.float32(0.01), dtype=np.float32)
+    ix.set_option(capi.OPT_HOST_PIPE, 1)
+    ix.set_tie_order(capi.TIES_FLANN)
+
+    def call_c():
+        ix.set_input(c1)
+        return ix.match_knn(c2)
+    got = call_c()
+    wantc = oracle.match_rift_knn(c1, c2)
+    okc = len(got) == len(wantc) and (got == wantc).all()
+    row.append(f"pipe 1 ties flann, tie-free data {per_call(call_c):8.1f} us{'' if okc else ' MISMATCH'}")
     cpu = per_call(lambda: oracle.match_rift_knn(d1, d2))
     print(f"n = {n:6d}: " + "  |  ".join(row) + f"  |  cpu oracle {cpu:8.1f} us", flush=True)
 ix.close()
