@@ -822,7 +822,8 @@ int pcc_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, int mem, int
         }
     }
     PCC_TRY(nn1_packed(ix, nq));
-    if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq));
+    if (ix->tie_mode == PCC_TIES_FLANN)
+        PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq, mem == PCC_MEM_HOST));
     int32_t* didx = idx;
     float* dd2 = d2;
     // small host results: the unpack kernel writes them into pinned host memory itself (no copy command, one wait)
@@ -1667,7 +1668,7 @@ int pcc_match_knn(pcc_index* ix, const void* des2, size_t n2, size_t stride, int
     } else {
         PCC_TRY(stage_queries(ix, des2, n2, stride, mem));
         PCC_TRY(nn1_packed(ix, n2));
-        if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), n2));
+        if (ix->tie_mode == PCC_TIES_FLANN) PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), n2, true));
         // (the unpack kernel writes the result arrays into pinned host memory itself: no copy command, one wait)
         PCC_TRY(ix->host_a.reserve(n2 * sizeof(int32_t)));
         PCC_TRY(ix->host_b.reserve(n2 * sizeof(float)));

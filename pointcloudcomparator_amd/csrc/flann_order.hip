@@ -160,9 +160,11 @@ static int ensure_tree(pcc_index* ix) {
 }
 
 // PCC_TIES_FLANN: rewrite the index part of the keys of tied queries (keys of the queries in q, nq of them)
-int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq) {
+// may_wait: the caller waits for the stream anyway (results in host memory).  Then, as long as the indexed cloud has no tree yet, the
+// number of tied queries is read back first and a call without any skips the tree altogether -- the host build is 1.3 ms for the
+// reference's largest descriptor cloud (18 381 records), per indexed cloud, i.e. per call in matchRIFTFeaturesKnn's pattern.
+int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq, bool may_wait) {
     if (nq == 0) return PCC_OK;
-    PCC_TRY(ensure_tree(ix));
     const unsigned int n = (unsigned int)nq, blocks = (n + 255) / 256;
     const unsigned int shard_cap = (blocks + PCC_TIE_SHARDS - 1) / PCC_TIE_SHARDS * 256;  // what a slice's blocks could append
     PCC_TRY(ix->tie_buf.reserve((size_t)shard_cap * PCC_TIE_SHARDS * sizeof(unsigned int) + 256));
@@ -170,6 +172,18 @@ int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys,
     unsigned int* counters = ix->small.as<unsigned int>() + PCC_TIE_CTR0;
     PCC_HIP(hipMemsetAsync(counters, 0, PCC_TIE_SHARDS * PCC_OPEN_CTR_STRIDE * 4, ix->stream));
     PCC_TRY(launch_tie_list(ix, q, keys, nq, list, counters, shard_cap));
+    if (may_wait && !ix->flann_valid) {
+        unsigned int h[PCC_TIE_SHARDS * PCC_OPEN_CTR_STRIDE];
+        PCC_HIP(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
+        PCC_HIP(hipStreamSynchronize(ix->stream));
+        unsigned int flagged = 0;
+        for (int sh = 0; sh < PCC_TIE_SHARDS; ++sh) flagged += h[sh * PCC_OPEN_CTR_STRIDE];
+        if (flagged == 0) {  // every minimum is unique: the lowest index is FLANN's answer
+            ix->ties_pending = true;  // (the counters are all zero)
+            return PCC_OK;
+        }
+    }
+    PCC_TRY(ensure_tree(ix));
     const FlannNode* nodes = ix->flann_nodes.as<FlannNode>();
     const float* leaf = ix->flann_leaf.as<float>();
     const unsigned int nv = (unsigned int)ix->flann.n_valid;

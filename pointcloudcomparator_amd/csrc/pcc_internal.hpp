@@ -420,7 +420,7 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
                   int32_t* labels_dev /* n_orig, device */, int32_t* n_clusters, int32_t* sizes, int max_sizes);
 // ---- flann_order.hip: flags[i] = 1 when another reference shares query i's minimum distance; the tied queries walked
 // through FLANN's tree on the device
-int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq);
+int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq, bool may_wait = false);
 // ---- icp.hip -----------------------------------------------------------------------------
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
 struct IcpState;

@@ -484,3 +484,25 @@ def test_small_calls_with_one_valid_reference_and_overflow(gpu):
         idx, d2 = ix.nn1(far)
         oi, od = oracle.nn1_exhaustive(a2, far)
         assert (idx == oi).all() and (_bits(d2) == _bits(od)).all() and idx[0] == -1 and idx[1] == 0
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_BRUTE, capi.ENGINE_GRID])
+def test_ties_flann_without_any_tie_skips_the_tree_and_keeps_the_answer(gpu, engine):
+    """PCC_TIES_FLANN on host data whose minima are all unique: the tied-query count is read back before the host tree is built
+    and the call ends there -- same indices as the kd-tree walk (which can only differ at ties); a later query WITH ties on the
+    same cloud then builds the tree"""
+    a = synth.corridor_cloud(18381, synth.SEED_A)
+    q = synth.corridor_cloud(5000, synth.SEED_B)
+    fi, fd = oracle.KdTree(a).nn1_batch(q)
+    li, _ = oracle.nn1_exhaustive(a, q)
+    assert (fi == li).all()  # (no tie in this pair of clouds)
+    with capi.Index(a, engine=engine) as ix:
+        ix.set_tie_order(capi.TIES_FLANN)
+        idx, d2 = ix.nn1(q)
+        st = ix.stats()
+        assert (idx == fi).all() and (_bits(d2) == _bits(fd)).all() and st[5] == 0 and st[6] == 0
+        # midpoints of pairs of references: two references at exactly the same distance wherever the midpoint is exact
+        mid = ((a[:2000].astype(np.float64) + a[1:2001].astype(np.float64)) / 2).astype(np.float32)
+        fi2, fd2 = oracle.KdTree(a).nn1_batch(mid)
+        idx2, d22 = ix.nn1(mid)
+        assert (idx2 == fi2).all() and (_bits(d22) == _bits(fd2)).all()
