@@ -742,6 +742,16 @@ def main():
                 row[key] = per_call(call)
             row["cpu_oracle_us"] = per_call(lambda: oracle.match_rift_knn(d1, d2_))
             row["gpu_over_cpu"] = row["gpu_flann_ties_us"] / row["cpu_oracle_us"]
+            # the same in FLANN's tie order on descriptors WITHOUT exact ties (continuous values): no tied query, no tie replay
+            c1_ = rng.random((n, 32), dtype=np.float32)
+            c2_ = np.ascontiguousarray(c1_[rng.permutation(n)] + rng.random((n, 32), dtype=np.float32) * np.float32(0.01), dtype=np.float32)
+
+            def call_c():
+                ix.set_input(c1_)
+                return ix.match_knn(c2_)
+            got_c, want_c = call_c(), oracle.match_rift_knn(c1_, c2_)
+            row["tie_free_matches_equal_oracle"] = bool(len(got_c) == len(want_c) and (got_c == want_c).all())
+            row["gpu_flann_tie_free_us"] = per_call(call_c)
             rows.append(row)
         ix.close()
         # C1: 10k x 10k XYZ, k = 1, host memory in and out
