@@ -198,6 +198,7 @@ static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride,
             const size_t dst_stride = stride >= 24 ? 12 : stride;
             PCC_TRY(raw.reserve(n * dst_stride + 16));
             if (!ix->pipe) ix->pipe = new HostPipe();
+            ix->small_raw_n = 0;  // (the chunk buffers are the small-call buffers: an indexed cloud's raw records do not survive this)
             PCC_TRY(ix->pipe->upload(ix->stream, static_cast<const char*>(pts), n, stride, raw.as<char>(), dst_stride));
             stride = dst_stride;
         } else if (ix->opt.host_pipe && bytes <= SMALL_DIRECT_BYTES) {
@@ -212,6 +213,7 @@ static int stage_points(pcc_index* ix, const void* pts, size_t n, size_t stride,
             PCC_HIP(hipEventSynchronize(ix->pipe->ev[slot]));  // (whoever read this buffer last has finished: nearly always true already)
             memcpy(ix->pipe->buf[slot].p, pts, bytes);
             src = ix->pipe->buf[slot].p;
+            if (slot == 0) { ix->small_raw_n = n; ix->small_raw_stride = stride; }  // (the indexed cloud's records stay there: small_tie_replay)
             PCC_TRY(launch_pack(ix->stream, src, n, stride, packed, blk_stats, n_blocks, zero_word, seeds, invalid_keys, cells, gd, grid));
             PCC_HIP(hipEventRecord(ix->pipe->ev[slot], ix->stream));
             return PCC_OK;
@@ -260,6 +262,7 @@ static int deliver(pcc_index* ix, const T* dev, T* user, size_t count, int mem) 
     if (mem == PCC_MEM_HOST) {
         if (ix->opt.host_pipe && count * sizeof(T) >= PIPE_MIN_BYTES && !host_pointer_is_pinned(user)) {
             if (!ix->pipe) ix->pipe = new HostPipe();
+            ix->small_raw_n = 0;  // (as in stage_points)
             PCC_TRY(ix->pipe->download(ix->stream, reinterpret_cast<const char*>(dev), reinterpret_cast<char*>(user), count * sizeof(T)));
         } else
         PCC_HIP(hipMemcpyAsync(user, dev, count * sizeof(T), hipMemcpyDeviceToHost, ix->stream));
@@ -285,8 +288,9 @@ static int small_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, boo
     const size_t nblk = (nq + 63) / 64;
     PCC_TRY(ix->q_packed.reserve(nq * sizeof(float4)));
     PCC_TRY(ix->out_packed.reserve(nq * sizeof(unsigned long long)));
-    PCC_TRY(ix->host_a.reserve((nq + nblk) * sizeof(int32_t)));  // (+ the tie count of every workgroup)
+    PCC_TRY(ix->host_a.reserve((nq + 2 * nblk) * sizeof(int32_t)));  // (+ per workgroup: tied queries, indices the replay changed)
     PCC_TRY(ix->host_b.reserve(nq * sizeof(float)));
+    if (flann) PCC_TRY(ix->tie_buf.reserve(nq + 64));  // (a tie flag per query)
     if (!ix->pipe) ix->pipe = new HostPipe();
     PCC_TRY(ix->pipe->init());
     PCC_HIP(hipEventSynchronize(ix->pipe->ev[1]));  // (whoever read the query buffer last has finished)
@@ -296,26 +300,40 @@ static int small_nn1(pcc_index* ix, const void* q, size_t nq, size_t stride, boo
     ix->stats[0] = 0;
     ix->stats[1] = nq;
     ix->stats_pending = false;
-    unsigned int* tie_blocks = flann ? reinterpret_cast<unsigned int*>(ix->host_a.as<int32_t>() + nq) : nullptr;
+    int32_t* hidx = ix->host_a.as<int32_t>();
+    unsigned int* tie_blocks = flann ? reinterpret_cast<unsigned int*>(hidx + nq) : nullptr;
+    unsigned char* tie_q = flann ? ix->tie_buf.as<unsigned char>() : nullptr;
     ev_mark(ix, EV_MAIN0);
     PCC_TRY(launch_small_nn1(ix->stream, ix->pipe->buf[1].p, nq, stride, ix->refs.as<float4>(), ix->n_orig, ix->q_packed.as<float4>(),
-                             ix->out_packed.as<unsigned long long>(), want_idx || flann ? ix->host_a.as<int32_t>() : nullptr,
-                             want_d2 ? ix->host_b.as<float>() : nullptr, tie_blocks));
+                             ix->out_packed.as<unsigned long long>(), want_idx || flann ? hidx : nullptr,
+                             want_d2 ? ix->host_b.as<float>() : nullptr, tie_blocks, tie_q));
     ev_mark(ix, EV_MAIN1);
     ev_mark(ix, EV_CALL1);
     // (the wait below is also what lets the next call overwrite the pinned query buffer: no event is recorded for it)
     PCC_HIP(hipStreamSynchronize(ix->stream));
-    if (flann) {
-        unsigned int tied = 0;
-        for (size_t b = 0; b < nblk; ++b) tied += tie_blocks[b];
-        ix->ties_pending = false;
-        ix->ties_flagged = ix->ties_changed = 0;
-        if (tied) {
-            PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq));
-            PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, nq, ix->host_a.as<int32_t>(), nullptr));
+    if (!flann) return PCC_OK;
+    unsigned int tied = 0;
+    for (size_t b = 0; b < nblk; ++b) tied += tie_blocks[b];
+    ix->ties_pending = false;
+    ix->ties_flagged = tied;
+    ix->ties_changed = 0;
+    if (tied == 0) return PCC_OK;
+    if (ix->small_raw_n == ix->n_orig) {
+        unsigned int* changed_blocks = tie_blocks + nblk;
+        bool done = false;
+        PCC_TRY(small_tie_replay(ix, ix->pipe->buf[0].p, nq, tie_q, hidx, changed_blocks, &done));
+        if (done) {
             PCC_HIP(hipStreamSynchronize(ix->stream));
+            for (size_t b = 0; b < nblk; ++b) ix->ties_changed += changed_blocks[b];
+            return PCC_OK;
         }
     }
+    // (the separate launches' replay: its tree build downloads the packed cloud into host_a, which may move -- the indices are
+    // unpacked again, all of them, into wherever it is afterwards; the distances in host_b stand)
+    PCC_TRY(resolve_ties_flann(ix, ix->q_packed.as<float4>(), ix->out_packed.as<unsigned long long>(), nq));
+    PCC_TRY(ix->host_a.reserve((nq + 2 * nblk) * sizeof(int32_t)));
+    PCC_TRY(launch_unpack(ix->stream, ix->out_packed.as<unsigned long long>(), nullptr, nq, ix->host_a.as<int32_t>(), nullptr));
+    PCC_HIP(hipStreamSynchronize(ix->stream));
     return PCC_OK;
 }
 
@@ -377,6 +395,7 @@ int set_input(pcc_index* ix, const void* pts, size_t n, size_t stride, int mem) 
     ix->has_grid = false;
     ix->order_valid = false;
     ix->flann_valid = false;
+    ix->small_raw_n = 0;
     ix->occ_valid = false;
     ix->q_cells_n = 0;  // (cells staged against the grid that is about to be replaced)
     ix->self_rows_k = 0;
@@ -479,6 +498,7 @@ int pcc_index_destroy(pcc_index* ix) {
             if (ix->ev[sl][k]) (void)hipEventDestroy(ix->ev[sl][k]);
     ix->host_a.release();
     ix->host_b.release();
+    ix->host_c.release();
     if (ix->pipe) { ix->pipe->release(); delete ix->pipe; ix->pipe = nullptr; }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     if (ix->h_grid) (void)hipHostFree(ix->h_grid);

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cstring>
 #include <thread>
+#include <vector>
 
 namespace pcc {
 
@@ -231,6 +232,85 @@ int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys,
     }
     PCC_HIP(hipGetLastError());
     ix->ties_pending = true;  // pcc_index_stats adds the shards up
+    return PCC_OK;
+}
+
+// ---- the small-call form ------------------------------------------------------------------------------------------------
+// one lane per query of the call; the flagged ones take k_tie_walk's walk, statement for statement
+template <int STACK>
+__global__ void __launch_bounds__(64)
+k_small_tie_walk(const FlannNode* __restrict__ nodes, const float* __restrict__ leaf_pts, FlannBox root, unsigned int n_valid,
+                 const float4* __restrict__ q, unsigned long long* __restrict__ keys, const unsigned char* __restrict__ tie_q, unsigned int nq,
+                 int32_t* __restrict__ idx_host, unsigned int* __restrict__ changed_blocks) {
+    const unsigned int i = blockIdx.x * 64u + threadIdx.x;
+    bool changed = false;
+    if (i < nq && tie_q[i]) {
+        const float4 qv = q[i];
+        const unsigned long long key = keys[i];
+        const float bd = __uint_as_float((unsigned int)(key >> 32));
+        bool unc = true;
+        int32_t fi = flann_walk_tied<24>(nodes, leaf_pts, root, n_valid, qv.x, qv.y, qv.z, bd, &unc);
+        float d2 = bd;
+        if (unc) fi = flann_walk<STACK>(nodes, leaf_pts, root, n_valid, qv.x, qv.y, qv.z, &d2);
+        if (fi >= 0 && __float_as_uint(d2) == (unsigned int)(key >> 32) && (unsigned int)fi != (unsigned int)key) {
+            keys[i] = (key & 0xffffffff00000000ull) | (unsigned int)fi;
+            idx_host[i] = fi;
+            changed = true;
+        }
+    }
+    const unsigned long long mc = __ballot(changed);
+    if (threadIdx.x == 0) changed_blocks[blockIdx.x] = (unsigned int)__popcll(mc);
+}
+
+int small_tie_replay(pcc_index* ix, const void* raw_refs, size_t nq, const unsigned char* tie_q, int32_t* idx_host,
+                     unsigned int* changed_blocks, bool* done) {
+    *done = false;
+    if (!ix->flann_valid) {
+        // FLANN's tree from the raw records the small-call path keeps in pinned memory (k_pack's finite test, k_pack's flags): no
+        // download; the flat arrays go up from a pinned staging buffer without a wait
+        const size_t n = ix->n_orig, stride = ix->small_raw_stride;
+        std::vector<float> packed(n * 4);
+        const char* raw = static_cast<const char*>(raw_refs);
+        for (size_t i = 0; i < n; ++i) {
+            const float* p = reinterpret_cast<const float*>(raw + i * stride);
+            const float x = p[0], y = p[1], z = p[2];
+            const bool fin = (x - x) == 0.0f && (y - y) == 0.0f && (z - z) == 0.0f;
+            const int32_t w = fin ? (int32_t)i : -1;
+            float* o = &packed[i * 4];
+            o[0] = fin ? x : 0.f;
+            o[1] = fin ? y : 0.f;
+            o[2] = fin ? z : 0.f;
+            memcpy(o + 3, &w, 4);
+        }
+        ix->flann.build(packed.data(), n, ix->opt.flann_split, 1);
+        if (ix->flann.depth > 128) return PCC_OK;  // (resolve_ties_flann builds it again its own way: deep trees are its business)
+        const size_t nb = ix->flann.nodes.size() * sizeof(FlannNode), lb = ix->flann.leaf_pts.size() * sizeof(float);
+        const size_t nb_al = (nb + 15) & ~(size_t)15;
+        PCC_TRY(ix->host_c.reserve(nb_al + lb + 16));
+        PCC_TRY(ix->flann_nodes.reserve(nb + 16));
+        PCC_TRY(ix->flann_leaf.reserve(lb + 16));
+        memcpy(ix->host_c.p, ix->flann.nodes.data(), nb);
+        memcpy(ix->host_c.as<char>() + nb_al, ix->flann.leaf_pts.data(), lb);
+        if (nb) PCC_HIP(hipMemcpyAsync(ix->flann_nodes.p, ix->host_c.p, nb, hipMemcpyHostToDevice, ix->stream));
+        if (lb) PCC_HIP(hipMemcpyAsync(ix->flann_leaf.p, ix->host_c.as<char>() + nb_al, lb, hipMemcpyHostToDevice, ix->stream));
+        std::vector<FlannNode>().swap(ix->flann.nodes);
+        std::vector<float>().swap(ix->flann.leaf_pts);
+        ix->flann_valid = true;  // (valid for whoever is enqueued behind the two copies; the staging buffer is not touched before the
+                                 // next set_input, and every small call ends with a wait)
+    }
+    if (ix->flann.depth > 128) return PCC_OK;
+    const unsigned int blocks = (unsigned int)((nq + 63) / 64);
+    const FlannNode* nodes = ix->flann_nodes.as<FlannNode>();
+    const float* leaf = ix->flann_leaf.as<float>();
+    const unsigned int nv = (unsigned int)ix->flann.n_valid;
+    if (ix->flann.depth <= 48)
+        hipLaunchKernelGGL(k_small_tie_walk<48>, dim3(blocks), dim3(64), 0, ix->stream, nodes, leaf, ix->flann.root, nv, ix->q_packed.as<float4>(),
+                           ix->out_packed.as<unsigned long long>(), tie_q, (unsigned int)nq, idx_host, changed_blocks);
+    else
+        hipLaunchKernelGGL(k_small_tie_walk<128>, dim3(blocks), dim3(64), 0, ix->stream, nodes, leaf, ix->flann.root, nv, ix->q_packed.as<float4>(),
+                           ix->out_packed.as<unsigned long long>(), tie_q, (unsigned int)nq, idx_host, changed_blocks);
+    PCC_HIP(hipGetLastError());
+    *done = true;
     return PCC_OK;
 }
 

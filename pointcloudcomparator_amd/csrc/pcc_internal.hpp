@@ -245,6 +245,7 @@ struct pcc_index {
     int tie_mode = PCC_TIES_LOWEST_INDEX;
     pcc::FlannTree flann;
     bool flann_valid = false;
+    size_t small_raw_n = 0, small_raw_stride = 0;  // the indexed cloud's raw records are in the pinned small-call buffer (slot 0): n, stride; 0 = not
     int self_rows_k = 0;      // self_rows holds the self k-NN rows of the indexed cloud with this many neighbours (0: nothing kept)
     pcc::DevBuf self_rows;
     bool occ_valid = false;   // occ (device word): number of non-empty cells of the current grid, counted at the first radius count
@@ -260,6 +261,7 @@ struct pcc_index {
     uint64_t ties_flagged = 0, ties_changed = 0;  // of the last search in FLANN mode
     void* pinned = nullptr;  // small pinned host block for scalar read-backs
     pcc::HostBuf host_a, host_b;  // large pinned read-back buffers
+    pcc::HostBuf host_c;          // pinned staging of the FLANN tree a small call builds (flann_order.hip)
     pcc::HostPipe* pipe = nullptr;  // two pinned chunk buffers + events, made at the first large host transfer (api.hip)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // HIP-event instrumentation (pcc_index_enable_timing): event pairs on the index's stream
@@ -366,7 +368,7 @@ int launch_nn1_brute(hipStream_t s, const float4* refs, size_t m, const float4* 
 // ---- small-call form (small.hip): the query side of a k = 1 call in one launch -- raw host-pinned queries in, (idx, d2) out into
 // pinned host memory, q_packed / out_packed written as the separate launches would
 int launch_small_nn1(hipStream_t s, const void* raw_q, size_t nq, size_t stride, const float4* refs, size_t n, float4* q_packed,
-                     unsigned long long* out_packed, int32_t* idx, float* d2, unsigned int* tie_blocks);  // tie_blocks: PCC_TIES_FLANN, one word per 64 queries
+                     unsigned long long* out_packed, int32_t* idx, float* d2, unsigned int* tie_blocks, unsigned char* tie_q);  // PCC_TIES_FLANN: tied queries per 64 (pinned) and a flag per query (device)
 constexpr size_t SMALL_FUSED_REFS = 4096;    // indexed clouds up to here take it (PCC_ENGINE_AUTO's exhaustive range)
 constexpr size_t SMALL_FUSED_POINTS = 8192;  // indexed clouds up to here: the grid parameters come from the pack kernel's last workgroup
 
@@ -421,6 +423,12 @@ int grid_clusters(pcc_index* ix, float r, float r2, uint32_t min_size, uint32_t 
 // ---- flann_order.hip: flags[i] = 1 when another reference shares query i's minimum distance; the tied queries walked
 // through FLANN's tree on the device
 int resolve_ties_flann(pcc_index* ix, const float4* q, unsigned long long* keys, size_t nq, bool may_wait = false);
+// The small-call form of the replay (small.hip has flagged the tied queries, tie_q[i] != 0, and the indexed cloud's raw records are
+// still in the pinned buffer): tree built from those records, uploaded without a wait, ONE launch walks the flagged queries and
+// writes the changed indices into idx_host (pinned) and their number per 64 queries into changed_blocks (pinned).  *done = false:
+// the tree is deeper than the device walk takes, nothing was enqueued (the caller takes resolve_ties_flann).
+int small_tie_replay(pcc_index* ix, const void* raw_refs, size_t nq, const unsigned char* tie_q, int32_t* idx_host,
+                     unsigned int* changed_blocks, bool* done);
 // ---- icp.hip -----------------------------------------------------------------------------
 // per-workgroup partial sums (17 doubles each) of the matched pairs; returns #blocks written
 struct IcpState;

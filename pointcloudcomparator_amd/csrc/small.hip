@@ -23,12 +23,13 @@ constexpr int SMALL_WAVES = 16;  // waves of a workgroup: each takes a sixteenth
 // TIES (PCC_TIES_FLANN): a query whose minimum distance is shared by a second reference is TIED -- FLANN's tree walk may return
 // another index than the lowest (flann_order.hip).  The kernel counts the tied queries of every workgroup into tie_blocks[] (pinned
 // host memory); with none anywhere -- real descriptors: exact float ties are rare -- the lowest index IS FLANN's answer and the call
-// is complete; otherwise the caller replays the ties on q_packed / out_packed as after the separate launches.
+// is complete; otherwise the flagged queries (tie_q[], device memory) are walked through FLANN's tree by one more launch
+// (flann_order.hip: small_tie_replay), or the caller replays the ties on q_packed / out_packed as after the separate launches.
 template <bool TIES>
 __global__ void __launch_bounds__(SMALL_WAVES * 64)
 k_small_nn1(const char* __restrict__ raw_q, unsigned int nq, size_t stride, const float4* __restrict__ refs, unsigned int n,
             float4* __restrict__ q_packed, unsigned long long* __restrict__ out_packed, int32_t* __restrict__ idx,
-            float* __restrict__ d2, unsigned int* __restrict__ tie_blocks) {
+            float* __restrict__ d2, unsigned int* __restrict__ tie_blocks, unsigned char* __restrict__ tie_q) {
     __shared__ float4 sq[64];
     __shared__ unsigned long long sk[SMALL_WAVES][64];
     __shared__ unsigned char st[SMALL_WAVES][64];
@@ -84,8 +85,10 @@ k_small_nn1(const char* __restrict__ raw_q, unsigned int nq, size_t stride, cons
             const unsigned long long k = sk[w][lane];
             tied = tied || ((unsigned int)(k >> 32) == (unsigned int)(key >> 32) && (k != key || st[w][lane] != 0));
         }
-        const unsigned long long m = __ballot(tied && ok && i < nq);
+        tied = tied && ok && i < nq;
+        const unsigned long long m = __ballot(tied);
         if (lane == 0) tie_blocks[blockIdx.x] = (unsigned int)__popcll(m);
+        if (i < nq) tie_q[i] = tied ? 1 : 0;
     }
     if (i >= nq) return;
     out_packed[i] = key;
@@ -94,15 +97,15 @@ k_small_nn1(const char* __restrict__ raw_q, unsigned int nq, size_t stride, cons
 }
 
 int launch_small_nn1(hipStream_t s, const void* raw_q, size_t nq, size_t stride, const float4* refs, size_t n, float4* q_packed,
-                     unsigned long long* out_packed, int32_t* idx, float* d2, unsigned int* tie_blocks) {
+                     unsigned long long* out_packed, int32_t* idx, float* d2, unsigned int* tie_blocks, unsigned char* tie_q) {
     if (nq == 0) return PCC_OK;
     const dim3 wg((unsigned int)((nq + 63) / 64)), th(SMALL_WAVES * 64);
     if (tie_blocks)
         hipLaunchKernelGGL(k_small_nn1<true>, wg, th, 0, s, static_cast<const char*>(raw_q), (unsigned int)nq, stride, refs, (unsigned int)n,
-                           q_packed, out_packed, idx, d2, tie_blocks);
+                           q_packed, out_packed, idx, d2, tie_blocks, tie_q);
     else
         hipLaunchKernelGGL(k_small_nn1<false>, wg, th, 0, s, static_cast<const char*>(raw_q), (unsigned int)nq, stride, refs, (unsigned int)n,
-                           q_packed, out_packed, idx, d2, tie_blocks);
+                           q_packed, out_packed, idx, d2, tie_blocks, tie_q);
     PCC_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -506,3 +506,50 @@ def test_ties_flann_without_any_tie_skips_the_tree_and_keeps_the_answer(gpu, eng
         fi2, fd2 = oracle.KdTree(a).nn1_batch(mid)
         idx2, d22 = ix.nn1(mid)
         assert (idx2 == fi2).all() and (_bits(d22) == _bits(fd2)).all()
+
+
+@pytest.mark.parametrize("m,n", [(4, 4), (100, 100), (1000, 777), (4096, 2000)])
+def test_small_calls_replay_flann_ties_on_the_device(gpu, m, n):
+    """lattice descriptors (duplicates, exact ties everywhere) in FLANN's tie order through the small-call form: the search kernel
+    flags the tied queries, the tree is built from the raw records the call still holds in pinned memory, one more launch walks
+    the flagged queries -- against the kd-tree walk of the oracle; again on the same index (the tree is kept), under another split
+    rule (it is rebuilt), and after a large host query has gone through the same pinned buffers (the records are gone: the
+    replay of the separate launches takes over)"""
+    rng = np.random.default_rng(m + 7)
+    a = (rng.integers(0, 9, (m, 3)) * np.float32(0.125)).astype(np.float32)
+    q = (rng.integers(0, 17, (n, 3)) * np.float32(0.0625)).astype(np.float32)
+    if n >= 100:
+        q[3] = np.nan
+    ra, rq = _records(a, 32), _records(q, 32)
+    fi, fd = oracle.KdTree(a).nn1_batch(q)
+    li, ld = oracle.nn1_exhaustive(a, q)
+    assert m < 100 or (fi != li).sum() > 5
+    with capi.Index(ra) as ix:
+        ix.set_tie_order(capi.TIES_FLANN)
+        for _ in range(2):
+            idx, d2 = ix.nn1(rq)
+            st = ix.stats()
+            assert (idx == fi).all(), np.nonzero(idx != fi)[0][:5]
+            assert (_bits(d2) == _bits(fd)).all()
+            assert st[6] == (fi != li).sum() and st[5] >= st[6]
+        got = ix.match_knn(rq, 0.05)
+        assert list(got) == [0] + [int(i) for i, d in zip(fi, fd) if i >= 0 and d < np.float32(0.05)]
+        oracle.set_split_rule(1)
+        try:
+            f1, _ = oracle.KdTree(a).nn1_batch(q)
+        finally:
+            oracle.set_split_rule(0)
+        ix.set_option(capi.OPT_FLANN_SPLIT, 1)
+        assert (ix.nn1(rq)[0] == f1).all()
+        ix.set_option(capi.OPT_FLANN_SPLIT, 0)
+        assert (ix.nn1(rq)[0] == fi).all()
+        if m == 1000:
+            big = synth.corridor_cloud(800_000, synth.SEED_B)      # 9.6 MB: staged through the pinned chunk buffers
+            bi, bd = ix.nn1(big)
+            obi, obd = oracle.KdTree(a).nn1_batch(big)
+            assert (bi == obi).all() and (_bits(bd) == _bits(obd)).all()
+            ix.set_option(capi.OPT_FLANN_SPLIT, 1)                   # (a new tree is needed, and the raw records are gone)
+            assert (ix.nn1(rq)[0] == f1).all()
+            ix.set_input(ra)
+            ix.set_option(capi.OPT_FLANN_SPLIT, 0)
+            assert (ix.nn1(rq)[0] == fi).all()
