@@ -5,6 +5,7 @@
 // L2_Simple<float>.  Reference call sites: src/comparator.cpp:576-580 (the indices matchRIFTFeaturesKnn hands on).
 #include "pcc_internal.hpp"
 #include "grid_device.hpp"
+#include <algorithm>
 #include <cfloat>
 #include <cstring>
 #include <thread>
@@ -146,7 +147,8 @@ static int ensure_tree(pcc_index* ix) {
     PCC_HIP(hipStreamSynchronize(ix->stream));
     unsigned int threads = std::thread::hardware_concurrency();
     threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
-    ix->flann.build(ix->host_a.as<float>(), ix->n_orig, ix->opt.flann_split, ix->n_orig >= 50000 ? threads : 1);
+    // (threads: the build forks at its top levels while a side holds more than 4096 points; 18 381 records 1.3 -> 0.55 ms with four)
+    ix->flann.build(ix->host_a.as<float>(), ix->n_orig, ix->opt.flann_split, ix->n_orig >= 50000 ? threads : (ix->n_orig >= 6000 ? std::min(threads, 4u) : 1u));
     PCC_TRY(ix->flann_nodes.reserve(ix->flann.nodes.size() * sizeof(FlannNode) + 16));
     PCC_TRY(ix->flann_leaf.reserve(ix->flann.leaf_pts.size() * sizeof(float) + 16));
     PCC_HIP(hipMemcpyAsync(ix->flann_nodes.p, ix->flann.nodes.data(), ix->flann.nodes.size() * sizeof(FlannNode), hipMemcpyHostToDevice, ix->stream));
